@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- cell-updates/s of NonhydrostaticModel time_step! (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1: BASELINE config 2 -- 256^3 triply-periodic RectilinearGrid, WENO5 (Z weights), AB2, Float64,
+no tracers; u, v, w ~ U[-0.5, 0.5) (PCG64 seed 1), projected by set!; fixed dt = 0.2 dx / max|u|.
+N > 1: one process per GPU (torch.distributed.run), z-slab decomposition of (256, 256, 256 N) --
+weak scaling, RCCL halo exchange + transposed FFT inside libocnhip.so.
+
+One JSON line is printed by rank 0.  `value` is whole-job cell-updates/s with all inputs resident in
+HBM when the timed region starts.  `roofline` is for the dominant kernel (measured live with HIP
+events on the library's stream); `cpu_baseline` is the NumPy oracle timed on this host (rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+# algorithmic bytes per cell: whole AB2 step and per phase
+B_ALG_STEP = 336.0
+B_ALG_PHASE = {"tendencies": 48.0, "step": 96.0, "rhs": 32.0, "fft_forward": 48.0, "spectral_solve": 16.0,
+               "fft_backward": 48.0, "pcorrect": 56.0, "fused_tendency_step": 96.0, "poisson_fused": 80.0}
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """oracle (NumPy restatement of the reference algorithm) on a bounded sample of the same workload."""
+    import oracle as O
+    n = 64
+    N = (n, n, n)
+    rng = np.random.default_rng(1)
+    g = O.RectilinearGrid(size=N, extent=(1, 1, 1), topology=(O.Periodic,) * 3)
+    m = O.NonhydrostaticModel(g, advection=O.WENO5())
+    O.set_model(m, u=rng.random(N) - 0.5, v=rng.random(N) - 0.5, w=rng.random(N) - 0.5)
+    dt = 0.2 / n / np.abs(m.u.data).max()
+    O.time_step(m, dt)   # warm-up (Euler step)
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 3 or (time.perf_counter() - t0 < seconds_budget and steps < 40):
+        O.time_step(m, dt)
+        steps += 1
+    el = time.perf_counter() - t0
+    return {"value": n ** 3 * steps / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} AB2 WENO5 steps at {n}^3 (same workload, 1/64 of the cells), NumPy oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, nargs=3, default=None, help="override per-GPU size (debug)")
+    ap.add_argument("--stepper", default="AB2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    os.environ.pop("OCNHIP_LIB", None)      # the product library only
+    import __graft_entry__ as ge
+    ocn = ge.load_package()                 # loads libocnhip.so before anything touches torch
+    ocn._lib.load()
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("gloo")     # rendezvous / barriers / max-reduce only; data path is RCCL in the library
+
+    n = tuple(args.size) if args.size else (256, 256, 256)
+    ctx = ocn.Context(local_rank)
+    if world > 1:
+        from importlib import import_module
+        par = import_module("ocnhip.parallel")
+        par.init_comm(ctx, dist, rank, world)
+    Nglobal = (n[0], n[1], n[2] * world)
+    grid = ocn.RectilinearGrid(ctx, size=Nglobal, extent=(1, 1, float(world)), topology=("Periodic",) * 3)
+    model = ocn.NonhydrostaticModel(grid, advection=ocn.WENO5(), timestepper=args.stepper)
+    rng = np.random.default_rng(1 + rank)
+    local = model.u.size
+    ocn.set_model(model, u=rng.random(local) - 0.5, v=rng.random(local) - 0.5, w=rng.random(local) - 0.5)
+    umax = np.abs(model.u.interior()).max()
+    if dist is not None:
+        import torch
+        t = torch.tensor([umax], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        umax = float(t[0])
+    dt = 0.2 * (1.0 / n[0]) / umax
+
+    for _ in range(args.warmup):
+        ocn.time_step(model, dt)
+    ctx.sync()
+    ctx.profile(True)
+    ctx.profile_reset()
+    if dist is not None:
+        dist.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ocn.time_step(model, dt)
+    ctx.sync()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    ctx.profile(False)
+    if dist is not None:
+        import torch
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t[0])
+
+    div = model.max_abs_divergence()
+    cells = Nglobal[0] * Nglobal[1] * Nglobal[2]
+    ms = el / args.steps * 1e3
+    value = cells * args.steps / el
+
+    phases = {}
+    for ph in list(B_ALG_PHASE) + ["fill_halos", "store", "copy_pressure", "time_step", "halo_exchange", "transpose"]:
+        avg, cnt = ctx.profile_read(ph)
+        if cnt:
+            phases[ph] = {"avg_ms": avg, "launches": cnt}
+    cells_local = n[0] * n[1] * n[2]
+    cand = {p: v for p, v in phases.items() if p in B_ALG_PHASE}
+    dom = max(cand, key=lambda p: cand[p]["avg_ms"] * cand[p]["launches"]) if cand else None
+    roofline = None
+    if dom:
+        ach = B_ALG_PHASE[dom] * cells_local / (cand[dom]["avg_ms"] * 1e-3)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK, "traffic": None,
+                    "alg_bytes_per_launch": B_ALG_PHASE[dom] * cells_local, "avg_launch_ms": cand[dom]["avg_ms"]}
+    step_frac = value / world * B_ALG_STEP / HBM_PEAK
+
+    if rank == 0:
+        out = {
+            "metric": "cell-updates/sec per time_step!, 256^3 Nonhydrostatic WENO5", "value": value,
+            "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} triply-periodic RectilinearGrid, "
+                                   f"NonhydrostaticModel WENO5(zweno) + FFT Poisson, {args.stepper}, halo 3, no tracers",
+                       "decomposition": f"z-slabs x{world}", "dt": dt},
+            "roofline": roofline,
+            "step_roofline": {"alg_bytes_per_cell_update": B_ALG_STEP, "frac_of_hbm_peak": step_frac},
+            "phases_ms": {k: round(v["avg_ms"], 4) for k, v in phases.items()},
+            "max_abs_divergence": div,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

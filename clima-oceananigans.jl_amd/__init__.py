@@ -1,0 +1,16 @@
+"""ocnhip: MI355X-native `time_step!` for Oceananigans' NonhydrostaticModel (host-side mirror).
+
+The reference is Julia; no Julia toolchain exists in the build image, so the host side above the
+C ABI (include/ocnhip.h) is this thin Python mirror of the reference's constructors and verbs:
+``RectilinearGrid``, ``NonhydrostaticModel``, ``set_model`` (= ``set!``), ``time_step`` (= ``time_step!``),
+``update_state``, ``fill_halo_regions`` ... with the reference's names, argument meaning and error
+behaviour.  The Julia `ROCmGPU` shim a maintainer would add is in INTEGRATION.md / julia/ROCmGPU.jl.
+All numerical work happens in libocnhip.so (hand-written HIP for gfx950 + hipFFT/rocFFT + RCCL).
+"""
+from .api import (Context, RectilinearGrid, NonhydrostaticModel, Periodic, Bounded, Flat, Center, Face,  # noqa: F401
+                  WENO5, CenteredSecondOrder, CenteredFourthOrder, UpwindBiasedFifthOrder, ScalarDiffusivity,
+                  AnisotropicMinimumDissipation, FPlane, BuoyancyTracer, SeawaterBuoyancy,
+                  FluxBC, ValueBC, GradientBC, time_step, set_model, update_state, OcnError)
+from . import _lib  # noqa: F401
+
+__all__ = ["Context", "RectilinearGrid", "NonhydrostaticModel", "time_step", "set_model"]

@@ -1,0 +1,120 @@
+"""ctypes binding of libocnhip.so (the C ABI declared in include/ocnhip.h).
+
+The library is the product: if it is missing this module raises -- there is no CPU fallback.
+``OCNHIP_LIB`` may point at another build of the *same sources* (tests/hostemu sets it to the
+host-emulation build so that kernels can be exercised on a machine without a GPU; see
+csrc/compat.h).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_TRACERS = 8
+
+# enums (include/ocnhip.h)
+PERIODIC, BOUNDED, FLAT = 0, 1, 2
+CENTER, FACE = 0, 1
+ADV_NONE, ADV_C2, ADV_C4, ADV_U5, ADV_WENO5_Z, ADV_WENO5_JS = range(6)
+STEPPER_AB2, STEPPER_RK3 = 0, 1
+CLOSURE_NONE, CLOSURE_SCALAR, CLOSURE_AMD = 0, 1, 2
+BUOYANCY_NONE, BUOYANCY_TRACER, BUOYANCY_LINEAR_TS = 0, 1, 2
+BC_DEFAULT, BC_PERIODIC, BC_NOFLUX, BC_FLUX, BC_VALUE, BC_GRADIENT, BC_IMPENETRABLE, BC_NONE = range(8)
+WEST, EAST, SOUTH, NORTH, BOTTOM, TOP = range(6)
+F_U, F_V, F_W, F_PHY, F_PNHS, F_GN, F_GM, F_TRACER, F_NU, F_KAPPA = 0, 1, 2, 3, 4, 16, 32, 48, 64, 72
+
+ERRORS = {-1: "OCN_EINVAL", -2: "OCN_ENOMEM", -3: "OCN_EHIP", -4: "OCN_EUNSUPPORTED", -5: "OCN_ESTATE"}
+
+
+class GridDesc(C.Structure):
+    _fields_ = [("N", C.c_int32 * 3), ("H", C.c_int32 * 3), ("topology", C.c_int32 * 3),
+                ("x0", C.c_double * 3), ("L", C.c_double * 3), ("z_faces", C.POINTER(C.c_double)),
+                ("rank", C.c_int32), ("nranks", C.c_int32)]
+
+
+class BC(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("value", C.c_double), ("array", C.POINTER(C.c_double))]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("advection", C.c_int32), ("stepper", C.c_int32), ("chi", C.c_double),
+                ("n_tracers", C.c_int32), ("closure", C.c_int32), ("nu", C.c_double),
+                ("kappa", C.c_double * MAX_TRACERS), ("amd_Cnu", C.c_double),
+                ("amd_Ckappa", C.c_double * MAX_TRACERS), ("coriolis_fplane", C.c_int32), ("f", C.c_double),
+                ("buoyancy", C.c_int32), ("b_index", C.c_int32), ("T_index", C.c_int32), ("S_index", C.c_int32),
+                ("g", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
+                ("bcs", (BC * 6) * (3 + MAX_TRACERS))]
+
+
+class OcnError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path():
+    return os.environ.get("OCNHIP_LIB") or os.path.join(HERE, "libocnhip.so")
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise OcnError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(path)
+    P, I, D = C.c_void_p, C.c_int, C.c_double
+    PD = C.POINTER(C.c_double)
+    sig = {
+        "ocn_abi_version": (I, []),
+        "ocn_init": (I, [I, C.POINTER(P)]),
+        "ocn_destroy": (None, [P]),
+        "ocn_sync": (I, [P]),
+        "ocn_last_error": (C.c_char_p, [P]),
+        "ocn_stream": (P, [P]),
+        "ocn_grid_create": (I, [P, C.POINTER(GridDesc), C.POINTER(P)]),
+        "ocn_grid_destroy": (None, [P]),
+        "ocn_model_create": (I, [P, C.POINTER(ModelDesc), C.POINTER(P)]),
+        "ocn_model_destroy": (None, [P]),
+        "ocn_model_halo": (I, [P, C.POINTER(C.c_int32 * 3)]),
+        "ocn_field_shape": (I, [P, I, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32 * 3)]),
+        "ocn_field_device_ptr": (P, [P, I]),
+        "ocn_field_upload": (I, [P, I, PD]),
+        "ocn_field_download": (I, [P, I, PD]),
+        "ocn_field_set_interior": (I, [P, I, PD]),
+        "ocn_field_get_interior": (I, [P, I, PD]),
+        "ocn_fill_halos": (I, [P, C.c_uint32]),
+        "ocn_update_state": (I, [P]),
+        "ocn_compute_tendencies": (I, [P]),
+        "ocn_ab2_step": (I, [P, D, D]),
+        "ocn_rk3_substep": (I, [P, D, D, D, I]),
+        "ocn_store_tendencies": (I, [P]),
+        "ocn_pressure_correction": (I, [P, D]),
+        "ocn_poisson_solve_host": (I, [P, PD, PD]),
+        "ocn_pressure_correct_velocities": (I, [P, D]),
+        "ocn_set_epilogue": (I, [P, I]),
+        "ocn_time_step": (I, [P, D, I]),
+        "ocn_clock": (I, [P, PD, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+        "ocn_set_clock": (I, [P, D, C.c_int64, D]),
+        "ocn_max_abs_divergence": (I, [P, PD]),
+        "ocn_comm_unique_id": (I, [P]),
+        "ocn_comm_init": (I, [P, I, I, P]),
+        "ocn_comm_rank": (I, [P, C.POINTER(I), C.POINTER(I)]),
+        "ocn_profile_enable": (I, [P, I]),
+        "ocn_profile_read": (I, [P, C.c_char_p, PD, C.POINTER(C.c_int64)]),
+        "ocn_profile_reset": (I, [P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)   # AttributeError here = the library does not export what the header declares
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    _lib._signatures = sig
+    return _lib
+
+
+def check(rc, ctx=None):
+    if rc != 0:
+        msg = load().ocn_last_error(ctx).decode(errors="replace")
+        raise OcnError(f"{ERRORS.get(rc, rc)}: {msg}")

@@ -1,0 +1,749 @@
+// api.hip -- the C ABI of include/ocnhip.h: handles, memory, and the stream-ordered orchestration of
+// time_step! (TimeSteppers/quasi_adams_bashforth_2.jl:70-104, runge_kutta_3.jl:81-152).
+#include <cstdarg>
+
+#include "internal.h"
+
+#ifdef OCN_HOST_EMU
+thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+emu_barrier g_emu_barrier;
+#endif
+
+static char g_last_error[512] = {0};
+
+void ocn_set_error(ocn_ctx* ctx, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+  if (ctx) memcpy(ctx->err, g_last_error, sizeof(g_last_error));
+}
+
+// ---- profiling -------------------------------------------------------------------------------------------
+ProfScope::ProfScope(ocn_ctx* ctx, const char* nm) : c(ctx), name(nm) {
+  if (!c->profiling) return;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  hipEventRecord(a, c->stream);
+}
+ProfScope::~ProfScope() {
+  if (!c->profiling || !a) return;
+  hipEventRecord(b, c->stream);
+  c->prof[name].ev.emplace_back(a, b);
+}
+static void prof_collect(ocn_ctx* c) {
+  hipStreamSynchronize(c->stream);
+  for (auto& kv : c->prof) {
+    for (auto& e : kv.second.ev) {
+      float ms = 0;
+      hipEventElapsedTime(&ms, e.first, e.second);
+      kv.second.total_ms += ms;
+      kv.second.count += 1;
+      hipEventDestroy(e.first);
+      hipEventDestroy(e.second);
+    }
+    kv.second.ev.clear();
+  }
+}
+
+extern "C" {
+
+int ocn_abi_version(void) { return OCN_ABI_VERSION; }
+
+const char* ocn_last_error(ocn_ctx* ctx) { return ctx ? ctx->err : g_last_error; }
+
+int ocn_init(int device_id, ocn_ctx** out) {
+  if (!out) return OCN_EINVAL;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    ocn_set_error(nullptr, "no HIP device available (hipGetDeviceCount)");
+    return OCN_EHIP;
+  }
+  if (device_id < 0 || device_id >= n) {
+    ocn_set_error(nullptr, "device %d out of range (%d devices)", device_id, n);
+    return OCN_EINVAL;
+  }
+  ocn_ctx* c = new ocn_ctx;
+  c->device = device_id;
+  OCN_HIP_CHECK(nullptr, hipSetDevice(device_id));
+  OCN_HIP_CHECK(nullptr, hipStreamCreate(&c->stream));
+  *out = c;
+  return OCN_OK;
+}
+
+void ocn_destroy(ocn_ctx* ctx) {
+  if (!ctx) return;
+  prof_collect(ctx);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int ocn_sync(ocn_ctx* ctx) {
+  if (!ctx) return OCN_EINVAL;
+  OCN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  OCN_HIP_CHECK(ctx, hipGetLastError());
+  return OCN_OK;
+}
+
+void* ocn_stream(ocn_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int ocn_profile_enable(ocn_ctx* ctx, int on) {
+  if (!ctx) return OCN_EINVAL;
+  if (!on) prof_collect(ctx);
+  ctx->profiling = on != 0;
+  return OCN_OK;
+}
+int ocn_profile_reset(ocn_ctx* ctx) {
+  if (!ctx) return OCN_EINVAL;
+  prof_collect(ctx);
+  ctx->prof.clear();
+  return OCN_OK;
+}
+int ocn_profile_read(ocn_ctx* ctx, const char* phase, double* avg_ms, int64_t* count) {
+  if (!ctx || !phase) return OCN_EINVAL;
+  prof_collect(ctx);
+  auto it = ctx->prof.find(phase);
+  if (it == ctx->prof.end() || it->second.count == 0) {
+    if (avg_ms) *avg_ms = 0;
+    if (count) *count = 0;
+    return OCN_OK;
+  }
+  if (avg_ms) *avg_ms = it->second.total_ms / it->second.count;
+  if (count) *count = it->second.count;
+  return OCN_OK;
+}
+
+// ---- grid ---------------------------------------------------------------------------------------------------
+// stretched-axis spacings incl. halos: Grids/grid_generation.jl:28-75 (Bounded and Periodic variants)
+static void stretched_spacings(const std::vector<double>& Fi, int N, int H, bool bounded, std::vector<double>& dzc,
+                               std::vector<double>& dzf) {
+  std::vector<double> dm(H), dp(H);
+  for (int i = 1; i <= H; ++i) {
+    if (bounded) {
+      dm[i - 1] = Fi[1] - Fi[0];
+      dp[i - 1] = Fi[N] - Fi[N - 1];
+    } else {
+      dm[i - 1] = Fi[N - H + i] - Fi[N - H + i - 1];
+      dp[i - 1] = Fi[i] - Fi[i - 1];
+    }
+  }
+  std::vector<double> dpr(dp.rbegin(), dp.rend());
+  std::vector<double> F;
+  for (int i = 0; i < H; ++i) {
+    double s = 0;
+    for (int q = i; q < H; ++q) s += dm[q];
+    F.push_back(Fi[0] - s);
+  }
+  for (int i = 0; i <= N; ++i) F.push_back(Fi[i]);
+  std::vector<double> Fp;
+  for (int i = 0; i < H; ++i) {
+    double s = 0;
+    for (int q = i; q < H; ++q) s += dpr[q];
+    Fp.push_back(Fi[N] + s);
+  }
+  for (int i = H - 1; i >= 0; --i) F.push_back(Fp[i]);
+  int TC = N + 2 * H;
+  int TF = bounded ? N + 1 + 2 * H : N + 2 * H;
+  std::vector<double> C(TC);
+  for (int i = 0; i < TC; ++i) C[i] = (F[i + 1] + F[i]) / 2;
+  std::vector<double> dF;
+  for (int i = 1; i < TC; ++i) dF.push_back(C[i] - C[i - 1]);
+  F.resize(TF);
+  dzc.resize(TF - 1);
+  for (int i = 0; i < TF - 1; ++i) dzc[i] = F[i + 1] - F[i];
+  std::vector<double> d2;
+  d2.push_back(dF.front());
+  for (double x : dF) d2.push_back(x);
+  d2.push_back(dF.back());
+  for (int i = (int)d2.size() - 1; i >= 1; --i) d2[i] = d2[i - 1];
+  dzf = d2;
+  // make sure kernels can index dzc[k+H] for k in [-H, N+H] and dzf[k+H+1] for k in [-H-1, N+H]
+  while ((int)dzc.size() < N + 2 * H + 1) dzc.push_back(dzc.back());
+  while ((int)dzf.size() < N + 2 * H + 2) dzf.push_back(dzf.back());
+}
+
+static int grid_build_dev(ocn_grid* g) {
+  GridDev& d = g->dev;
+  memset(&d, 0, sizeof(d));
+  d.Nx = g->N[0]; d.Ny = g->N[1]; d.Nz = g->N[2];
+  d.Hx = g->H[0]; d.Hy = g->H[1]; d.Hz = g->H[2];
+  d.sy = d.Nx + 2 * d.Hx;
+  d.sz = d.sy * (d.Ny + 2 * d.Hy);
+  // regular axes: L/N (grid_generation.jl:84; the reference rounds a BigFloat quotient once)
+  d.dx = (double)((long double)g->L[0] / g->N[0]);
+  d.dy = (double)((long double)g->L[1] / g->N[1]);
+  d.rdx = 1.0 / d.dx;
+  d.rdy = 1.0 / d.dy;
+  d.zb = g->topo[2] == OCN_BOUNDED;
+  d.zflat = g->topo[2] == OCN_FLAT;
+  d.dz = d.zflat ? 1.0 : (double)((long double)g->L[2] / g->N[2]);
+  hipFree(g->d_dzc);
+  hipFree(g->d_dzf);
+  g->d_dzc = g->d_dzf = nullptr;
+  if (!g->z_regular) {
+    stretched_spacings(g->zF_int, g->N[2], g->H[2], g->topo[2] == OCN_BOUNDED, g->h_dzc, g->h_dzf);
+    OCN_HIP_CHECK(g->ctx, hipMalloc((void**)&g->d_dzc, g->h_dzc.size() * sizeof(double)));
+    OCN_HIP_CHECK(g->ctx, hipMalloc((void**)&g->d_dzf, g->h_dzf.size() * sizeof(double)));
+    OCN_HIP_CHECK(g->ctx, hipMemcpy(g->d_dzc, g->h_dzc.data(), g->h_dzc.size() * sizeof(double), hipMemcpyHostToDevice));
+    OCN_HIP_CHECK(g->ctx, hipMemcpy(g->d_dzf, g->h_dzf.data(), g->h_dzf.size() * sizeof(double), hipMemcpyHostToDevice));
+    d.dzc = g->d_dzc;
+    d.dzf = g->d_dzf;
+  }
+  return OCN_OK;
+}
+
+int ocn_grid_create(ocn_ctx* ctx, const ocn_grid_desc* desc, ocn_grid** out) {
+  if (!ctx || !desc || !out) return OCN_EINVAL;
+  for (int d = 0; d < 3; ++d) {
+    if (desc->N[d] < 1 || desc->H[d] < 0) {
+      ocn_set_error(ctx, "invalid size/halo in direction %d", d);
+      return OCN_EINVAL;
+    }
+    if (desc->topology[d] < OCN_PERIODIC || desc->topology[d] > OCN_FLAT) return OCN_EINVAL;
+  }
+  if (desc->topology[0] != OCN_PERIODIC || desc->topology[1] != OCN_PERIODIC) {
+    ocn_set_error(ctx, "only (Periodic, Periodic, *) topologies are supported: Bounded/Flat x or y needs the "
+                       "cosine-transform solver (SURVEY section 8f, rank 2)");
+    return OCN_EUNSUPPORTED;
+  }
+  ocn_grid* g = new ocn_grid;
+  g->ctx = ctx;
+  g->d = *desc;
+  for (int d = 0; d < 3; ++d) {
+    g->N[d] = desc->N[d];
+    g->H[d] = desc->H[d];
+    g->topo[d] = desc->topology[d];
+    g->L[d] = desc->L[d];
+    g->x0[d] = desc->x0[d];
+  }
+  if (g->topo[2] == OCN_FLAT) {
+    g->N[2] = 1;
+    g->H[2] = 0;
+    g->L[2] = 1.0;
+  }
+  g->z_regular = desc->z_faces == nullptr;
+  if (!g->z_regular) {
+    if (g->topo[2] == OCN_FLAT) return OCN_EINVAL;
+    g->zF_int.assign(desc->z_faces, desc->z_faces + g->N[2] + 1);
+    for (int k = 0; k < g->N[2]; ++k)
+      if (!(g->zF_int[k + 1] > g->zF_int[k])) {
+        ocn_set_error(ctx, "z_faces must be strictly increasing");
+        delete g;
+        return OCN_EINVAL;
+      }
+    g->L[2] = g->zF_int[g->N[2]] - g->zF_int[0];
+    g->x0[2] = g->zF_int[0];
+    if (g->topo[2] == OCN_PERIODIC) {
+      ocn_set_error(ctx, "a stretched Periodic z axis has no pressure solver in the reference either "
+                         "(NonhydrostaticModels.jl:18-27)");
+      delete g;
+      return OCN_EUNSUPPORTED;
+    }
+  }
+  for (int d = 0; d < 3; ++d)
+    if (g->topo[d] != OCN_FLAT && !(g->L[d] > 0)) {
+      ocn_set_error(ctx, "extent must be positive in direction %d", d);
+      delete g;
+      return OCN_EINVAL;
+    }
+  int rc = grid_build_dev(g);
+  if (rc) {
+    delete g;
+    return rc;
+  }
+  *out = g;
+  return OCN_OK;
+}
+
+void ocn_grid_destroy(ocn_grid* g) {
+  if (!g) return;
+  hipFree(g->d_dzc);
+  hipFree(g->d_dzf);
+  delete g;
+}
+
+}  // extern "C"
+
+// ---- fields ---------------------------------------------------------------------------------------------------
+double* Field::interior() const { return d + Hx + Hy * sy + Hz * sz; }
+
+static int field_alloc(ocn_model* m, Field& f, int lx, int ly, int lz) {
+  ocn_grid* g = m->g;
+  f.loc[0] = lx; f.loc[1] = ly; f.loc[2] = lz;
+  for (int d = 0; d < 3; ++d) {
+    int loc = f.loc[d];
+    if (g->topo[d] == OCN_FLAT) f.T[d] = g->N[d];
+    else if (loc == OCN_FACE && g->topo[d] == OCN_BOUNDED) f.T[d] = g->N[d] + 1 + 2 * g->H[d];
+    else f.T[d] = g->N[d] + 2 * g->H[d];
+  }
+  f.n = (size_t)f.T[0] * f.T[1] * f.T[2];
+  f.sy = f.T[0];
+  f.sz = (long)f.T[0] * f.T[1];
+  f.Hx = g->H[0]; f.Hy = g->H[1]; f.Hz = g->H[2];
+  OCN_HIP_CHECK(m->ctx, hipMalloc((void**)&f.d, f.n * sizeof(double)));
+  OCN_HIP_CHECK(m->ctx, hipMemsetAsync(f.d, 0, f.n * sizeof(double), m->ctx->stream));
+  f.present = true;
+  for (int s = 0; s < 6; ++s) f.bc[s] = BCdev{OCN_BC_NONE, 0.0, nullptr};
+  return OCN_OK;
+}
+
+// default boundary conditions (BoundaryConditions/field_boundary_conditions.jl:13-35)
+static void default_bcs(ocn_model* m, Field& f, bool auxiliary) {
+  for (int d = 0; d < 3; ++d) {
+    int kind;
+    int topo = m->g->topo[d];
+    if (topo == OCN_PERIODIC) kind = OCN_BC_PERIODIC;
+    else if (topo == OCN_FLAT) kind = OCN_BC_NONE;
+    else if (f.loc[d] == OCN_CENTER) kind = OCN_BC_NOFLUX;
+    else kind = auxiliary ? OCN_BC_NONE : OCN_BC_IMPENETRABLE;
+    f.bc[2 * d] = BCdev{kind, 0.0, nullptr};
+    f.bc[2 * d + 1] = BCdev{kind, 0.0, nullptr};
+  }
+}
+
+Field* model_field(ocn_model* m, int id) {
+  Field* f = nullptr;
+  if (id == OCN_F_U) f = &m->u;
+  else if (id == OCN_F_V) f = &m->v;
+  else if (id == OCN_F_W) f = &m->w;
+  else if (id == OCN_F_PHY) f = &m->pHY;
+  else if (id == OCN_F_PNHS) f = &m->pNHS;
+  else if (id >= OCN_F_GN && id < OCN_F_GN + 3 + m->nt) f = &m->Gn[id - OCN_F_GN];
+  else if (id >= OCN_F_GM && id < OCN_F_GM + 3 + m->nt) f = &m->Gm[id - OCN_F_GM];
+  else if (id >= OCN_F_TRACER && id < OCN_F_TRACER + m->nt) f = &m->tr[id - OCN_F_TRACER];
+  else if (id == OCN_F_NU) f = &m->nu_e;
+  else if (id >= OCN_F_KAPPA && id < OCN_F_KAPPA + m->nt) f = &m->kappa_e[id - OCN_F_KAPPA];
+  if (f && !f->present) return nullptr;
+  return f;
+}
+
+// ---- halo fills (fill_halo_regions.jl:34-102): Bounded z first, then the periodic directions ------------
+static void fill_fields(ocn_model* m, Field** fs, int n) {
+  if (n == 0) return;
+  ProfScope ps(m->ctx, "fill_halos");
+  const GridDev& g = m->gd;
+  if (g.zb)
+    for (int i = 0; i < n; ++i) launch_fill_z_bounded(m, *fs[i]);
+  FieldPtrs F;
+  F.n = n;
+  for (int i = 0; i < n; ++i) {
+    F.p[i] = fs[i]->d;
+    F.Tz[i] = fs[i]->T[2];
+  }
+  // Julia's insertion sort with the non-strict `fill_first` comparator visits all-periodic directions in
+  // the order z, y, x; for periodic fills over full parent extents any order gives the same halos.
+  if (m->g->topo[2] == OCN_PERIODIC) launch_fill_periodic(m, F, 2);
+  launch_fill_periodic(m, F, 1);
+  launch_fill_periodic(m, F, 0);
+}
+
+static void fill_velocities_tracers(ocn_model* m, bool tracers) {
+  Field* fs[OCN_NF];
+  int n = 0;
+  fs[n++] = &m->u;
+  fs[n++] = &m->v;
+  fs[n++] = &m->w;
+  if (tracers)
+    for (int t = 0; t < m->nt; ++t) fs[n++] = &m->tr[t];
+  fill_fields(m, fs, n);
+}
+
+static int update_state(ocn_model* m) {
+  // update_nonhydrostatic_model_state.jl:14-37
+  fill_velocities_tracers(m, true);
+  if (m->d.closure == OCN_CLOSURE_AMD) {
+    launch_amd(m);
+    Field* fs[OCN_NF];
+    int n = 0;
+    fs[n++] = &m->nu_e;
+    for (int t = 0; t < m->nt; ++t) fs[n++] = &m->kappa_e[t];
+    fill_fields(m, fs, n);
+  }
+  launch_hydrostatic(m);
+  if (m->pHY.present && m->d.buoyancy != OCN_BUOYANCY_NONE) {
+    Field* fs[1] = {&m->pHY};
+    fill_fields(m, fs, 1);
+  }
+  return OCN_OK;
+}
+
+static int pressure_correction(ocn_model* m, double dt) {
+  // pressure_correction.jl:10-23
+  fill_velocities_tracers(m, false);
+  int rc = poisson_solve(m, dt);
+  if (rc) return rc;
+  Field* fs[1] = {&m->pNHS};
+  fill_fields(m, fs, 1);
+  return OCN_OK;
+}
+
+static void zero_Gm(ocn_model* m) {
+  for (int f = 0; f < 3 + m->nt; ++f) hipMemsetAsync(m->Gm[f].d, 0, m->Gm[f].n * sizeof(double), m->ctx->stream);
+}
+
+static int time_step_ab2(ocn_model* m, double dt, int force_euler) {
+  // quasi_adams_bashforth_2.jl:70-104
+  bool euler = force_euler || (dt != m->previous_dt);
+  double chi = euler ? -0.5 : m->d.chi;
+  if (euler) zero_Gm(m);
+  m->previous_dt = dt;
+  if (m->iteration == 0) update_state(m);
+  launch_tendencies(m);
+  launch_step(m, dt, 1.5 + chi, -(0.5 + chi), 1);
+  int rc = pressure_correction(m, dt);
+  if (rc) return rc;
+  launch_pcorrect(m, dt);
+  launch_store(m);
+  m->time += dt;
+  m->iteration += 1;
+  m->stage = 1;
+  return update_state(m);
+}
+
+static int time_step_rk3(ocn_model* m, double dt) {
+  // runge_kutta_3.jl:57-62,81-152
+  if (m->iteration == 0) update_state(m);
+  const double g1 = 8.0 / 15.0, g2 = 5.0 / 12.0, g3 = 3.0 / 4.0, z2 = -17.0 / 60.0, z3 = -5.0 / 12.0;
+  const double gam[3] = {g1, g2, g3}, zet[3] = {0.0, z2, z3};
+  const double sdt[3] = {g1 * dt, (g2 + z2) * dt, (g3 + z3) * dt};
+  for (int s = 0; s < 3; ++s) {
+    launch_tendencies(m);
+    launch_step(m, dt, gam[s], zet[s], s > 0);
+    int rc = pressure_correction(m, sdt[s]);
+    if (rc) return rc;
+    launch_pcorrect(m, sdt[s]);
+    m->time += sdt[s];
+    if (s < 2) {
+      m->stage += 1;
+      launch_store(m);
+    } else {
+      m->iteration += 1;
+      m->stage = 1;
+    }
+    update_state(m);
+  }
+  return OCN_OK;
+}
+
+extern "C" {
+
+int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
+  if (!g || !desc || !out) return OCN_EINVAL;
+  ocn_ctx* ctx = g->ctx;
+  if (desc->n_tracers < 0 || desc->n_tracers > OCN_MAX_TRACERS) return OCN_EINVAL;
+  if (desc->advection < OCN_ADV_NONE || desc->advection > OCN_ADV_WENO5_JS) return OCN_EINVAL;
+  if (desc->closure == OCN_CLOSURE_AMD) {
+    ocn_set_error(ctx, "AnisotropicMinimumDissipation is not implemented yet");
+    return OCN_EUNSUPPORTED;
+  }
+  // halo inflation (nonhydrostatic_model.jl:140-148; Advection.jl:40)
+  static const int buffer[6] = {0, 0, 1, 2, 2, 2};
+  int need = buffer[desc->advection] + 1;
+  bool changed = false;
+  for (int d = 0; d < 3; ++d)
+    if (g->topo[d] != OCN_FLAT && g->H[d] < need) {
+      g->H[d] = need;
+      changed = true;
+    }
+  if (changed) {
+    int rc = grid_build_dev(g);
+    if (rc) return rc;
+  }
+  ocn_model* m = new ocn_model;
+  m->g = g;
+  m->ctx = ctx;
+  m->d = *desc;
+  m->nt = desc->n_tracers;
+  m->gd = g->dev;
+  m->gd.nb = buffer[desc->advection];
+  int rc = 0;
+  rc |= field_alloc(m, m->u, OCN_FACE, OCN_CENTER, OCN_CENTER);
+  rc |= field_alloc(m, m->v, OCN_CENTER, OCN_FACE, OCN_CENTER);
+  rc |= field_alloc(m, m->w, OCN_CENTER, OCN_CENTER, OCN_FACE);
+  rc |= field_alloc(m, m->pNHS, OCN_CENTER, OCN_CENTER, OCN_CENTER);
+  if (g->topo[2] != OCN_FLAT) rc |= field_alloc(m, m->pHY, OCN_CENTER, OCN_CENTER, OCN_CENTER);
+  for (int t = 0; t < m->nt; ++t) rc |= field_alloc(m, m->tr[t], OCN_CENTER, OCN_CENTER, OCN_CENTER);
+  for (int f = 0; f < 3 + m->nt; ++f) {
+    int lx = f == 0, ly = f == 1, lz = f == 2;
+    rc |= field_alloc(m, m->Gn[f], lx, ly, lz);
+    rc |= field_alloc(m, m->Gm[f], lx, ly, lz);
+  }
+  if (rc) {
+    ocn_model_destroy(m);
+    return OCN_ENOMEM;
+  }
+  default_bcs(m, m->u, false);
+  default_bcs(m, m->v, false);
+  default_bcs(m, m->w, false);
+  default_bcs(m, m->pNHS, true);
+  if (m->pHY.present) default_bcs(m, m->pHY, true);
+  for (int t = 0; t < m->nt; ++t) default_bcs(m, m->tr[t], false);
+  // user boundary conditions (only z sides can be non-periodic here)
+  for (int f = 0; f < 3 + m->nt; ++f) {
+    Field* fld = f == 0 ? &m->u : f == 1 ? &m->v : f == 2 ? &m->w : &m->tr[f - 3];
+    for (int s = 0; s < 6; ++s) {
+      const ocn_bc& b = desc->bcs[f][s];
+      if (b.kind == OCN_BC_DEFAULT) continue;
+      int dim = s / 2;
+      if (g->topo[dim] != OCN_BOUNDED) {
+        if (b.kind == OCN_BC_PERIODIC || b.kind == OCN_BC_NONE) continue;
+        ocn_set_error(ctx, "non-periodic boundary condition on a non-Bounded side (field %d side %d)", f, s);
+        ocn_model_destroy(m);
+        return OCN_EINVAL;
+      }
+      BCdev bd{b.kind, b.value, nullptr};
+      if (b.array) {
+        size_t nn = (size_t)g->N[0] * g->N[1];
+        double* dptr = nullptr;
+        if (hipMalloc((void**)&dptr, nn * sizeof(double)) != hipSuccess) {
+          ocn_model_destroy(m);
+          return OCN_ENOMEM;
+        }
+        hipMemcpy(dptr, b.array, nn * sizeof(double), hipMemcpyHostToDevice);
+        m->owned.push_back(dptr);
+        bd.arr = dptr;
+      }
+      fld->bc[s] = bd;
+    }
+  }
+  if (hipMalloc((void**)&m->d_red, 64) != hipSuccess) {
+    ocn_model_destroy(m);
+    return OCN_ENOMEM;
+  }
+  m->solver = poisson_create(m);
+  if (!m->solver) {
+    ocn_model_destroy(m);
+    return OCN_EHIP;
+  }
+  update_state(m);  // nonhydrostatic_model.jl:200
+  *out = m;
+  return OCN_OK;
+}
+
+void ocn_model_destroy(ocn_model* m) {
+  if (!m) return;
+  hipStreamSynchronize(m->ctx->stream);
+  Field* all[] = {&m->u, &m->v, &m->w, &m->pHY, &m->pNHS, &m->nu_e, &m->us, &m->vs, &m->ws};
+  for (Field* f : all) hipFree(f->d);
+  for (int t = 0; t < OCN_MAX_TRACERS; ++t) {
+    hipFree(m->tr[t].d);
+    hipFree(m->kappa_e[t].d);
+  }
+  for (int f = 0; f < OCN_NF; ++f) {
+    hipFree(m->Gn[f].d);
+    hipFree(m->Gm[f].d);
+  }
+  for (double* p : m->owned) hipFree(p);
+  hipFree(m->d_red);
+  poisson_destroy(m->solver);
+  delete m;
+}
+
+int ocn_model_halo(const ocn_model* m, int32_t H[3]) {
+  if (!m || !H) return OCN_EINVAL;
+  for (int d = 0; d < 3; ++d) H[d] = m->g->H[d];
+  return OCN_OK;
+}
+
+int ocn_field_shape(const ocn_model* m, int field_id, int32_t total[3], int32_t interior[3], int32_t halo[3]) {
+  Field* f = model_field(const_cast<ocn_model*>(m), field_id);
+  if (!f) return OCN_EINVAL;
+  for (int d = 0; d < 3; ++d) {
+    if (total) total[d] = f->T[d];
+    if (halo) halo[d] = m->g->H[d];
+    if (interior)
+      interior[d] = m->g->N[d] + ((f->loc[d] == OCN_FACE && m->g->topo[d] == OCN_BOUNDED) ? 1 : 0);
+  }
+  return OCN_OK;
+}
+
+void* ocn_field_device_ptr(ocn_model* m, int field_id) {
+  Field* f = model_field(m, field_id);
+  return f ? f->d : nullptr;
+}
+
+int ocn_field_upload(ocn_model* m, int field_id, const double* host) {
+  Field* f = model_field(m, field_id);
+  if (!f || !host) return OCN_EINVAL;
+  OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));
+  OCN_HIP_CHECK(m->ctx, hipMemcpy(f->d, host, f->n * sizeof(double), hipMemcpyHostToDevice));
+  return OCN_OK;
+}
+
+int ocn_field_download(const ocn_model* m, int field_id, double* host) {
+  Field* f = model_field(const_cast<ocn_model*>(m), field_id);
+  if (!f || !host) return OCN_EINVAL;
+  OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));
+  OCN_HIP_CHECK(m->ctx, hipMemcpy(host, f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
+  return OCN_OK;
+}
+
+int ocn_field_set_interior(ocn_model* m, int field_id, const double* host) {
+  Field* f = model_field(m, field_id);
+  if (!f || !host) return OCN_EINVAL;
+  int32_t it[3];
+  ocn_field_shape(m, field_id, nullptr, it, nullptr);
+  std::vector<double> buf(f->n);
+  int rc = ocn_field_download(m, field_id, buf.data());
+  if (rc) return rc;
+  for (int k = 0; k < it[2]; ++k)
+    for (int j = 0; j < it[1]; ++j)
+      memcpy(&buf[f->Hx + (size_t)(j + f->Hy) * f->sy + (size_t)(k + f->Hz) * f->sz],
+             &host[(size_t)it[0] * (j + (size_t)it[1] * k)], it[0] * sizeof(double));
+  return ocn_field_upload(m, field_id, buf.data());
+}
+
+int ocn_field_get_interior(const ocn_model* m, int field_id, double* host) {
+  Field* f = model_field(const_cast<ocn_model*>(m), field_id);
+  if (!f || !host) return OCN_EINVAL;
+  int32_t it[3];
+  ocn_field_shape(m, field_id, nullptr, it, nullptr);
+  std::vector<double> buf(f->n);
+  int rc = ocn_field_download(m, field_id, buf.data());
+  if (rc) return rc;
+  for (int k = 0; k < it[2]; ++k)
+    for (int j = 0; j < it[1]; ++j)
+      memcpy(&host[(size_t)it[0] * (j + (size_t)it[1] * k)],
+             &buf[f->Hx + (size_t)(j + f->Hy) * f->sy + (size_t)(k + f->Hz) * f->sz], it[0] * sizeof(double));
+  return OCN_OK;
+}
+
+int ocn_fill_halos(ocn_model* m, uint32_t mask) {
+  if (!m) return OCN_EINVAL;
+  Field* fs[OCN_NF + 2];
+  int n = 0;
+  const int ids[5] = {OCN_F_U, OCN_F_V, OCN_F_W, OCN_F_PHY, OCN_F_PNHS};
+  for (int b = 0; b < 5; ++b)
+    if (mask & (1u << b)) {
+      Field* f = model_field(m, ids[b]);
+      if (f) fs[n++] = f;
+    }
+  for (int t = 0; t < m->nt; ++t)
+    if (mask & (1u << (8 + t))) fs[n++] = &m->tr[t];
+  // fields of one call share one batched launch; aux fields (pressures) use their own z conditions
+  fill_fields(m, fs, n);
+  return OCN_OK;
+}
+
+int ocn_update_state(ocn_model* m) { return m ? update_state(m) : OCN_EINVAL; }
+
+int ocn_compute_tendencies(ocn_model* m) {
+  if (!m) return OCN_EINVAL;
+  launch_tendencies(m);
+  return OCN_OK;
+}
+
+int ocn_ab2_step(ocn_model* m, double dt, double chi) {
+  if (!m) return OCN_EINVAL;
+  launch_step(m, dt, 1.5 + chi, -(0.5 + chi), 1);
+  return OCN_OK;
+}
+
+int ocn_rk3_substep(ocn_model* m, double dt, double gamma, double zeta, int has_zeta) {
+  if (!m) return OCN_EINVAL;
+  launch_step(m, dt, gamma, zeta, has_zeta);
+  return OCN_OK;
+}
+
+int ocn_store_tendencies(ocn_model* m) {
+  if (!m) return OCN_EINVAL;
+  launch_store(m);
+  return OCN_OK;
+}
+
+int ocn_pressure_correction(ocn_model* m, double dt) { return m ? pressure_correction(m, dt) : OCN_EINVAL; }
+
+int ocn_pressure_correct_velocities(ocn_model* m, double dt) {
+  if (!m) return OCN_EINVAL;
+  launch_pcorrect(m, dt);
+  return OCN_OK;
+}
+
+int ocn_poisson_solve_host(ocn_model* m, const double* rhs, double* phi) {
+  if (!m || !rhs || !phi) return OCN_EINVAL;
+  size_t n = (size_t)m->g->N[0] * m->g->N[1] * m->g->N[2];
+  double *a = nullptr, *b = nullptr;
+  OCN_HIP_CHECK(m->ctx, hipMalloc((void**)&a, n * sizeof(double)));
+  OCN_HIP_CHECK(m->ctx, hipMalloc((void**)&b, n * sizeof(double)));
+  hipMemcpy(a, rhs, n * sizeof(double), hipMemcpyHostToDevice);
+  int rc = poisson_solve_rhs(m, a, b);
+  hipStreamSynchronize(m->ctx->stream);
+  if (!rc) hipMemcpy(phi, b, n * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(a);
+  hipFree(b);
+  return rc;
+}
+
+int ocn_set_epilogue(ocn_model* m, int enforce_incompressibility) {
+  // set_nonhydrostatic_model.jl:45-58
+  if (!m) return OCN_EINVAL;
+  update_state(m);
+  if (enforce_incompressibility) {
+    int rc = pressure_correction(m, 1.0);
+    if (rc) return rc;
+    launch_pcorrect(m, 1.0);
+    update_state(m);
+  }
+  return OCN_OK;
+}
+
+int ocn_time_step(ocn_model* m, double dt, int force_euler) {
+  if (!m) return OCN_EINVAL;
+  ProfScope ps(m->ctx, "time_step");
+  if (m->d.stepper == OCN_STEPPER_AB2) return time_step_ab2(m, dt, force_euler);
+  return time_step_rk3(m, dt);
+}
+
+int ocn_clock(const ocn_model* m, double* time, int64_t* iteration, int32_t* stage) {
+  if (!m) return OCN_EINVAL;
+  if (time) *time = m->time;
+  if (iteration) *iteration = m->iteration;
+  if (stage) *stage = m->stage;
+  return OCN_OK;
+}
+
+int ocn_set_clock(ocn_model* m, double time, int64_t iteration, double previous_dt) {
+  if (!m) return OCN_EINVAL;
+  m->time = time;
+  m->iteration = iteration;
+  m->previous_dt = previous_dt;
+  return OCN_OK;
+}
+
+int ocn_max_abs_divergence(ocn_model* m, double* out) {
+  if (!m || !out) return OCN_EINVAL;
+  OCN_HIP_CHECK(m->ctx, hipMemsetAsync(m->d_red, 0, 8, m->ctx->stream));
+  launch_maxdiv(m, m->d_red);
+  OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));
+  OCN_HIP_CHECK(m->ctx, hipMemcpy(out, m->d_red, 8, hipMemcpyDeviceToHost));
+  return OCN_OK;
+}
+
+// ---- multi-GPU (comm.hip replaces these when built with RCCL) ------------------------------------------------------
+#ifndef OCN_WITH_RCCL
+int ocn_comm_unique_id(void* out128) {
+  (void)out128;
+  ocn_set_error(nullptr, "libocnhip was built without RCCL");
+  return OCN_EUNSUPPORTED;
+}
+int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* id) {
+  (void)id;
+  if (!ctx) return OCN_EINVAL;
+  if (nranks == 1) {
+    ctx->rank = 0;
+    ctx->nranks = 1;
+    return OCN_OK;
+  }
+  (void)rank;
+  ocn_set_error(ctx, "libocnhip was built without RCCL");
+  return OCN_EUNSUPPORTED;
+}
+#endif
+int ocn_comm_rank(const ocn_ctx* ctx, int* rank, int* nranks) {
+  if (!ctx) return OCN_EINVAL;
+  if (rank) *rank = ctx->rank;
+  if (nranks) *nranks = ctx->nranks;
+  return OCN_OK;
+}
+
+}  // extern "C"

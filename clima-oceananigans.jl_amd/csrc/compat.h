@@ -1,0 +1,152 @@
+// compat.h -- one source tree, two builds.
+//
+//   default            : hipcc --offload-arch=gfx950  -> libocnhip.so (THE product; needs an MI355X)
+//   -DOCN_HOST_EMU     : g++ -x c++                   -> tests/hostemu/libocnhip_hostemu.so
+//
+// The host-emulation build exists only so that the *same kernel source* can be executed on the
+// build container (which has no GPU) by `pytest -m "not gpu"` to catch indexing / arithmetic bugs
+// before GPU minutes are spent.  It is test infrastructure: the Python package never loads it on
+// its own (it loads libocnhip.so or raises), and nothing in bench.py / smoke() may use it.
+#pragma once
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#ifndef OCN_HOST_EMU
+// ------------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+
+#define OCN_DEVFN __device__ __forceinline__
+
+template <class K, class... A>
+static inline void ocn_launch(K kern, dim3 grid, dim3 block, hipStream_t s, A... args) {
+  hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
+}
+// kernels that use __shared__ / __syncthreads go through the same call on the GPU
+template <class K, class... A>
+static inline void ocn_launch_sync(K kern, dim3 grid, dim3 block, hipStream_t s, A... args) {
+  hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
+}
+#define OCN_SHARED __shared__
+
+#else
+// ------------------------------------------------------------------------------------------------
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define OCN_DEVFN inline
+#define OCN_SHARED static
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
+typedef struct emu_stream* hipStream_t;
+struct emu_event { std::chrono::steady_clock::time_point t; };
+typedef emu_event* hipEvent_t;
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+
+static inline const char* hipGetErrorString(hipError_t) { return "host-emu error"; }
+static inline hipError_t hipSetDevice(int) { return 0; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipDeviceSynchronize() { return 0; }
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
+static inline hipError_t hipFree(void* p) { free(p); return 0; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memmove(d, s, n); return 0; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event; return 0; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return 0; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+  return 0;
+}
+
+// barrier-free kernels: plain nested loops
+template <class K, class... A>
+static inline void ocn_launch(K kern, dim3 grid, dim3 block, hipStream_t, A... args) {
+  gridDim = grid;
+  blockDim = block;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        blockIdx = dim3(bx, by, bz);
+        for (unsigned tz = 0; tz < block.z; ++tz)
+          for (unsigned ty = 0; ty < block.y; ++ty)
+            for (unsigned tx = 0; tx < block.x; ++tx) {
+              threadIdx = dim3(tx, ty, tz);
+              kern(args...);
+            }
+      }
+}
+
+// kernels with __syncthreads: one OS thread per GPU thread of a block, blocks run one at a time
+struct emu_barrier {
+  std::mutex m;
+  std::condition_variable cv;
+  unsigned count = 0, n = 0, gen = 0;
+  void wait() {
+    std::unique_lock<std::mutex> lk(m);
+    unsigned g = gen;
+    if (++count == n) { count = 0; ++gen; cv.notify_all(); }
+    else cv.wait(lk, [&] { return g != gen; });
+  }
+};
+extern emu_barrier g_emu_barrier;
+static inline void __syncthreads() { g_emu_barrier.wait(); }
+
+template <class K, class... A>
+static inline void ocn_launch_sync(K kern, dim3 grid, dim3 block, hipStream_t, A... args) {
+  unsigned nt = block.x * block.y * block.z;
+  g_emu_barrier.n = nt;
+  g_emu_barrier.count = 0;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        std::vector<std::thread> th;
+        th.reserve(nt);
+        for (unsigned t = 0; t < nt; ++t)
+          th.emplace_back([=]() {
+            gridDim = grid;
+            blockDim = block;
+            blockIdx = dim3(bx, by, bz);
+            threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            kern(args...);
+          });
+        for (auto& x : th) x.join();
+      }
+}
+#endif
+
+#define OCN_HIP_CHECK(ctx, call)                                                            \
+  do {                                                                                      \
+    hipError_t e__ = (call);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      ocn_set_error(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return OCN_EHIP;                                                                      \
+    }                                                                                       \
+  } while (0)

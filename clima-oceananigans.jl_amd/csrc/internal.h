@@ -1,0 +1,120 @@
+// internal.h -- host-side objects behind the opaque handles of include/ocnhip.h
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ocnhip.h"
+#include "compat.h"
+#include "stencils.h"
+
+#define OCN_NF (3 + OCN_MAX_TRACERS)
+
+struct ProfPhase {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  double total_ms = 0;
+  int64_t count = 0;
+};
+
+struct ocn_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[512] = {0};
+  bool profiling = false;
+  std::map<std::string, ProfPhase> prof;
+  // multi-GPU
+  int rank = 0, nranks = 1;
+  void* comm = nullptr;  // ncclComm_t
+};
+
+void ocn_set_error(ocn_ctx* ctx, const char* fmt, ...);
+
+struct ocn_grid {
+  ocn_ctx* ctx;
+  ocn_grid_desc d;
+  int N[3], H[3], topo[3];
+  double L[3], x0[3];
+  bool z_regular;
+  std::vector<double> zF_int;            // interior faces (stretched)
+  std::vector<double> h_dzc, h_dzf;      // host spacings incl. halos (stretched), layout as GridDev
+  double* d_dzc = nullptr;
+  double* d_dzf = nullptr;
+  GridDev dev;                           // for the current halo
+};
+
+struct BCdev {
+  int kind;
+  double value;
+  const double* arr;  // device (Nx*Ny) or null
+};
+
+struct Field {
+  double* d = nullptr;  // parent array on the device
+  int T[3] = {0, 0, 0};
+  int loc[3] = {0, 0, 0};
+  size_t n = 0;
+  BCdev bc[6];
+  bool present = false;
+  double* interior() const;  // pointer to the first interior cell
+  long sy = 0, sz = 0;
+  int Hx = 0, Hy = 0, Hz = 0;
+};
+
+struct PoissonSolver;
+
+struct ocn_model {
+  ocn_grid* g;
+  ocn_ctx* ctx;
+  ocn_model_desc d;
+  GridDev gd;
+  int nt;  // tracers
+  Field u, v, w, pHY, pNHS;
+  Field tr[OCN_MAX_TRACERS], Gn[OCN_NF], Gm[OCN_NF];
+  Field nu_e, kappa_e[OCN_MAX_TRACERS];
+  // projection scratch: predictor velocities are written here by the fused kernels
+  Field us, vs, ws;
+  PoissonSolver* solver = nullptr;
+  std::vector<double*> owned;  // extra device allocations (bc arrays)
+  // clock / stepper state
+  double time = 0, previous_dt = INFINITY;
+  int64_t iteration = 0;
+  int stage = 1;
+  double* d_red = nullptr;  // reduction scratch
+  int fast_path = 0;        // 1: fused periodic WENO kernels usable
+};
+
+Field* model_field(ocn_model* m, int id);
+
+// ---- kernels.hip ------------------------------------------------------------------------------------
+struct FieldPtrs {
+  double* p[OCN_NF];
+  int Tz[OCN_NF];
+  int n;
+};
+void launch_fill_periodic(ocn_model* m, const FieldPtrs& f, int dim);
+void launch_fill_z_bounded(ocn_model* m, Field& f);
+void launch_tendencies(ocn_model* m);
+void launch_step(ocn_model* m, double dt, double cn, double cm, int use_m);
+void launch_store(ocn_model* m);
+void launch_rhs(ocn_model* m, double dt, double* rhs, int mult_dz);
+void launch_pcorrect(ocn_model* m, double dt);
+void launch_hydrostatic(ocn_model* m);
+void launch_copy_to_field(ocn_model* m, const double* src, Field& f);
+void launch_maxdiv(ocn_model* m, double* out_dev);
+void launch_amd(ocn_model* m);
+
+// ---- poisson.hip ------------------------------------------------------------------------------------
+PoissonSolver* poisson_create(ocn_model* m);
+void poisson_destroy(PoissonSolver* s);
+int poisson_solve(ocn_model* m, double dt);             // rhs from velocities -> pNHS interior
+int poisson_solve_rhs(ocn_model* m, const double* rhs_dev, double* phi_dev);  // generic (tests)
+double* poisson_rhs_buffer(PoissonSolver* s);
+
+// ---- profiling ----------------------------------------------------------------------------------------
+struct ProfScope {
+  ocn_ctx* c;
+  hipEvent_t a = nullptr, b = nullptr;
+  const char* name;
+  ProfScope(ocn_ctx* ctx, const char* nm);
+  ~ProfScope();
+};

@@ -1,0 +1,515 @@
+// kernels.hip -- general (any supported configuration) kernels of the time_step! path.
+// One thread per cell / column; no LDS.  The fused, tiled kernels for the headline configuration
+// live in fused.hip; these are the correctness baseline and the path for every other configuration.
+//
+// Reference kernels restated (paths relative to /root/reference/src):
+//   Models/NonhydrostaticModels/calculate_nonhydrostatic_tendencies.jl:155-180 + nonhydrostatic_tendency_kernel_functions.jl:44-232
+//   Advection/momentum_advection_operators.jl:52-86, tracer_advection_operators.jl:31-35
+//   TurbulenceClosures/closure_kernel_operators.jl:22-48, abstract_scalar_diffusivity_closure.jl:172-207
+//   Coriolis/f_plane.jl:42-44, BuoyancyModels/{buoyancy_tracer.jl:12, linear_equation_of_state.jl:69-77}
+//   TimeSteppers/quasi_adams_bashforth_2.jl:158-166, runge_kutta_3.jl:204-218, store_tendencies.jl:8-11
+//   BoundaryConditions/fill_halo_regions_periodic.jl:37-65, fill_halo_regions_flux.jl:16-35,
+//   fill_halo_regions_value_gradient.jl:7-99, fill_halo_regions_open.jl:34-39, apply_flux_bcs.jl:111-160
+//   Models/NonhydrostaticModels/solve_for_pressure.jl:15-33, pressure_correction.jl:34-40,
+//   update_hydrostatic_pressure.jl:10-18
+#include "internal.h"
+
+struct Phys {
+  int closure;          // OCN_CLOSURE_*
+  double nu;
+  int coriolis;
+  double f;
+  const double* pH;     // interior pointer or null
+  const double* nu_e;   // AMD
+  int buoyancy, bi, Ti, Si;
+  double g, alpha, beta;
+};
+
+static inline dim3 grid3(const GridDev& g, dim3 b) {
+  return dim3((g.Nx + b.x - 1) / b.x, (g.Ny + b.y - 1) / b.y, (g.Nz + b.z - 1) / b.z);
+}
+
+// viscosity at the four stress locations (closure_kernel_operators.jl:72-90)
+OCN_DEVFN double nu_ccc(const Phys& ph, long p) { return ph.nu_e ? ph.nu_e[p] : ph.nu; }
+OCN_DEVFN double nu_ffc(const Phys& ph, long p, long sy) {
+  return ph.nu_e ? 0.25 * ((ph.nu_e[p - 1 - sy] + ph.nu_e[p - sy]) + (ph.nu_e[p - 1] + ph.nu_e[p])) : ph.nu;
+}
+OCN_DEVFN double nu_fcf(const Phys& ph, long p, long sz) {
+  return ph.nu_e ? 0.25 * ((ph.nu_e[p - 1 - sz] + ph.nu_e[p - sz]) + (ph.nu_e[p - 1] + ph.nu_e[p])) : ph.nu;
+}
+OCN_DEVFN double nu_cff(const Phys& ph, long p, long sy, long sz) {
+  return ph.nu_e ? 0.25 * ((ph.nu_e[p - sy - sz] + ph.nu_e[p - sz]) + (ph.nu_e[p - sy] + ph.nu_e[p])) : ph.nu;
+}
+
+template <int ADV>
+__global__ void k_tend_uvw(GridDev g, Phys ph, const double* __restrict__ u, const double* __restrict__ v,
+                           const double* __restrict__ w, double* __restrict__ Gu, double* __restrict__ Gv,
+                           double* __restrict__ Gw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  const long sy = g.sy, sz = g.sz;
+  const long c = i + j * sy + k * sz;
+  const int kk = k + 1;  // 1-based, as in the reference's boundary-buffer tests
+  const bool zb = g.zb != 0, zf = g.zflat != 0;
+  const int Nz = g.Nz, nb = g.nb;
+  const double rdx = g.rdx, rdy = g.rdy;
+  const double rdzc = zf ? 0.0 : 1.0 / g_dzc(g, k);
+  const double rdzf = zf ? 0.0 : 1.0 / g_dzf(g, k);
+  double gu = 0, gv = 0, gw = 0;
+
+  if (ADV != ADV_NONE) {
+    // ---- div_vu at fcc (momentum_advection_operators.jl:52-56) ----
+    auto Fuu = [&](long p) { return adv_flux<ADV>(u + p + 1, 1, sym_b<ADV>(u + p, 1, false, 0, 0, 0)); };
+    auto Fvu = [&](long p) { return adv_flux<ADV>(u + p, sy, sym_b<ADV>(v + p - 1, 1, false, 0, 0, 0)); };
+    auto Fwu = [&](long p, int k1) {
+      return adv_flux_b<ADV>(u + p, sz, sym_b<ADV>(w + p - 1, 1, false, 0, 0, 0), zb, k1, Nz, nb);
+    };
+    gu -= (Fuu(c) - Fuu(c - 1)) * rdx + (Fvu(c + sy) - Fvu(c)) * rdy;
+    if (!zf) gu -= (Fwu(c + sz, kk + 1) - Fwu(c, kk)) * rdzc;
+    // ---- div_vv at cfc (:68-72) ----
+    auto Fuv = [&](long p) { return adv_flux<ADV>(v + p, 1, sym_b<ADV>(u + p - sy, sy, false, 0, 0, 0)); };
+    auto Fvv = [&](long p) { return adv_flux<ADV>(v + p + sy, sy, sym_b<ADV>(v + p, sy, false, 0, 0, 0)); };
+    auto Fwv = [&](long p, int k1) {
+      return adv_flux_b<ADV>(v + p, sz, sym_b<ADV>(w + p - sy, sy, false, 0, 0, 0), zb, k1, Nz, nb);
+    };
+    gv -= (Fuv(c + 1) - Fuv(c)) * rdx + (Fvv(c) - Fvv(c - sy)) * rdy;
+    if (!zf) gv -= (Fwv(c + sz, kk + 1) - Fwv(c, kk)) * rdzc;
+    // ---- div_vw at ccf (:82-86) ----
+    // advecting u, v interpolated in z to the w level.  CenteredSecondOrder interpolates the
+    // *area-weighted* velocity (centered_second_order.jl:24-25): Ax = dy*dz_c varies with k on stretched grids.
+    auto uz = [&](const double* q, long p) -> double {
+      if (zf) return q[p];
+      if (ADV == ADV_C2 && g.dzc) return 0.5 * (g_dzc(g, k - 1) * q[p - sz] + g_dzc(g, k) * q[p]) * rdzf;
+      return sym_b<ADV>(q + p - sz, sz, zb, kk, Nz, nb);
+    };
+    auto Fuw = [&](long p) { return adv_flux<ADV>(w + p, 1, uz(u, p)); };
+    auto Fvw = [&](long p) { return adv_flux<ADV>(w + p, sy, uz(v, p)); };
+    gw -= (Fuw(c + 1) - Fuw(c)) * rdx + (Fvw(c + sy) - Fvw(c)) * rdy;
+    if (!zf) {
+      auto Fww = [&](long p, int k1) {
+        return adv_flux_b<ADV>(w + p + sz, sz, sym_b<ADV>(w + p, sz, zb, k1, Nz, nb), zb, k1, Nz, nb);
+      };
+      gw -= (Fww(c, kk) - Fww(c - sz, kk - 1)) * rdzf;
+    }
+  }
+  // ---- Coriolis (f_plane.jl:42-44) ----
+  if (ph.coriolis) {
+    gu += ph.f * (0.5 * (0.5 * (v[c - 1] + v[c]) + 0.5 * (v[c - 1 + sy] + v[c + sy])));
+    gv -= ph.f * (0.5 * (0.5 * (u[c - sy] + u[c + 1 - sy]) + 0.5 * (u[c] + u[c + 1])));
+  }
+  // ---- hydrostatic pressure gradient (nonhydrostatic_tendency_kernel_functions.jl:10-15) ----
+  if (ph.pH) {
+    gu -= (ph.pH[c] - ph.pH[c - 1]) * rdx;
+    gv -= (ph.pH[c] - ph.pH[c - sy]) * rdy;
+  }
+  // ---- viscous stress divergence (closure_kernel_operators.jl:22-41; fluxes -2 nu Sigma) ----
+  if (ph.closure != OCN_CLOSURE_NONE) {
+    auto rzf = [&](int kf) { return zf ? 0.0 : 1.0 / g_dzf(g, kf); };
+    auto S11 = [&](long p) { return (u[p + 1] - u[p]) * rdx; };
+    auto S22 = [&](long p) { return (v[p + sy] - v[p]) * rdy; };
+    auto S33 = [&](long p, int kc) { return zf ? 0.0 : (w[p + sz] - w[p]) / g_dzc(g, kc); };
+    auto S12 = [&](long p) { return 0.5 * ((u[p] - u[p - sy]) * rdy + (v[p] - v[p - 1]) * rdx); };
+    auto S13 = [&](long p, int kf) { return 0.5 * ((zf ? 0.0 : (u[p] - u[p - sz]) * rzf(kf)) + (w[p] - w[p - 1]) * rdx); };
+    auto S23 = [&](long p, int kf) { return 0.5 * ((zf ? 0.0 : (v[p] - v[p - sz]) * rzf(kf)) + (w[p] - w[p - sy]) * rdy); };
+    double tu = (nu_ccc(ph, c) * S11(c) - nu_ccc(ph, c - 1) * S11(c - 1)) * rdx +
+                (nu_ffc(ph, c + sy, sy) * S12(c + sy) - nu_ffc(ph, c, sy) * S12(c)) * rdy;
+    double tv = (nu_ffc(ph, c + 1, sy) * S12(c + 1) - nu_ffc(ph, c, sy) * S12(c)) * rdx +
+                (nu_ccc(ph, c) * S22(c) - nu_ccc(ph, c - sy) * S22(c - sy)) * rdy;
+    double tw = (nu_fcf(ph, c + 1, sz) * S13(c + 1, k) - nu_fcf(ph, c, sz) * S13(c, k)) * rdx +
+                (nu_cff(ph, c + sy, sy, sz) * S23(c + sy, k) - nu_cff(ph, c, sy, sz) * S23(c, k)) * rdy;
+    if (!zf) {
+      tu += (nu_fcf(ph, c + sz, sz) * S13(c + sz, k + 1) - nu_fcf(ph, c, sz) * S13(c, k)) * rdzc;
+      tv += (nu_cff(ph, c + sz, sy, sz) * S23(c + sz, k + 1) - nu_cff(ph, c, sy, sz) * S23(c, k)) * rdzc;
+      tw += (nu_ccc(ph, c) * S33(c, k) - nu_ccc(ph, c - sz) * S33(c - sz, k - 1)) * rdzf;
+    }
+    gu += 2.0 * tu;
+    gv += 2.0 * tv;
+    gw += 2.0 * tw;
+  }
+  Gu[c] = gu;
+  Gv[c] = gv;
+  Gw[c] = gw;
+}
+
+template <int ADV>
+__global__ void k_tend_c(GridDev g, const double* __restrict__ u, const double* __restrict__ v,
+                         const double* __restrict__ w, const double* __restrict__ q, double kap,
+                         const double* __restrict__ kap_e, int closure, double* __restrict__ Gc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  const long sy = g.sy, sz = g.sz;
+  const long c = i + j * sy + k * sz;
+  const int kk = k + 1;
+  const bool zb = g.zb != 0, zf = g.zflat != 0;
+  const double rdx = g.rdx, rdy = g.rdy;
+  const double rdzc = zf ? 0.0 : 1.0 / g_dzc(g, k);
+  double gc = 0;
+  if (ADV != ADV_NONE) {
+    // tracer_advection_operators.jl:31-35; advecting velocity un-interpolated
+    auto Fx = [&](long p) { return adv_flux<ADV>(q + p, 1, u[p]); };
+    auto Fy = [&](long p) { return adv_flux<ADV>(q + p, sy, v[p]); };
+    gc -= (Fx(c + 1) - Fx(c)) * rdx + (Fy(c + sy) - Fy(c)) * rdy;
+    if (!zf) {
+      auto Fz = [&](long p, int k1) { return adv_flux_b<ADV>(q + p, sz, w[p], zb, k1, g.Nz, g.nb); };
+      gc -= (Fz(c + sz, kk + 1) - Fz(c, kk)) * rdzc;
+    }
+  }
+  if (closure != OCN_CLOSURE_NONE) {
+    // div q = div(-kappa grad c)  (closure_kernel_operators.jl:43-48)
+    auto kx = [&](long p) { return kap_e ? 0.5 * (kap_e[p - 1] + kap_e[p]) : kap; };
+    auto ky = [&](long p) { return kap_e ? 0.5 * (kap_e[p - sy] + kap_e[p]) : kap; };
+    auto kz = [&](long p) { return kap_e ? 0.5 * (kap_e[p - sz] + kap_e[p]) : kap; };
+    double d = (kx(c + 1) * (q[c + 1] - q[c]) * rdx - kx(c) * (q[c] - q[c - 1]) * rdx) * rdx +
+               (ky(c + sy) * (q[c + sy] - q[c]) * rdy - ky(c) * (q[c] - q[c - sy]) * rdy) * rdy;
+    if (!zf)
+      d += (kz(c + sz) * (q[c + sz] - q[c]) / g_dzf(g, k + 1) - kz(c) * (q[c] - q[c - sz]) / g_dzf(g, k)) * rdzc;
+    gc += d;
+  }
+  Gc[c] = gc;
+}
+
+// ---- flux boundary conditions at bottom / top (apply_flux_bcs.jl:125-160) ---------------------------
+__global__ void k_apply_z_flux(GridDev g, double* __restrict__ G, int zloc_face, BCdev bot, BCdev top) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const long c = i + j * g.sy;
+  if (bot.kind == OCN_BC_FLUX) {
+    double val = bot.arr ? bot.arr[i + (long)j * g.Nx] : bot.value;
+    double dzv = zloc_face ? g_dzf(g, 0) : g_dzc(g, 0);
+    G[c] += val / dzv;
+  }
+  if (top.kind == OCN_BC_FLUX) {
+    double val = top.arr ? top.arr[i + (long)j * g.Nx] : top.value;
+    int kt = g.Nz - 1;
+    double dzv = zloc_face ? g_dzf(g, kt) : g_dzc(g, kt);
+    G[c + kt * g.sz] -= val / dzv;
+  }
+}
+
+void launch_tendencies(ocn_model* m) {
+  ProfScope ps(m->ctx, "tendencies");
+  const GridDev& g = m->gd;
+  hipStream_t s = m->ctx->stream;
+  Phys ph;
+  memset(&ph, 0, sizeof(ph));
+  ph.closure = m->d.closure;
+  ph.nu = m->d.nu;
+  ph.coriolis = m->d.coriolis_fplane;
+  ph.f = m->d.f;
+  ph.pH = m->pHY.present ? m->pHY.interior() : nullptr;
+  ph.nu_e = m->nu_e.present ? m->nu_e.interior() : nullptr;
+  dim3 b(64, 4, 1), gr = grid3(g, b);
+  const double *u = m->u.interior(), *v = m->v.interior(), *w = m->w.interior();
+  double *Gu = m->Gn[0].interior(), *Gv = m->Gn[1].interior(), *Gw = m->Gn[2].interior();
+#define TEND_CASE(A)                                                            \
+  case A:                                                                       \
+    ocn_launch(k_tend_uvw<A>, gr, b, s, g, ph, u, v, w, Gu, Gv, Gw);           \
+    for (int t = 0; t < m->nt; ++t)                                            \
+      ocn_launch(k_tend_c<A>, gr, b, s, g, u, v, w, (const double*)m->tr[t].interior(), m->d.kappa[t], \
+                 (const double*)(m->kappa_e[t].present ? m->kappa_e[t].interior() : nullptr), m->d.closure, \
+                 m->Gn[3 + t].interior());                                      \
+    break;
+  switch (m->d.advection) {
+    TEND_CASE(ADV_NONE)
+    TEND_CASE(ADV_C2)
+    TEND_CASE(ADV_C4)
+    TEND_CASE(ADV_U5)
+    TEND_CASE(ADV_WENO_Z)
+    TEND_CASE(ADV_WENO_JS)
+  }
+#undef TEND_CASE
+  // boundary contributions: only z can be Bounded here
+  if (g.zb) {
+    dim3 b2(64, 4, 1), g2((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
+    for (int f = 0; f < 3 + m->nt; ++f) {
+      Field* fld = f == 0 ? &m->u : f == 1 ? &m->v : f == 2 ? &m->w : &m->tr[f - 3];
+      const BCdev &bot = fld->bc[OCN_BOTTOM], &top = fld->bc[OCN_TOP];
+      bool nb = bot.kind == OCN_BC_FLUX && (bot.arr || bot.value != 0.0);
+      bool nt = top.kind == OCN_BC_FLUX && (top.arr || top.value != 0.0);
+      if (!nb && !nt) continue;
+      BCdev b_ = bot, t_ = top;
+      if (!nb) b_.kind = OCN_BC_NOFLUX;
+      if (!nt) t_.kind = OCN_BC_NOFLUX;
+      ocn_launch(k_apply_z_flux, g2, b2, s, g, m->Gn[f].interior(), fld->loc[2], b_, t_);
+    }
+  }
+}
+
+// ---- time stepping (ab2_step_field!, rk3_substep_field!, store_field_tendencies!) ------------------
+struct StepPtrs {
+  double* U[OCN_NF];
+  const double* Gn[OCN_NF];
+  const double* Gm[OCN_NF];
+  int n;
+};
+
+__global__ void k_step(GridDev g, StepPtrs P, double dt, double cn, double cm, int use_m) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  const long c = i + j * g.sy + k * g.sz;
+  for (int f = 0; f < P.n; ++f) {
+    // quasi_adams_bashforth_2.jl:165 / runge_kutta_3.jl:208,216 operation order
+    double inc = use_m ? dt * (cn * P.Gn[f][c] + cm * P.Gm[f][c]) : dt * cn * P.Gn[f][c];
+    P.U[f][c] += inc;
+  }
+}
+
+// U += dt * (cn * Gn + cm * Gm)   [AB2: cn = 1.5+chi, cm = -(0.5+chi);  RK3: cn = gamma, cm = zeta]
+void launch_step(ocn_model* m, double dt, double cn, double cm, int use_m) {
+  ProfScope ps(m->ctx, "step");
+  const GridDev& g = m->gd;
+  StepPtrs P;
+  P.n = 3 + m->nt;
+  for (int f = 0; f < P.n; ++f) {
+    Field* fld = f == 0 ? &m->u : f == 1 ? &m->v : f == 2 ? &m->w : &m->tr[f - 3];
+    P.U[f] = fld->interior();
+    P.Gn[f] = m->Gn[f].interior();
+    P.Gm[f] = m->Gm[f].interior();
+  }
+  dim3 b(64, 4, 1);
+  ocn_launch(k_step, grid3(g, b), b, m->ctx->stream, g, P, dt, cn, cm, use_m);
+}
+
+struct CopyPtrs {
+  double* dst[OCN_NF];
+  const double* src[OCN_NF];
+  int n;
+};
+__global__ void k_copy_interior(GridDev g, CopyPtrs P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  const long c = i + j * g.sy + k * g.sz;
+  for (int f = 0; f < P.n; ++f) P.dst[f][c] = P.src[f][c];
+}
+
+void launch_store(ocn_model* m) {
+  ProfScope ps(m->ctx, "store");
+  CopyPtrs P;
+  P.n = 3 + m->nt;
+  for (int f = 0; f < P.n; ++f) {
+    P.dst[f] = m->Gm[f].interior();
+    P.src[f] = m->Gn[f].interior();
+  }
+  dim3 b(64, 4, 1);
+  ocn_launch(k_copy_interior, grid3(m->gd, b), b, m->ctx->stream, m->gd, P);
+}
+
+// ---- halo fills ------------------------------------------------------------------------------------------
+// Periodic: exact restatement of fill_halo_regions_periodic.jl:37-65 on the *parent* array, sequential in
+// the halo index (matters when N < H), launched over the full parent extent of the other two dims.
+__global__ void k_fill_periodic(FieldPtrs F, int dim, int N, int H, int Tx, int Ty) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y * blockDim.y + threadIdx.y;
+  const int f = blockIdx.z;
+  const int Tz = F.Tz[f];
+  double* p = F.p[f];
+  const long sy = Tx, sz = (long)Tx * Ty;
+  long base, st;
+  if (dim == 0) {  // a: y, b: z
+    if (a >= Ty || b >= Tz) return;
+    base = a * sy + b * sz;
+    st = 1;
+  } else if (dim == 1) {  // a: x, b: z
+    if (a >= Tx || b >= Tz) return;
+    base = a + b * sz;
+    st = sy;
+  } else {  // a: x, b: y
+    if (a >= Tx || b >= Ty) return;
+    base = a + b * sy;
+    st = sz;
+  }
+  for (int i = 0; i < H; ++i) {
+    p[base + i * st] = p[base + (N + i) * st];
+    p[base + (N + H + i) * st] = p[base + (H + i) * st];
+  }
+}
+
+void launch_fill_periodic(ocn_model* m, const FieldPtrs& F, int dim) {
+  const GridDev& g = m->gd;
+  int Tx = g.Nx + 2 * g.Hx, Ty = g.Ny + 2 * g.Hy;
+  int N = dim == 0 ? g.Nx : dim == 1 ? g.Ny : g.Nz;
+  int H = dim == 0 ? g.Hx : dim == 1 ? g.Hy : g.Hz;
+  if (H == 0) return;
+  int Tzmax = 0;
+  for (int f = 0; f < F.n; ++f) Tzmax = F.Tz[f] > Tzmax ? F.Tz[f] : Tzmax;
+  int na = dim == 0 ? Ty : Tx;
+  int nbb = dim == 2 ? Ty : Tzmax;
+  dim3 b(dim == 0 ? 8 : 64, dim == 0 ? 32 : 4, 1);
+  dim3 gr((na + b.x - 1) / b.x, (nbb + b.y - 1) / b.y, F.n);
+  ocn_launch(k_fill_periodic, gr, b, m->ctx->stream, F, dim, N, H, Tx, Ty);
+}
+
+// Bounded z: one halo cell per side (fill_halo_regions_flux.jl:16-35, ..value_gradient.jl:81-99, ..open.jl:34-39)
+__global__ void k_fill_z_bounded(GridDev g, double* __restrict__ p, int face, BCdev bot, BCdev top) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const long c = i + j * g.sy, sz = g.sz;
+  const int Nz = g.Nz;
+  // bottom
+  {
+    double val = bot.arr ? bot.arr[i + (long)j * g.Nx] : bot.value;
+    if (bot.kind == OCN_BC_NOFLUX || bot.kind == OCN_BC_FLUX) p[c - sz] = p[c];
+    else if (bot.kind == OCN_BC_IMPENETRABLE) p[c] = val;
+    else if (bot.kind == OCN_BC_VALUE || bot.kind == OCN_BC_GRADIENT) {
+      double D = face ? g_dzc(g, 0) : g_dzf(g, 0);   // spacing at flip(loc), index 1 (1-based)
+      double cI = p[c];
+      double grad = bot.kind == OCN_BC_GRADIENT ? val : (cI - val) / (D / 2);
+      p[c - sz] = cI + grad * (-D);
+    }
+  }
+  // top
+  {
+    double val = top.arr ? top.arr[i + (long)j * g.Nx] : top.value;
+    if (top.kind == OCN_BC_NOFLUX || top.kind == OCN_BC_FLUX) p[c + Nz * sz] = p[c + (Nz - 1) * sz];
+    else if (top.kind == OCN_BC_IMPENETRABLE) p[c + Nz * sz] = val;
+    else if (top.kind == OCN_BC_VALUE || top.kind == OCN_BC_GRADIENT) {
+      double D = face ? g_dzc(g, Nz) : g_dzf(g, Nz);  // index Nz+1 (1-based)
+      double cI = p[c + (Nz - 1) * sz];
+      double grad = top.kind == OCN_BC_GRADIENT ? val : (val - cI) / (D / 2);
+      p[c + Nz * sz] = cI + grad * D;
+    }
+  }
+}
+
+void launch_fill_z_bounded(ocn_model* m, Field& f) {
+  const GridDev& g = m->gd;
+  dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
+  ocn_launch(k_fill_z_bounded, gr, b, m->ctx->stream, g, f.interior(), f.loc[2], f.bc[OCN_BOTTOM], f.bc[OCN_TOP]);
+}
+
+// ---- Poisson right-hand side (solve_for_pressure.jl:15-18,30-33) ------------------------------------------
+__global__ void k_rhs(GridDev g, const double* __restrict__ u, const double* __restrict__ v,
+                      const double* __restrict__ w, double rdt, int mult_dz, double* __restrict__ rhs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  const long c = i + j * g.sy + k * g.sz;
+  double dzc = g.zflat ? 1.0 : g_dzc(g, k);
+  double div = (u[c + 1] - u[c]) * g.rdx + (v[c + g.sy] - v[c]) * g.rdy;
+  if (!g.zflat) div += (w[c + g.sz] - w[c]) / dzc;
+  double r = div * rdt;
+  if (mult_dz) r *= dzc;
+  rhs[i + (long)g.Nx * (j + (long)g.Ny * k)] = r;
+}
+
+void launch_rhs(ocn_model* m, double dt, double* rhs, int mult_dz) {
+  ProfScope ps(m->ctx, "rhs");
+  dim3 b(64, 4, 1);
+  ocn_launch(k_rhs, grid3(m->gd, b), b, m->ctx->stream, m->gd, (const double*)m->u.interior(),
+             (const double*)m->v.interior(), (const double*)m->w.interior(), 1.0 / dt, mult_dz, rhs);
+}
+
+// ---- projection (pressure_correction.jl:34-40) -----------------------------------------------------------------
+__global__ void k_pcorrect(GridDev g, const double* __restrict__ p, double dt, double* __restrict__ u,
+                           double* __restrict__ v, double* __restrict__ w) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  const long c = i + j * g.sy + k * g.sz;
+  double pc = p[c];
+  u[c] -= (pc - p[c - 1]) * g.rdx * dt;
+  v[c] -= (pc - p[c - g.sy]) * g.rdy * dt;
+  if (!g.zflat) w[c] -= (pc - p[c - g.sz]) / g_dzf(g, k) * dt;
+}
+
+void launch_pcorrect(ocn_model* m, double dt) {
+  ProfScope ps(m->ctx, "pcorrect");
+  dim3 b(64, 4, 1);
+  ocn_launch(k_pcorrect, grid3(m->gd, b), b, m->ctx->stream, m->gd, (const double*)m->pNHS.interior(), dt,
+             m->u.interior(), m->v.interior(), m->w.interior());
+}
+
+// ---- hydrostatic pressure anomaly (update_hydrostatic_pressure.jl:10-18) ---------------------------------------
+__global__ void k_hydrostatic(GridDev g, Phys ph, const double* __restrict__ b0, const double* __restrict__ T,
+                              const double* __restrict__ S, double* __restrict__ pH) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const long c = i + j * g.sy, sz = g.sz;
+  auto bz = [&](long p) -> double {
+    if (ph.buoyancy == OCN_BUOYANCY_TRACER) return b0[p];
+    if (ph.buoyancy == OCN_BUOYANCY_LINEAR_TS) return ph.g * (ph.alpha * T[p] - ph.beta * S[p]);
+    return 0.0;
+  };
+  const int Nz = g.Nz;
+  double bup = bz(c + Nz * sz);
+  double acc = 0;
+  for (int k = Nz - 1; k >= 0; --k) {
+    double bk = bz(c + k * sz);
+    double term = 0.5 * (bk + bup) * g_dzf(g, k + 1);
+    acc = (k == Nz - 1) ? -term : acc - term;
+    pH[c + k * sz] = acc;
+    bup = bk;
+  }
+}
+
+void launch_hydrostatic(ocn_model* m) {
+  if (!m->pHY.present || m->d.buoyancy == OCN_BUOYANCY_NONE) return;  // pHY' stays identically zero
+  ProfScope ps(m->ctx, "hydrostatic");
+  const GridDev& g = m->gd;
+  Phys ph;
+  memset(&ph, 0, sizeof(ph));
+  ph.buoyancy = m->d.buoyancy;
+  ph.g = m->d.g;
+  ph.alpha = m->d.alpha;
+  ph.beta = m->d.beta;
+  const double* b0 = m->d.b_index >= 0 ? m->tr[m->d.b_index].interior() : nullptr;
+  const double* T = m->d.T_index >= 0 ? m->tr[m->d.T_index].interior() : nullptr;
+  const double* S = m->d.S_index >= 0 ? m->tr[m->d.S_index].interior() : nullptr;
+  dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
+  ocn_launch(k_hydrostatic, gr, b, m->ctx->stream, g, ph, b0, T, S, m->pHY.interior());
+}
+
+// ---- compact (Nx,Ny,Nz) array -> field interior (copy_real_component!, fft_based_poisson_solver.jl:122-125) --
+__global__ void k_copy_to_field(GridDev g, const double* __restrict__ src, double* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  dst[i + j * g.sy + k * g.sz] = src[i + (long)g.Nx * (j + (long)g.Ny * k)];
+}
+void launch_copy_to_field(ocn_model* m, const double* src, Field& f) {
+  dim3 b(64, 4, 1);
+  ocn_launch(k_copy_to_field, grid3(m->gd, b), b, m->ctx->stream, m->gd, src, f.interior());
+}
+
+// ---- max |div U| (test helper) -------------------------------------------------------------------------------------
+__global__ void k_maxdiv(GridDev g, const double* __restrict__ u, const double* __restrict__ v,
+                         const double* __restrict__ w, double* out) {
+  // one thread per (i,j) column, atomic max on the bit pattern of a non-negative double
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  double mx = 0;
+  for (int k = 0; k < g.Nz; ++k) {
+    const long c = i + j * g.sy + k * g.sz;
+    double div = (u[c + 1] - u[c]) * g.rdx + (v[c + g.sy] - v[c]) * g.rdy;
+    if (!g.zflat) div += (w[c + g.sz] - w[c]) / g_dzc(g, k);
+    mx = fmax(mx, fabs(div));
+  }
+#ifndef OCN_HOST_EMU
+  atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(mx));
+#else
+  if (mx > *out) *out = mx;
+#endif
+}
+void launch_maxdiv(ocn_model* m, double* out_dev) {
+  const GridDev& g = m->gd;
+  dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
+  ocn_launch(k_maxdiv, gr, b, m->ctx->stream, g, (const double*)m->u.interior(), (const double*)m->v.interior(),
+             (const double*)m->w.interior(), out_dev);
+}
+
+void launch_amd(ocn_model* m) { (void)m; }

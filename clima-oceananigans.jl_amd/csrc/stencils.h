@@ -1,0 +1,138 @@
+// stencils.h -- device-side staggered-grid stencils shared by every kernel.
+//
+// Restated from the reference (paths relative to /root/reference/src):
+//   Advection/weno_fifth_order.jl:12-19,266-272,311-317,380-403,518-524   (WENO5, Z and JS weights)
+//   Advection/upwind_biased_fifth_order.jl:24-46                           (U5)
+//   Advection/centered_fourth_order.jl:17-33                               (4th-order symmetric)
+//   Advection/upwind_biased_advective_fluxes.jl:10                         (upwind_biased_product)
+//   Advection/topologically_conditional_interpolation.jl:19-21             (boundary buffers)
+//
+// Memory model: every field is the reference's parent array (x fastest).  Kernels receive a pointer
+// to the *first interior cell* so that p[i + j*sy + k*sz] with i,j,k possibly negative reaches halos.
+#pragma once
+#include "compat.h"
+
+enum { ADV_NONE = 0, ADV_C2 = 1, ADV_C4 = 2, ADV_U5 = 3, ADV_WENO_Z = 4, ADV_WENO_JS = 5 };
+
+struct GridDev {
+  int Nx, Ny, Nz, Hx, Hy, Hz;
+  long sy, sz;              // strides of the parent array (sx = 1)
+  double dx, dy, dz;        // dz: regular spacing (1 for Flat z)
+  double rdx, rdy;
+  const double* dzc;        // stretched z: spacing at centres, entry [k + Hz]   (k = 0-based centre index)
+  const double* dzf;        //              spacing at faces,   entry [k + Hz + 1] (k = 0-based face index)
+  int zb;                   // z Bounded
+  int zflat;                // z Flat
+  int nb;                   // boundary buffer of the advection scheme
+};
+
+OCN_DEVFN double g_dzc(const GridDev& g, int k) { return g.dzc ? g.dzc[k + g.Hz] : g.dz; }
+OCN_DEVFN double g_dzf(const GridDev& g, int k) { return g.dzf ? g.dzf[k + g.Hz + 1] : g.dz; }
+
+// ---- second / fourth order symmetric interpolation -------------------------------------------------
+// value midway between p[0] and p[s]
+OCN_DEVFN double sym2(const double* p, long s) { return 0.5 * (p[0] + p[s]); }
+// I3 of centered_fourth_order.jl:17-24:  f - delta(delta f)/6
+OCN_DEVFN double i3(const double* p, long s) { return p[0] - ((p[s] - p[0]) - (p[0] - p[-s])) / 6.0; }
+OCN_DEVFN double sym4(const double* p, long s) { return 0.5 * (i3(p, s) + i3(p + s, s)); }
+
+// ---- fast reciprocal for the WENO weights: one hardware rcp + 2 Newton steps (<= 1 ulp-ish) -------
+OCN_DEVFN double fast_rcp(double x) {
+#ifndef OCN_HOST_EMU
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+
+// ---- upwind-biased reconstruction at the face between p[-s] and p[0] ---------------------------------
+// `pos` selects the left-biased (u > 0) or right-biased (u <= 0) member.  Inputs are mirrored so that
+// (A3,A2,A1,A0,B1) = (p[-3s],p[-2s],p[-s],p[0],p[s]) for the left form and
+//                    (p[2s], p[s], p[0], p[-s],p[-2s]) for the right form.  The candidate
+// polynomials and optimal weights of the right-biased form are exact mirrors of the left ones
+// (weno_fifth_order.jl:368,518-524); the 1/4-terms of its outer smoothness indicators are NOT
+// (weno_fifth_order.jl:315,317 as written) and are reproduced through the (cL, cR) coefficients.
+template <int ADV>
+OCN_DEVFN double recon5(double A3, double A2, double A1, double A0, double B1, bool pos) {
+  if (ADV == ADV_U5) {
+    return (2.0 * A3 - 13.0 * A2 + 47.0 * A1 + 27.0 * A0 - 3.0 * B1) / 60.0;
+  } else {
+    const double cL = pos ? 3.0 : 1.0, cR = pos ? 1.0 : 3.0;
+    double t0 = A1 - 2.0 * A0 + B1, u0 = cL * A1 - 4.0 * A0 + cR * B1;   // nearest stencil (optimal weight 3/10)
+    double t1 = A2 - 2.0 * A1 + A0, u1 = A2 - A0;                         // middle  stencil (3/5)
+    double t2 = A3 - 2.0 * A2 + A1, u2 = cR * A3 - 4.0 * A2 + cL * A1;   // farthest stencil (1/10)
+    double b0 = (13.0 / 12.0) * t0 * t0 + 0.25 * u0 * u0;
+    double b1 = (13.0 / 12.0) * t1 * t1 + 0.25 * u1 * u1;
+    double b2 = (13.0 / 12.0) * t2 * t2 + 0.25 * u2 * u2;
+    double p0 = (1.0 / 3.0) * A1 + (5.0 / 6.0) * A0 - (1.0 / 6.0) * B1;
+    double p1 = -(1.0 / 6.0) * A2 + (5.0 / 6.0) * A1 + (1.0 / 3.0) * A0;
+    double p2 = (1.0 / 3.0) * A3 - (7.0 / 6.0) * A2 + (11.0 / 6.0) * A1;
+    const double eps = 1e-6;
+    double d0 = b0 + eps, d1 = b1 + eps, d2 = b2 + eps;
+    double a0, a1, a2;
+    if (ADV == ADV_WENO_Z) {
+      // alpha_k = C_k (1 + (tau/d_k)^2) = C_k (d_k^2 + tau^2) / d_k^2 ; common denominator d0^2 d1^2 d2^2
+      double tau = fabs(b2 - b0), tt = tau * tau;
+      double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
+      a0 = 0.3 * (q0 + tt) * (q1 * q2);
+      a1 = 0.6 * (q1 + tt) * (q0 * q2);
+      a2 = 0.1 * (q2 + tt) * (q0 * q1);
+    } else {
+      // alpha_k = C_k / d_k^2
+      double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
+      a0 = 0.3 * (q1 * q2);
+      a1 = 0.6 * (q0 * q2);
+      a2 = 0.1 * (q0 * q1);
+    }
+    return (a0 * p0 + a1 * p1 + a2 * p2) * fast_rcp(a0 + a1 + a2);
+  }
+}
+
+// upwind reconstruction from memory: face between p[-s] and p[0], advecting velocity ut
+template <int ADV>
+OCN_DEVFN double recon_mem(const double* p, long s, double ut) {
+  bool pos = ut > 0.0;
+  double m3 = p[-3 * s], m2 = p[-2 * s], m1 = p[-s], c0 = p[0], c1 = p[s], c2 = p[2 * s];
+  double A3 = pos ? m3 : c2, A2 = pos ? m2 : c1, A1 = pos ? m1 : c0, A0 = pos ? c0 : m1, B1 = pos ? c1 : m2;
+  return recon5<ADV>(A3, A2, A1, A0, B1, pos);
+}
+
+// advective flux (per unit area) through the face between p[-s] and p[0]; ut = advecting velocity there
+template <int ADV>
+OCN_DEVFN double adv_flux(const double* p, long s, double ut) {
+  if (ADV == ADV_C4) return ut * sym4(p - s, s);
+  if (ADV == ADV_C2) return ut * sym2(p - s, s);
+  return ut * recon_mem<ADV>(p, s, ut);
+}
+
+// ---- Bounded-direction versions (topologically_conditional_interpolation.jl:19-21,46-79) ------------
+// idx: 1-based index of the evaluation point along the bounded direction, N its size, nb the buffer.
+OCN_DEVFN bool outside_sym(int idx, int N, int nb) { return idx > nb && idx < N + 1 - nb; }
+OCN_DEVFN bool outside_left(int idx, int N, int nb) { return idx > nb && idx < N + 1 - (nb - 1); }
+OCN_DEVFN bool outside_right(int idx, int N, int nb) { return idx > nb - 1 && idx < N + 1 - nb; }
+
+// symmetric interpolation midway between p[0] and p[s] along a possibly Bounded direction
+template <int ADV>
+OCN_DEVFN double sym_b(const double* p, long s, bool bounded, int idx, int N, int nb) {
+  if (ADV == ADV_C2) return sym2(p, s);
+  if (bounded && !outside_sym(idx, N, nb)) return sym2(p, s);
+  return sym4(p, s);
+}
+
+template <int ADV>
+OCN_DEVFN double adv_flux_b(const double* p, long s, double ut, bool bounded, int idx, int N, int nb) {
+  if (ADV == ADV_C2) return ut * sym2(p - s, s);
+  if (ADV == ADV_C4) {
+    if (bounded && !outside_sym(idx, N, nb)) return ut * sym2(p - s, s);
+    return ut * sym4(p - s, s);
+  }
+  bool pos = ut > 0.0;
+  if (bounded) {
+    bool ok = pos ? outside_left(idx, N, nb) : outside_right(idx, N, nb);
+    if (!ok) return ut * sym2(p - s, s);
+  }
+  return ut * recon_mem<ADV>(p, s, ut);
+}

@@ -1,0 +1,202 @@
+/*
+ * ocnhip.h -- C ABI of libocnhip.so: an MI355X (gfx950) implementation of Oceananigans'
+ * NonhydrostaticModel `time_step!` hot path on a RectilinearGrid.
+ *
+ * The reference (Oceananigans.jl v0.76.8) is pure Julia and has no FFI / plugin registry: its only
+ * extension point is multiple dispatch on the architecture type carried by the grid
+ * (src/Architectures.jl:53-142, src/Grids/grid_utils.jl:39).  A `ROCmGPU <: AbstractArchitecture`
+ * shim overloads the phase-level functions listed beside each entry point below
+ * and forwards them here with `ccall`.  Paths are relative to /root/reference/src.
+ *
+ * Conventions
+ *   - every function returns 0 (OCN_OK) or a negative OCN_E* code; nothing throws across the boundary;
+ *     the message of the last failure is available from ocn_last_error().
+ *   - the library owns all device memory behind handles; host buffers belong to the caller and only
+ *     need to stay alive for the duration of the (synchronous) upload / download call.
+ *   - field memory is the reference's *parent* array: column-major (x fastest), halos included,
+ *     size total_size(loc, grid) (Grids/new_data.jl:16-61, Grids/grid_utils.jl:105-128), so a Julia
+ *     `OffsetArray` can alias ocn_field_device_ptr() with the usual offsets.
+ *   - one context = one device + one in-order HIP stream.  Compute calls are asynchronous with
+ *     respect to the host and ordered on that stream; only ocn_sync, uploads and downloads block.
+ *   - handles are not thread-safe: one host thread per context.
+ */
+#ifndef OCNHIP_H
+#define OCNHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCN_ABI_VERSION 1
+
+/* error codes */
+enum {
+  OCN_OK = 0,
+  OCN_EINVAL = -1,       /* bad argument / unsupported configuration             */
+  OCN_ENOMEM = -2,       /* device or host allocation failed                     */
+  OCN_EHIP = -3,         /* a HIP / hipFFT / RCCL call failed                    */
+  OCN_EUNSUPPORTED = -4, /* valid in the reference, outside this library's scope */
+  OCN_ESTATE = -5        /* call made in the wrong state                         */
+};
+
+/* topology of one direction (Grids/Grids.jl:60-93) */
+enum { OCN_PERIODIC = 0, OCN_BOUNDED = 1, OCN_FLAT = 2 };
+/* location of a field along one direction (Grids/Grids.jl: Center, Face) */
+enum { OCN_CENTER = 0, OCN_FACE = 1 };
+/* advection schemes (Advection/: centered_second_order.jl, centered_fourth_order.jl,
+ * upwind_biased_fifth_order.jl, weno_fifth_order.jl:162-180 with zweno = true / false) */
+enum { OCN_ADV_NONE = 0, OCN_ADV_C2 = 1, OCN_ADV_C4 = 2, OCN_ADV_U5 = 3, OCN_ADV_WENO5_Z = 4, OCN_ADV_WENO5_JS = 5 };
+/* time steppers (TimeSteppers/quasi_adams_bashforth_2.jl, runge_kutta_3.jl) */
+enum { OCN_STEPPER_AB2 = 0, OCN_STEPPER_RK3 = 1 };
+/* closures (TurbulenceClosures/turbulence_closure_implementations/{scalar_diffusivity,anisotropic_minimum_dissipation}.jl) */
+enum { OCN_CLOSURE_NONE = 0, OCN_CLOSURE_SCALAR = 1, OCN_CLOSURE_AMD = 2 };
+/* buoyancy models (BuoyancyModels/buoyancy_tracer.jl:12, linear_equation_of_state.jl:69-77) */
+enum { OCN_BUOYANCY_NONE = 0, OCN_BUOYANCY_TRACER = 1, OCN_BUOYANCY_LINEAR_TS = 2 };
+/* boundary-condition kinds (BoundaryConditions/boundary_condition.jl:8-11,77-96) */
+enum { OCN_BC_DEFAULT = 0, OCN_BC_PERIODIC = 1, OCN_BC_NOFLUX = 2, OCN_BC_FLUX = 3, OCN_BC_VALUE = 4,
+       OCN_BC_GRADIENT = 5, OCN_BC_IMPENETRABLE = 6, OCN_BC_NONE = 7 };
+/* sides */
+enum { OCN_WEST = 0, OCN_EAST = 1, OCN_SOUTH = 2, OCN_NORTH = 3, OCN_BOTTOM = 4, OCN_TOP = 5 };
+
+#define OCN_MAX_TRACERS 8
+
+/* field identifiers inside a model (Fields/field_tuples.jl:133-246) */
+enum {
+  OCN_F_U = 0, OCN_F_V = 1, OCN_F_W = 2,
+  OCN_F_PHY = 3,  /* pHY'  (absent for Flat z)  */
+  OCN_F_PNHS = 4, /* pNHS                        */
+  OCN_F_GN = 16,  /* G^n : OCN_F_GN + {0,1,2, 3+tracer}   (TimeSteppers: timestepper.G^n) */
+  OCN_F_GM = 32,  /* G^- : OCN_F_GM + {0,1,2, 3+tracer}                                    */
+  OCN_F_TRACER = 48, /* tracers: OCN_F_TRACER + index                                      */
+  OCN_F_NU = 64,     /* AMD eddy viscosity nu_e;  OCN_F_KAPPA + index: kappa_e             */
+  OCN_F_KAPPA = 72
+};
+
+typedef struct ocn_ctx ocn_ctx;
+typedef struct ocn_grid ocn_grid;
+typedef struct ocn_model ocn_model;
+
+/* RectilinearGrid(size=, halo=, topology=, x=, y=, z=)  -- Grids/rectilinear_grid.jl:249-279.
+ * x and y must be regular (extent given); z is regular when z_faces == NULL, otherwise z_faces
+ * holds the Nz+1 interior face positions (a "vertically stretched" grid even if the spacing is
+ * uniform, which selects the Fourier-tridiagonal solver exactly as NonhydrostaticModels.jl:18-27). */
+typedef struct ocn_grid_desc {
+  int32_t N[3];        /* Nx, Ny, Nz (1 for Flat directions)              */
+  int32_t H[3];        /* halo (0 for Flat directions)                    */
+  int32_t topology[3]; /* OCN_PERIODIC / OCN_BOUNDED / OCN_FLAT           */
+  double x0[3];        /* left end of the domain per direction            */
+  double L[3];         /* extent per direction (ignored for stretched z)  */
+  const double* z_faces; /* NULL or Nz+1 doubles (host)                   */
+  /* domain decomposition (Distributed/multi_architectures.jl:20-47): z-slabs. local = this rank's slab */
+  int32_t rank, nranks;
+} ocn_grid_desc;
+
+/* one side of one field: kind + constant value or host array over the two other (interior) dims */
+typedef struct ocn_bc {
+  int32_t kind;         /* OCN_BC_*  (OCN_BC_DEFAULT -> field_boundary_conditions.jl:13-35) */
+  double value;         /* used when array == NULL                                            */
+  const double* array;  /* optional host array (N_a x N_b, column-major), copied at creation */
+} ocn_bc;
+
+/* NonhydrostaticModel(; grid, advection, buoyancy, coriolis, closure, boundary_conditions, tracers,
+ * timestepper) -- Models/NonhydrostaticModels/nonhydrostatic_model.jl:102-203.  Forcings, Stokes drift,
+ * background fields, immersed boundaries and particles are user Julia closures / out of scope: not
+ * representable across a C ABI, the shim rejects them. */
+typedef struct ocn_model_desc {
+  int32_t advection;   /* OCN_ADV_*                                   */
+  int32_t stepper;     /* OCN_STEPPER_*                               */
+  double chi;          /* AB2 parameter (quasi_adams_bashforth_2.jl:45: 0.1) */
+  int32_t n_tracers;   /* <= OCN_MAX_TRACERS                          */
+  int32_t closure;     /* OCN_CLOSURE_*                               */
+  double nu;           /* ScalarDiffusivity nu                        */
+  double kappa[OCN_MAX_TRACERS]; /* ScalarDiffusivity kappa per tracer */
+  double amd_Cnu;      /* AMD Poincare constants                      */
+  double amd_Ckappa[OCN_MAX_TRACERS];
+  int32_t coriolis_fplane; /* 0 / 1 */
+  double f;            /* FPlane f (Coriolis/f_plane.jl:42-44)         */
+  int32_t buoyancy;    /* OCN_BUOYANCY_*                              */
+  int32_t b_index, T_index, S_index; /* tracer indices used by the buoyancy model (-1: absent) */
+  double g, alpha, beta; /* SeawaterBuoyancy(LinearEquationOfState)   */
+  ocn_bc bcs[3 + OCN_MAX_TRACERS][6]; /* [field: u,v,w,tracers...][side] */
+} ocn_model_desc;
+
+/* ---- context (Architectures.jl:53-142: device, array_type, arch_array, device_event) ---------- */
+int ocn_abi_version(void);
+int ocn_init(int device_id, ocn_ctx** out);
+void ocn_destroy(ocn_ctx* ctx);
+int ocn_sync(ocn_ctx* ctx);                       /* wait(device(arch), event) everywhere in the reference */
+const char* ocn_last_error(ocn_ctx* ctx);         /* ctx may be NULL: last global error */
+void* ocn_stream(ocn_ctx* ctx);                   /* the hipStream_t, for callers that enqueue their own work */
+
+/* ---- grid (Grids/rectilinear_grid.jl:249-279, Grids/zeros.jl:7) --------------------------------- */
+int ocn_grid_create(ocn_ctx* ctx, const ocn_grid_desc* desc, ocn_grid** out);
+void ocn_grid_destroy(ocn_grid* g);
+
+/* ---- model -------------------------------------------------------------------------------------- */
+int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out);
+void ocn_model_destroy(ocn_model* m);
+/* halo actually used (the model inflates it like nonhydrostatic_model.jl:140-148) */
+int ocn_model_halo(const ocn_model* m, int32_t H[3]);
+
+/* ---- fields: parent arrays incl. halos (Fields/field.jl:16-30; OutputWriters/fetch_output.jl:26) - */
+int ocn_field_shape(const ocn_model* m, int field_id, int32_t total[3], int32_t interior[3], int32_t halo[3]);
+void* ocn_field_device_ptr(ocn_model* m, int field_id);           /* Julia unsafe_wrap / torch from_blob */
+int ocn_field_upload(ocn_model* m, int field_id, const double* host_parent);   /* arch_array(GPU(), a) */
+int ocn_field_download(const ocn_model* m, int field_id, double* host_parent); /* arch_array(CPU(), a) */
+int ocn_field_set_interior(ocn_model* m, int field_id, const double* host_interior); /* Fields/set!.jl:21-39 */
+int ocn_field_get_interior(const ocn_model* m, int field_id, double* host_interior);
+
+/* ---- phase-level entry points (each replaces one overloaded Julia method) ------------------------- */
+/* fill_halo_regions!(c, bcs, loc, grid)                      BoundaryConditions/fill_halo_regions.jl:34-46
+ * mask: bit f set -> fill field f in {u,v,w,pHY,pNHS} ; bit (8+i) -> tracer i                           */
+int ocn_fill_halos(ocn_model* m, uint32_t field_mask);
+/* update_state!(model)          Models/NonhydrostaticModels/update_nonhydrostatic_model_state.jl:14-37 */
+int ocn_update_state(ocn_model* m);
+/* calculate_tendencies!(model)  .../calculate_nonhydrostatic_tendencies.jl:12-36 (interior + boundary) */
+int ocn_compute_tendencies(ocn_model* m);
+/* ab2_step!(model, dt, chi)     TimeSteppers/quasi_adams_bashforth_2.jl:116-150 */
+int ocn_ab2_step(ocn_model* m, double dt, double chi);
+/* rk3_substep!(model, dt, gamma, zeta)  TimeSteppers/runge_kutta_3.jl:161-218 ; has_zeta = 0 for stage 1 */
+int ocn_rk3_substep(ocn_model* m, double dt, double gamma, double zeta, int has_zeta);
+/* store_tendencies!(model)      TimeSteppers/store_tendencies.jl:14-36 */
+int ocn_store_tendencies(ocn_model* m);
+/* calculate_pressure_correction!(model, dt)  .../pressure_correction.jl:10-23 (fill, rhs, solve, fill) */
+int ocn_pressure_correction(ocn_model* m, double dt);
+/* solve!(phi, solver, rhs): Solvers/fft_based_poisson_solver.jl:93-120 or
+ * Solvers/fourier_tridiagonal_poisson_solver.jl:74-101 (rhs NOT pre-multiplied by dz).
+ * rhs / phi: host arrays (Nx,Ny,Nz), used by the Poisson property tests.                                */
+int ocn_poisson_solve_host(ocn_model* m, const double* rhs, double* phi);
+/* pressure_correct_velocities!(model, dt)    .../pressure_correction.jl:43-56 */
+int ocn_pressure_correct_velocities(ocn_model* m, double dt);
+/* set!(model; ...) epilogue: update_state!, unit-dt projection, update_state!
+ *                                .../set_nonhydrostatic_model.jl:45-58 */
+int ocn_set_epilogue(ocn_model* m, int enforce_incompressibility);
+/* time_step!(model, dt; euler)  TimeSteppers/quasi_adams_bashforth_2.jl:70-104 / runge_kutta_3.jl:81-152.
+ * Whole sequence enqueued on the stream without host synchronisation.                                   */
+int ocn_time_step(ocn_model* m, double dt, int force_euler);
+/* model.clock (TimeSteppers/clock.jl:14-18) */
+int ocn_clock(const ocn_model* m, double* time, int64_t* iteration, int32_t* stage);
+int ocn_set_clock(ocn_model* m, double time, int64_t iteration, double previous_dt);
+/* max |div U| over the interior (test helper `divergence!`, test/utils_for_runtests.jl:60-67) */
+int ocn_max_abs_divergence(ocn_model* m, double* out);
+
+/* ---- multi-GPU: one process per GPU, z-slabs, RCCL (Distributed/multi_architectures.jl:20-137,
+ * halo_communication.jl:68-183, distributed_fft_based_poisson_solver.jl:95-196) ------------------- */
+int ocn_comm_unique_id(void* out128);                                      /* ncclGetUniqueId (128 bytes) */
+int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* unique_id128);
+int ocn_comm_rank(const ocn_ctx* ctx, int* rank, int* nranks);
+
+/* ---- measurement helpers (bench.py) -------------------------------------------------------------- */
+/* average device time [ms] of the `n` most recent launches of the named phase, measured with HIP
+ * events on the context stream when profiling is enabled */
+int ocn_profile_enable(ocn_ctx* ctx, int on);
+int ocn_profile_read(ocn_ctx* ctx, const char* phase, double* avg_ms, int64_t* count);
+int ocn_profile_reset(ocn_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCNHIP_H */

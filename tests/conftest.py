@@ -1,10 +1,46 @@
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+HOSTEMU = os.path.join(ROOT, "tests", "hostemu", "libocnhip_hostemu.so")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # One native library per process.  `-m gpu` runs use the product (libocnhip.so, HIP); every other
+    # run uses the host emulation of the same kernel sources (tests/hostemu, built by build()).
+    expr = (config.getoption("-m") or "").strip()
+    use_gpu = expr == "gpu" or os.environ.get("OCNHIP_TEST_BACKEND") == "gpu"
+    config._ocn_backend = "gpu" if use_gpu else "hostemu"
+    if use_gpu:
+        os.environ.pop("OCNHIP_LIB", None)
+    else:
+        os.environ["OCNHIP_LIB"] = HOSTEMU
+
+
+@pytest.fixture(scope="session")
+def backend(request):
+    return request.config._ocn_backend
+
+
+@pytest.fixture(scope="session")
+def ocn(request):
+    """the host-side package bound to the backend of this run"""
+    import __graft_entry__ as ge
+    if request.config._ocn_backend == "hostemu" and not os.path.exists(HOSTEMU):
+        import subprocess
+        subprocess.check_call(["make", "-C", ge.CSRC, "emu"])
+    return ge.load_package()
+
+
+def pytest_collection_modifyitems(config, items):
+    skip_gpu = pytest.mark.skip(reason="needs the HIP backend: run with -m gpu on an MI355X")
+    if config._ocn_backend != "gpu":
+        for it in items:
+            if "gpu" in it.keywords:
+                it.add_marker(skip_gpu)

@@ -1,0 +1,130 @@
+"""Shared parity cases: the same seeded configuration is run through the oracle and through the C ABI
+(HIP on the GPU box, host emulation of the same kernels elsewhere) and compared field by field.
+
+Tolerances (Float64): one tendency evaluation 1e-12 relative to max|G|;
+trajectories rtol sqrt(eps) with atol 1e-12 max|field| -- in practice we assert much tighter bounds.
+"""
+import numpy as np
+
+import oracle as O
+
+P, B, F = "Periodic", "Bounded", "Flat"
+
+
+def _adv(mod, name):
+    return {None: None, "WENO5": mod.WENO5(), "WENO5JS": mod.WENO5(zweno=False), "U5": mod.UpwindBiasedFifthOrder(),
+            "C4": mod.CenteredFourthOrder(), "C2": mod.CenteredSecondOrder()}[name]
+
+
+CASES = {
+    # headline configuration, small
+    "ppp_weno_ab2": dict(size=(16, 12, 10), topo=(P, P, P), extent=(1, 2, 1.5), adv="WENO5", stepper="AB2", steps=3, dt=2e-3),
+    "ppp_weno_rk3": dict(size=(12, 16, 8), topo=(P, P, P), extent=(1, 1, 1), adv="WENO5", stepper="RK3", steps=2, dt=4e-3),
+    "ppp_wenojs_tracer": dict(size=(8, 8, 8), topo=(P, P, P), extent=(1, 1, 1), adv="WENO5JS", stepper="AB2", steps=2,
+                              dt=2e-3, tracers=("c",)),
+    "ppp_u5_visc": dict(size=(10, 9, 8), topo=(P, P, P), extent=(1, 1, 1), adv="U5", stepper="AB2", steps=2, dt=2e-3,
+                        tracers=("c",), closure=(1e-2, 2e-2)),
+    "ppp_c4": dict(size=(8, 10, 12), topo=(P, P, P), extent=(1, 1, 1), adv="C4", stepper="RK3", steps=2, dt=2e-3),
+    "ppp_c2_default": dict(size=(8, 8, 8), topo=(P, P, P), extent=(1, 1, 1), adv="C2", stepper="AB2", steps=2, dt=2e-3,
+                           halo=(1, 1, 1)),
+    # bounded z, regular (reference: FFT + cosine transform; here: Fourier-tridiagonal, same discrete system)
+    "ppb_weno_full": dict(size=(12, 10, 9), topo=(P, P, B), extent=(1, 1, 1), adv="WENO5", stepper="RK3", steps=2, dt=2e-3,
+                          tracers=("T", "S"), closure=(1e-3, 2e-3), coriolis=1e-1, buoyancy="TS"),
+    "ppb_c2_btracer": dict(size=(8, 8, 8), topo=(P, P, B), extent=(1, 1, 1), adv="C2", stepper="AB2", steps=3, dt=5e-3,
+                           tracers=("b",), buoyancy="b"),
+    # bounded, stretched z + flux / gradient boundary conditions (ocean_wind_mixing-style)
+    "ppb_stretched_bcs": dict(size=(8, 8, 8), topo=(P, P, B), xy=((0, 1), (0, 1)),
+                              zfaces=[-1.0, -0.8, -0.62, -0.46, -0.32, -0.2, -0.1, -0.04, 0.0],
+                              adv="WENO5", stepper="RK3", steps=2, dt=2e-3, tracers=("T", "S"), closure=(1e-3, 1e-3),
+                              coriolis=1e-2, buoyancy="TS",
+                              bcs={"u": {"top": ("flux", -1e-2)}, "T": {"top": ("flux", 2e-3), "bottom": ("gradient", 0.01)},
+                                   "S": {"top": ("flux", -1e-3)}}),
+    "ppb_stretched_c2": dict(size=(6, 7, 8), topo=(P, P, B), xy=((0, 1), (0, 1)),
+                             zfaces=[0, 1, 2, 4, 7, 11, 16, 22, 29], adv="C2", stepper="AB2", steps=2, dt=1e-2,
+                             tracers=("b",), buoyancy="b", closure=(1e-2, 1e-2)),
+    # two-dimensional turbulence (BASELINE config 1): Flat z
+    "ppf_weno_rk3": dict(size=(16, 16), topo=(P, P, F), extent=(2 * np.pi, 2 * np.pi), adv="WENO5", stepper="RK3",
+                         steps=2, dt=0.05, closure=(1e-5, 0.0)),
+}
+
+
+def build(mod, cfg, rng_seed=1234):
+    """build + initialise a model with module `mod` (oracle or the ocnhip package)."""
+    kw = {}
+    if "extent" in cfg:
+        kw["extent"] = cfg["extent"]
+    else:
+        kw["x"], kw["y"] = cfg["xy"]
+        kw["z"] = np.array(cfg["zfaces"], dtype=float)
+    if "halo" in cfg:
+        kw["halo"] = cfg["halo"]
+    g = mod.RectilinearGrid(size=cfg["size"], topology=cfg["topo"], **kw)
+    mk = {}
+    if cfg.get("closure"):
+        mk["closure"] = mod.ScalarDiffusivity(nu=cfg["closure"][0], kappa=cfg["closure"][1])
+    if cfg.get("coriolis"):
+        mk["coriolis"] = mod.FPlane(cfg["coriolis"])
+    if cfg.get("buoyancy") == "TS":
+        mk["buoyancy"] = mod.SeawaterBuoyancy(thermal_expansion=2e-1, haline_contraction=8e-1)
+    elif cfg.get("buoyancy") == "b":
+        mk["buoyancy"] = mod.BuoyancyTracer()
+    if cfg.get("bcs"):
+        ctor = {"flux": mod.FluxBC, "value": mod.ValueBC, "gradient": mod.GradientBC}
+        mk["boundary_conditions"] = {f: {s: ctor[k](v) for s, (k, v) in sides.items()} for f, sides in cfg["bcs"].items()}
+    m = mod.NonhydrostaticModel(g, advection=_adv(mod, cfg["adv"]), timestepper=cfg["stepper"],
+                                tracers=cfg.get("tracers", ()), **mk)
+    rng = np.random.default_rng(rng_seed)
+    N = tuple(cfg["size"]) + ((1,) if len(cfg["size"]) == 2 else ())
+    bounded_z = cfg["topo"][2] == B
+    init = {"u": rng.random(N) - 0.5, "v": rng.random(N) - 0.5}
+    wN = (N[0], N[1], N[2] + 1) if bounded_z else N
+    w = rng.random(wN) - 0.5
+    if bounded_z:
+        w[:, :, 0] = 0
+        w[:, :, -1] = 0
+    if cfg["topo"][2] != F:
+        init["w"] = w
+    for t in cfg.get("tracers", ()):
+        init[t] = rng.random(N)
+    mod.set_model(m, **init)
+    return m
+
+
+def fields_of(m, oracle):
+    out = {}
+    names = ["u", "v", "w"] + list(m.tracers.keys())
+    for n in names:
+        f = getattr(m, n) if n in "uvw" else m.tracers[n]
+        out[n] = f.data.copy() if oracle else f.parent()
+        g = m.Gn[n]
+        out["Gn_" + n] = g.data.copy() if oracle else g.parent()
+    out["pNHS"] = m.pNHS.data.copy() if oracle else m.pNHS.parent()
+    if m.pHY is not None:
+        out["pHY"] = m.pHY.data.copy() if oracle else m.pHY.parent()
+    return out
+
+
+def run_case(ocn, name, check_each_step=True):
+    """returns the worst relative error over all fields and steps"""
+    cfg = CASES[name]
+    om = build(O, cfg)
+    dm = build(ocn, cfg)
+    worst = {}
+
+    def compare(tag):
+        a, b = fields_of(om, True), fields_of(dm, False)
+        for k in a:
+            assert a[k].shape == b[k].shape, (k, a[k].shape, b[k].shape)
+            scale = max(np.abs(a[k]).max(), 1e-300)
+            err = np.abs(a[k] - b[k]).max() / scale
+            if np.abs(a[k]).max() < 1e-13:   # identically-zero fields: absolute comparison
+                err = np.abs(a[k] - b[k]).max()
+            worst[k] = max(worst.get(k, 0.0), err)
+    compare("init")
+    for s in range(cfg["steps"]):
+        O.time_step(om, cfg["dt"])
+        ocn.time_step(dm, cfg["dt"])
+        if check_each_step or s == cfg["steps"] - 1:
+            compare(f"step{s}")
+    assert abs(om.time - dm.time) < 1e-14 and om.iteration == dm.iteration
+    return worst
