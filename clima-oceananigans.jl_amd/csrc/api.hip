@@ -308,7 +308,7 @@ Field* model_field(ocn_model* m, int id) {
   else if (id == OCN_F_W) f = &m->w;
   else if (id == OCN_F_PHY) f = &m->pHY;
   else if (id == OCN_F_PNHS) f = &m->pNHS;
-  else if (id >= OCN_F_GN && id < OCN_F_GN + 3 + m->nt) f = &m->Gn[id - OCN_F_GN];
+  else if (id >= OCN_F_GN && id < OCN_F_GN + 3 + m->nt) f = m->gn_alias_gm ? &m->Gm[id - OCN_F_GN] : &m->Gn[id - OCN_F_GN];
   else if (id >= OCN_F_GM && id < OCN_F_GM + 3 + m->nt) f = &m->Gm[id - OCN_F_GM];
   else if (id >= OCN_F_TRACER && id < OCN_F_TRACER + m->nt) f = &m->tr[id - OCN_F_TRACER];
   else if (id == OCN_F_NU) f = &m->nu_e;
@@ -381,6 +381,18 @@ static void zero_Gm(ocn_model* m) {
   for (int f = 0; f < 3 + m->nt; ++f) hipMemsetAsync(m->Gm[f].d, 0, m->Gm[f].n * sizeof(double), m->ctx->stream);
 }
 
+// one fused (sub)step of the fast path: tendencies + update, rhs, solve, projection + halo images
+static int fused_substep(ocn_model* m, double dt_full, double cn, double cm, int use_m, double dt_stage, bool swap) {
+  launch_fused_tend_step(m, dt_full, cn, cm, use_m);
+  launch_rhs_wrap(m, dt_stage, poisson_rhs_buffer(m->solver));
+  int rc = poisson_run(m);
+  if (rc) return rc;
+  launch_project(m, dt_stage, poisson_rhs_buffer(m->solver));
+  if (swap)
+    for (int f = 0; f < 3; ++f) std::swap(m->Gn[f], m->Gm[f]);   // store_tendencies! as a pointer swap
+  return OCN_OK;
+}
+
 static int time_step_ab2(ocn_model* m, double dt, int force_euler) {
   // quasi_adams_bashforth_2.jl:70-104
   bool euler = force_euler || (dt != m->previous_dt);
@@ -388,6 +400,16 @@ static int time_step_ab2(ocn_model* m, double dt, int force_euler) {
   if (euler) zero_Gm(m);
   m->previous_dt = dt;
   if (m->iteration == 0) update_state(m);
+  if (m->fast_path) {
+    m->gn_alias_gm = false;
+    int rc = fused_substep(m, dt, 1.5 + chi, -(0.5 + chi), 1, dt, true);
+    if (rc) return rc;
+    m->gn_alias_gm = true;   // G^n == G^- after store_tendencies!
+    m->time += dt;
+    m->iteration += 1;
+    m->stage = 1;
+    return OCN_OK;           // update_state!: halos were written by the projection; no pHY', no closure
+  }
   launch_tendencies(m);
   launch_step(m, dt, 1.5 + chi, -(0.5 + chi), 1);
   int rc = pressure_correction(m, dt);
@@ -406,6 +428,18 @@ static int time_step_rk3(ocn_model* m, double dt) {
   const double g1 = 8.0 / 15.0, g2 = 5.0 / 12.0, g3 = 3.0 / 4.0, z2 = -17.0 / 60.0, z3 = -5.0 / 12.0;
   const double gam[3] = {g1, g2, g3}, zet[3] = {0.0, z2, z3};
   const double sdt[3] = {g1 * dt, (g2 + z2) * dt, (g3 + z3) * dt};
+  if (m->fast_path) {
+    m->gn_alias_gm = false;
+    for (int s = 0; s < 3; ++s) {
+      int rc = fused_substep(m, dt, gam[s], zet[s], s > 0, sdt[s], s < 2);
+      if (rc) return rc;
+      m->time += sdt[s];
+      if (s < 2) m->stage += 1;
+    }
+    m->iteration += 1;
+    m->stage = 1;
+    return OCN_OK;
+  }
   for (int s = 0; s < 3; ++s) {
     launch_tendencies(m);
     launch_step(m, dt, gam[s], zet[s], s > 0);
@@ -510,6 +544,16 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
     ocn_model_destroy(m);
     return OCN_ENOMEM;
   }
+  m->fast_path = fused_available(m) ? 1 : 0;
+  if (getenv("OCNHIP_DEBUG")) fprintf(stderr, "[ocnhip] model: fast_path=%d\n", m->fast_path);
+  if (m->fast_path) {
+    int r2 = field_alloc(m, m->us, OCN_FACE, OCN_CENTER, OCN_CENTER) | field_alloc(m, m->vs, OCN_CENTER, OCN_FACE, OCN_CENTER) |
+             field_alloc(m, m->ws, OCN_CENTER, OCN_CENTER, OCN_FACE);
+    if (r2) {
+      ocn_model_destroy(m);
+      return OCN_ENOMEM;
+    }
+  }
   m->solver = poisson_create(m);
   if (!m->solver) {
     ocn_model_destroy(m);
@@ -563,6 +607,7 @@ void* ocn_field_device_ptr(ocn_model* m, int field_id) {
 }
 
 int ocn_field_upload(ocn_model* m, int field_id, const double* host) {
+  if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF) m->gn_alias_gm = false;
   Field* f = model_field(m, field_id);
   if (!f || !host) return OCN_EINVAL;
   OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));
@@ -629,6 +674,7 @@ int ocn_update_state(ocn_model* m) { return m ? update_state(m) : OCN_EINVAL; }
 
 int ocn_compute_tendencies(ocn_model* m) {
   if (!m) return OCN_EINVAL;
+  m->gn_alias_gm = false;
   launch_tendencies(m);
   return OCN_OK;
 }

@@ -33,6 +33,7 @@ static inline void ocn_launch_sync(K kern, dim3 grid, dim3 block, hipStream_t s,
   hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
 }
 #define OCN_SHARED __shared__
+#define OCN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 #else
 // ------------------------------------------------------------------------------------------------
@@ -55,6 +56,7 @@ extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 #define __launch_bounds__(...)
 #define OCN_DEVFN inline
 #define OCN_SHARED static
+#define OCN_SCHED_FENCE() ((void)0)
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };

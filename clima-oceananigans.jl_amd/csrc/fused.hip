@@ -1,0 +1,322 @@
+// fused.hip -- MI355X fast path for the headline configuration: (Periodic, Periodic, Periodic-or-slab),
+// regular spacing, upwind-biased 5th-order advection (WENO5 Z / JS, U5), no closure / Coriolis / buoyancy.
+//
+//   k_tend_step : calculate_G{u,v,w}! + ab2_step_field! / rk3_substep_field! in ONE pass.
+//                 (calculate_nonhydrostatic_tendencies.jl:155-170, quasi_adams_bashforth_2.jl:158-166,
+//                  runge_kutta_3.jl:204-218).  G^- <- G^n becomes a pointer swap (store_tendencies.jl).
+//   k_rhs_wrap  : calculate_pressure_source_term_fft_based_solver! reading the predictor with periodic
+//                 wrap indexing (no halo fill of U* needed)           (solve_for_pressure.jl:15-18)
+//   k_project   : copy_real_component! + _pressure_correct_velocities! + the periodic halo fills of
+//                 update_state! / calculate_pressure_correction!, all in one pass: each thread writes its
+//                 interior value and its periodic images             (pressure_correction.jl:34-40,
+//                 fill_halo_regions_periodic.jl:37-65)
+//
+// Design of k_tend_step (why it looks the way it does):
+//   * the kernel is FP64-VALU bound, not HBM bound: one WENO reconstruction is ~75 DP operations and the
+//     reference evaluates 36 per cell.  Here every face flux is evaluated once (9 per cell + 1/BY ghost
+//     overhead) and only on the upwind side (bitwise equal to upwind_biased_product for finite input).
+//   * a workgroup owns complete x rows (x wrap stays inside the workgroup) of BY-1 output rows plus one
+//     "ghost" row of threads that only produces the y-fluxes of the next row; waves of the ghost row
+//     retire early so the SIMDs stay balanced.
+//   * each thread computes the fluxes through the WEST / SOUTH / BOTTOM faces of its three velocity
+//     cells.  EAST and NORTH fluxes come from the neighbouring threads through LDS (6 doubles per thread,
+//     double buffered, one barrier per level); TOP fluxes are the next level's BOTTOM fluxes, carried in
+//     registers while the workgroup marches up a z-chunk.  z-stencils live in a 6-deep register window.
+#include "internal.h"
+
+#define FUSED_MAX_THREADS 1024
+
+struct FusedArgs {
+  const double *u, *v, *w;        // PARENT-array base pointers (halos valid); all fields share one layout
+  const double *gmu, *gmv, *gmw;  // G^-
+  double *gnu, *gnv, *gnw;        // G^n
+  double *us, *vs, *ws;           // predictor U*
+  unsigned org;                   // byte offset of the first interior cell inside a parent array
+  double dt, cn, cm;
+  int use_m;
+  int KZ;                         // levels per z-chunk
+  int BYo;                        // output rows per workgroup (= blockDim.y - 1)
+};
+
+OCN_DEVFN void sto(double* base, unsigned boff, double v) { *(double*)((char*)base + boff) = v; }
+
+template <int ADV>
+__global__ void __launch_bounds__(FUSED_MAX_THREADS) k_tend_step(GridDev g, FusedArgs a) {
+  // 96 KB flux exchange (double buffered) + 48 KB per-thread carry = 144 KB of the CU's 160 KB
+  OCN_SHARED double lds[2][6][FUSED_MAX_THREADS];
+  OCN_SHARED double own[6][FUSED_MAX_THREADS];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int BX = blockDim.x;
+  const int tid = ty * BX + tx;
+  const int i = tx;
+  const int j = blockIdx.x * a.BYo + ty;
+  const bool ghost = (ty == a.BYo);
+  const bool col_ok = i < g.Nx;
+  const bool row_ok = j < g.Ny;            // output row inside the domain
+  const bool do_y = col_ok && j <= g.Ny;   // south fluxes are needed up to row Ny (the north face of row Ny-1)
+  const bool full = col_ok && row_ok && !ghost;
+  const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
+  const int k0 = blockIdx.y * a.KZ;
+  const int k1 = (k0 + a.KZ < g.Nz) ? k0 + a.KZ : g.Nz;   // outputs for levels k0 .. k1-1
+  const double rdx = g.rdx, rdy = g.rdy, rdz = 1.0 / g.dz;
+  const unsigned cxy = a.org + (unsigned)(col_ok ? i : 0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
+
+  // right neighbour in x with periodic wrap inside the workgroup; upper neighbour in y
+  const int txe = (tx + 1 == g.Nx) ? 0 : tx + 1;
+  const int nid_e = ty * BX + (txe < BX ? txe : tx);
+  const int nid_n = (ty + 1 < (int)blockDim.y ? ty + 1 : ty) * BX + tx;
+
+  // z windows: values at levels k-3 .. k+2
+  double zu[6], zv[6], zw[6];
+  {
+    const unsigned c = cxy + (unsigned)k0 * szb;
+    for (int q = 0; q < 6; ++q) {
+      zu[q] = ldo(a.u, c + (unsigned)(q - 3) * szb);
+      zv[q] = ldo(a.v, c + (unsigned)(q - 3) * szb);
+      zw[q] = ldo(a.w, c + (unsigned)(q - 3) * szb);
+    }
+  }
+  for (int k = k0; k <= k1; ++k) {
+    const unsigned c = cxy + (unsigned)k * szb;
+    const int buf = (k - k0) & 1;
+    const bool last = (k == k1);           // only bottom fluxes are needed at the level above the chunk
+    // 4th-order interpolation from the z window: midway between levels k-1 and k
+    auto symz = [&](const double* z) {
+      double a0 = z[2] - ((z[3] - z[2]) - (z[2] - z[1])) * (1.0 / 6.0);
+      double a1 = z[3] - ((z[4] - z[3]) - (z[3] - z[2])) * (1.0 / 6.0);
+      return 0.5 * (a0 + a1);
+    };
+    auto reconz = [&](const double* z, double ut) {
+      bool pos = ut > 0.0;
+      return recon5<ADV>(pos ? z[0] : z[5], pos ? z[1] : z[4], pos ? z[2] : z[3], pos ? z[3] : z[2],
+                         pos ? z[4] : z[1], pos);
+    };
+    if (!last) {
+      if (full) {
+        // ---- fluxes through the WEST faces of the u, v, w cells ----
+        double utu = sym4_o(a.u, c - sxb, sxb);       // centre i-1: between u[i-1], u[i]
+        lds[buf][0][tid] = utu * recon_o<ADV>(a.u, c, sxb, utu);
+        OCN_SCHED_FENCE();
+        double utv = sym4_o(a.u, c - syb, syb);       // u interpolated in y to the v row (x-face i)
+        lds[buf][1][tid] = utv * recon_o<ADV>(a.v, c, sxb, utv);
+        OCN_SCHED_FENCE();
+        double utw = symz(zu);                        // u interpolated in z to the w level
+        lds[buf][2][tid] = utw * recon_o<ADV>(a.w, c, sxb, utw);
+        OCN_SCHED_FENCE();
+      }
+      if (do_y) {
+        // ---- fluxes through the SOUTH faces (also on the ghost row) ----
+        double vtu = sym4_o(a.v, c - sxb, sxb);       // v interpolated in x to the u column (y-face j)
+        lds[buf][3][tid] = vtu * recon_o<ADV>(a.u, c, syb, vtu);
+        OCN_SCHED_FENCE();
+        double vtv = sym4_o(a.v, c - syb, syb);       // centre j-1
+        lds[buf][4][tid] = vtv * recon_o<ADV>(a.v, c, syb, vtv);
+        OCN_SCHED_FENCE();
+        double vtw = symz(zv);
+        lds[buf][5][tid] = vtw * recon_o<ADV>(a.w, c, syb, vtw);
+        OCN_SCHED_FENCE();
+      }
+    }
+    double Fwu = 0, Fwv = 0, Fww = 0;
+    if (full) {
+      // ---- fluxes through the BOTTOM faces at level k ----
+      double wtu = sym4_o(a.w, c - sxb, sxb);         // w interpolated in x to the u column (between i-1, i)
+      Fwu = wtu * reconz(zu, wtu);
+      OCN_SCHED_FENCE();
+      double wtv = sym4_o(a.w, c - syb, syb);         // w interpolated in y to the v row
+      Fwv = wtv * reconz(zv, wtv);
+      OCN_SCHED_FENCE();
+      double wtw = symz(zw);
+      Fww = wtw * reconz(zw, wtw);
+    }
+    __syncthreads();
+    if (full) {
+      if (k > k0) {
+        // finalize level k-1: G = -(horizontal + (top - bottom)/dz), then the time-stepper update
+        const unsigned cm1 = c - szb;
+        double Gu = -(own[0][tid] + (Fwu - own[3][tid]) * rdz);
+        double Gv = -(own[1][tid] + (Fwv - own[4][tid]) * rdz);
+        double Gw = -(own[2][tid] + (Fww - own[5][tid]) * rdz);
+        sto(a.gnu, cm1, Gu);
+        sto(a.gnv, cm1, Gv);
+        sto(a.gnw, cm1, Gw);
+        double iu, iv, iw;
+        if (a.use_m) {
+          iu = a.dt * (a.cn * Gu + a.cm * ldo(a.gmu, cm1));
+          iv = a.dt * (a.cn * Gv + a.cm * ldo(a.gmv, cm1));
+          iw = a.dt * (a.cn * Gw + a.cm * ldo(a.gmw, cm1));
+        } else {
+          iu = a.dt * a.cn * Gu;
+          iv = a.dt * a.cn * Gv;
+          iw = a.dt * a.cn * Gw;
+        }
+        sto(a.us, cm1, zu[2] + iu);
+        sto(a.vs, cm1, zv[2] + iv);
+        sto(a.ws, cm1, zw[2] + iw);
+      }
+      if (!last) {
+        own[0][tid] = (lds[buf][0][nid_e] - lds[buf][0][tid]) * rdx + (lds[buf][3][nid_n] - lds[buf][3][tid]) * rdy;
+        own[1][tid] = (lds[buf][1][nid_e] - lds[buf][1][tid]) * rdx + (lds[buf][4][nid_n] - lds[buf][4][tid]) * rdy;
+        own[2][tid] = (lds[buf][2][nid_e] - lds[buf][2][tid]) * rdx + (lds[buf][5][nid_n] - lds[buf][5][tid]) * rdy;
+        own[3][tid] = Fwu;
+        own[4][tid] = Fwv;
+        own[5][tid] = Fww;
+      }
+    }
+    if (!last) {
+      // advance the z windows to level k+1
+      for (int q = 0; q < 5; ++q) {
+        zu[q] = zu[q + 1];
+        zv[q] = zv[q + 1];
+        zw[q] = zw[q + 1];
+      }
+      zu[5] = ldo(a.u, c + 3 * szb);
+      zv[5] = ldo(a.v, c + 3 * szb);
+      zw[5] = ldo(a.w, c + 3 * szb);
+    }
+  }
+}
+
+// ---- Poisson right-hand side with wrap indexing (no halo fill of the predictor) ----------------------
+__global__ void k_rhs_wrap(GridDev g, const double* __restrict__ us, const double* __restrict__ vs,
+                           const double* __restrict__ ws, double rdt, int zwrap, double* __restrict__ rhs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  const long sy = g.sy, sz = g.sz;
+  const long c = i + j * sy + k * sz;
+  const long ce = (i + 1 == g.Nx) ? c + 1 - g.Nx : c + 1;
+  const long cn = (j + 1 == g.Ny) ? c + sy - g.Ny * sy : c + sy;
+  const long ct = (zwrap && k + 1 == g.Nz) ? c + sz - g.Nz * sz : c + sz;
+  double div = (us[ce] - us[c]) * g.rdx + (vs[cn] - vs[c]) * g.rdy + (ws[ct] - ws[c]) / g.dz;
+  rhs[i + (long)g.Nx * (j + (long)g.Ny * k)] = div * rdt;
+}
+
+// ---- projection + pressure copy + all periodic halo images --------------------------------------------
+struct ProjArgs {
+  const double* phi;              // compact (Nx,Ny,Nz) solver output
+  const double *us, *vs, *ws;     // predictor (interior-origin pointers)
+  double *u, *v, *w, *p;          // destination fields (interior-origin pointers)
+  double dt;
+  int zwrap;                      // 1: z Periodic on this rank (write z images too)
+};
+
+OCN_DEVFN void store_images(const GridDev& g, double* f, int i, int j, int k, double val, int zwrap) {
+  // offsets of the periodic images of an interior point along each direction
+  long ox[3], oy[3], oz[3];
+  int nx = 0, ny = 0, nz = 0;
+  ox[nx++] = 0;
+  if (i < g.Hx) ox[nx++] = g.Nx;
+  if (i >= g.Nx - g.Hx) ox[nx++] = -g.Nx;
+  oy[ny++] = 0;
+  if (j < g.Hy) oy[ny++] = (long)g.Ny * g.sy;
+  if (j >= g.Ny - g.Hy) oy[ny++] = -(long)g.Ny * g.sy;
+  oz[nz++] = 0;
+  if (zwrap) {
+    if (k < g.Hz) oz[nz++] = (long)g.Nz * g.sz;
+    if (k >= g.Nz - g.Hz) oz[nz++] = -(long)g.Nz * g.sz;
+  }
+  const long c = i + j * g.sy + k * g.sz;
+  for (int c3 = 0; c3 < nz; ++c3)
+    for (int c2 = 0; c2 < ny; ++c2)
+      for (int c1 = 0; c1 < nx; ++c1) f[c + ox[c1] + oy[c2] + oz[c3]] = val;
+}
+
+__global__ void k_project(GridDev g, ProjArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  const long c = i + j * g.sy + k * g.sz;
+  const long Nx = g.Nx, Ny = g.Ny;
+  const long pc = i + Nx * (j + Ny * k);
+  const long pw_ = (i == 0) ? pc + Nx - 1 : pc - 1;
+  const long ps_ = (j == 0) ? pc + Nx * (Ny - 1) : pc - Nx;
+  // below: z wrap on a single rank; on a slab the level below the first one comes from the exchanged halo of p
+  double p0 = a.phi[pc];
+  double pb;
+  if (k > 0) pb = a.phi[pc - Nx * Ny];
+  else if (a.zwrap) pb = a.phi[pc + Nx * Ny * (g.Nz - 1)];
+  else pb = a.p[c - g.sz];
+  double un = a.us[c] - (p0 - a.phi[pw_]) * g.rdx * a.dt;
+  double vn = a.vs[c] - (p0 - a.phi[ps_]) * g.rdy * a.dt;
+  double wn = a.ws[c] - (p0 - pb) / g.dz * a.dt;
+  store_images(g, a.u, i, j, k, un, a.zwrap);
+  store_images(g, a.v, i, j, k, vn, a.zwrap);
+  store_images(g, a.w, i, j, k, wn, a.zwrap);
+  store_images(g, a.p, i, j, k, p0, a.zwrap);
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------
+bool fused_available(const ocn_model* m) {
+  const ocn_grid* g = m->g;
+  if (g->topo[0] != OCN_PERIODIC || g->topo[1] != OCN_PERIODIC || g->topo[2] != OCN_PERIODIC) return false;
+  if (!g->z_regular) return false;
+  int adv = m->d.advection;
+  if (adv != ADV_WENO_Z && adv != ADV_WENO_JS && adv != ADV_U5) return false;
+  if (m->d.closure != OCN_CLOSURE_NONE || m->d.coriolis_fplane || m->d.buoyancy != OCN_BUOYANCY_NONE) return false;
+  if (m->nt != 0) return false;
+  for (int d = 0; d < 3; ++d)
+    if (g->H[d] < 3 || g->N[d] < 2 * g->H[d]) return false;
+  if (g->N[0] > FUSED_MAX_THREADS / 2) return false;   // a workgroup must own complete x rows (+ a ghost row)
+  if (m->u.n * sizeof(double) >= (1ull << 31)) return false;   // 32-bit byte offsets
+  if (getenv("OCNHIP_NO_FUSED")) return false;
+  return true;
+}
+
+void fused_geometry(const ocn_model* m, dim3& block, dim3& grid, int& KZ, int& BYo) {
+  const GridDev& g = m->gd;
+  int BX = ((g.Nx + 63) / 64) * 64;
+  int BY = FUSED_MAX_THREADS / BX;
+  if (BY > 8) BY = 8;
+  if (BY > g.Ny + 1) BY = g.Ny + 1;
+  if (BY < 2) BY = 2;
+  BYo = BY - 1;
+  const char* e = getenv("OCNHIP_FUSED_KZ");
+  KZ = e ? atoi(e) : 32;
+  if (KZ < 1) KZ = 1;
+  if (KZ > g.Nz) KZ = g.Nz;
+  block = dim3(BX, BY, 1);
+  grid = dim3((g.Ny + BYo - 1) / BYo, (g.Nz + KZ - 1) / KZ, 1);
+}
+
+void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m) {
+  ProfScope ps(m->ctx, "fused_tendency_step");
+  FusedArgs a;
+  a.u = m->u.d; a.v = m->v.d; a.w = m->w.d;
+  a.gmu = m->Gm[0].d; a.gmv = m->Gm[1].d; a.gmw = m->Gm[2].d;
+  a.gnu = m->Gn[0].d; a.gnv = m->Gn[1].d; a.gnw = m->Gn[2].d;
+  a.us = m->us.d; a.vs = m->vs.d; a.ws = m->ws.d;
+  a.org = (unsigned)((m->u.Hx + m->u.Hy * m->u.sy + m->u.Hz * m->u.sz) * sizeof(double));
+  a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
+  dim3 block, grid;
+  fused_geometry(m, block, grid, a.KZ, a.BYo);
+  hipStream_t s = m->ctx->stream;
+  switch (m->d.advection) {
+    case ADV_WENO_Z: ocn_launch_sync(k_tend_step<ADV_WENO_Z>, grid, block, s, m->gd, a); break;
+    case ADV_WENO_JS: ocn_launch_sync(k_tend_step<ADV_WENO_JS>, grid, block, s, m->gd, a); break;
+    default: ocn_launch_sync(k_tend_step<ADV_U5>, grid, block, s, m->gd, a); break;
+  }
+}
+
+void launch_rhs_wrap(ocn_model* m, double dt, double* rhs) {
+  ProfScope ps(m->ctx, "rhs");
+  const GridDev& g = m->gd;
+  dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+  ocn_launch(k_rhs_wrap, gr, b, m->ctx->stream, g, (const double*)m->us.interior(), (const double*)m->vs.interior(),
+             (const double*)m->ws.interior(), 1.0 / dt, 1, rhs);
+}
+
+void launch_project(ocn_model* m, double dt, const double* phi) {
+  ProfScope ps(m->ctx, "pcorrect");
+  const GridDev& g = m->gd;
+  ProjArgs a;
+  a.phi = phi;
+  a.us = m->us.interior(); a.vs = m->vs.interior(); a.ws = m->ws.interior();
+  a.u = m->u.interior(); a.v = m->v.interior(); a.w = m->w.interior(); a.p = m->pNHS.interior();
+  a.dt = dt;
+  a.zwrap = 1;
+  dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+  ocn_launch(k_project, gr, b, m->ctx->stream, g, a);
+}

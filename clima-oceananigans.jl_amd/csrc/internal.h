@@ -81,6 +81,7 @@ struct ocn_model {
   int stage = 1;
   double* d_red = nullptr;  // reduction scratch
   int fast_path = 0;        // 1: fused periodic WENO kernels usable
+  bool gn_alias_gm = false; // after a fused AB2 step G^n and G^- are the same buffer (pointer swap instead of a copy)
 };
 
 Field* model_field(ocn_model* m, int id);
@@ -102,6 +103,13 @@ void launch_hydrostatic(ocn_model* m);
 void launch_copy_to_field(ocn_model* m, const double* src, Field& f);
 void launch_maxdiv(ocn_model* m, double* out_dev);
 void launch_amd(ocn_model* m);
+
+// ---- fused.hip -----------------------------------------------------------------------------------------
+bool fused_available(const ocn_model* m);
+void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m);
+void launch_rhs_wrap(ocn_model* m, double dt, double* rhs);
+void launch_project(ocn_model* m, double dt, const double* phi);
+int poisson_run(ocn_model* m);   // transforms + spectral solve on the solver's rhs buffer, in place
 
 // ---- poisson.hip ------------------------------------------------------------------------------------
 PoissonSolver* poisson_create(ocn_model* m);

@@ -298,6 +298,8 @@ static int run_solver(ocn_model* m) {
   return OCN_OK;
 }
 
+int poisson_run(ocn_model* m) { return run_solver(m); }
+
 // solve_for_pressure!(pNHS, solver, dt, U*)  (solve_for_pressure.jl:55-89)
 int poisson_solve(ocn_model* m, double dt) {
   PoissonSolver* s = m->solver;

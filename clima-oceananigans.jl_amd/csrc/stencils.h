@@ -33,7 +33,7 @@ OCN_DEVFN double g_dzf(const GridDev& g, int k) { return g.dzf ? g.dzf[k + g.Hz 
 // value midway between p[0] and p[s]
 OCN_DEVFN double sym2(const double* p, long s) { return 0.5 * (p[0] + p[s]); }
 // I3 of centered_fourth_order.jl:17-24:  f - delta(delta f)/6
-OCN_DEVFN double i3(const double* p, long s) { return p[0] - ((p[s] - p[0]) - (p[0] - p[-s])) / 6.0; }
+OCN_DEVFN double i3(const double* p, long s) { return p[0] - ((p[s] - p[0]) - (p[0] - p[-s])) * (1.0 / 6.0); }
 OCN_DEVFN double sym4(const double* p, long s) { return 0.5 * (i3(p, s) + i3(p + s, s)); }
 
 // ---- fast reciprocal for the WENO weights: one hardware rcp + 2 Newton steps (<= 1 ulp-ish) -------
@@ -58,7 +58,7 @@ OCN_DEVFN double fast_rcp(double x) {
 template <int ADV>
 OCN_DEVFN double recon5(double A3, double A2, double A1, double A0, double B1, bool pos) {
   if (ADV == ADV_U5) {
-    return (2.0 * A3 - 13.0 * A2 + 47.0 * A1 + 27.0 * A0 - 3.0 * B1) / 60.0;
+    return (2.0 * A3 - 13.0 * A2 + 47.0 * A1 + 27.0 * A0 - 3.0 * B1) * (1.0 / 60.0);
   } else {
     const double cL = pos ? 3.0 : 1.0, cR = pos ? 1.0 : 3.0;
     double t0 = A1 - 2.0 * A0 + B1, u0 = cL * A1 - 4.0 * A0 + cR * B1;   // nearest stencil (optimal weight 3/10)
@@ -135,4 +135,28 @@ OCN_DEVFN double adv_flux_b(const double* p, long s, double ut, bool bounded, in
     if (!ok) return ut * sym2(p - s, s);
   }
   return ut * recon_mem<ADV>(p, s, ut);
+}
+
+// ---- byte-offset addressing (fused kernels): base pointer in SGPRs + one 32-bit VGPR byte offset -------
+// Keeps addresses out of 64-bit VGPR pairs (global_load ... v_off, s[base:base+1]); arrays are < 2 GiB.
+OCN_DEVFN double ldo(const double* base, unsigned boff) { return *(const double*)((const char*)base + boff); }
+OCN_DEVFN double i3_o(const double* b, unsigned o, unsigned s) {
+  double c = ldo(b, o);
+  return c - ((ldo(b, o + s) - c) - (c - ldo(b, o - s))) * (1.0 / 6.0);
+}
+// midway between elements at byte offsets o and o + s
+OCN_DEVFN double sym4_o(const double* b, unsigned o, unsigned s) {
+  double m1 = ldo(b, o - s), c0 = ldo(b, o), c1 = ldo(b, o + s), c2 = ldo(b, o + 2 * s);
+  double a0 = c0 - ((c1 - c0) - (c0 - m1)) * (1.0 / 6.0);
+  double a1 = c1 - ((c2 - c1) - (c1 - c0)) * (1.0 / 6.0);
+  return 0.5 * (a0 + a1);
+}
+// upwind reconstruction at the face between elements o - s and o
+template <int ADV>
+OCN_DEVFN double recon_o(const double* b, unsigned o, unsigned s, double ut) {
+  bool pos = ut > 0.0;
+  double m3 = ldo(b, o - 3 * s), m2 = ldo(b, o - 2 * s), m1 = ldo(b, o - s), c0 = ldo(b, o), c1 = ldo(b, o + s),
+         c2 = ldo(b, o + 2 * s);
+  double A3 = pos ? m3 : c2, A2 = pos ? m2 : c1, A1 = pos ? m1 : c0, A0 = pos ? c0 : m1, B1 = pos ? c1 : m2;
+  return recon5<ADV>(A3, A2, A1, A0, B1, pos);
 }
