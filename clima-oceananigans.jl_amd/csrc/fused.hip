@@ -40,7 +40,7 @@ struct FusedArgs {
 
 OCN_DEVFN void sto(double* base, unsigned boff, double v) { *(double*)((char*)base + boff) = v; }
 
-template <int ADV>
+template <int ADV, bool FENCE>
 __global__ void __launch_bounds__(FUSED_MAX_THREADS) k_tend_step(GridDev g, FusedArgs a) {
   // 96 KB flux exchange (double buffered) + 48 KB per-thread carry = 144 KB of the CU's 160 KB
   OCN_SHARED double lds[2][6][FUSED_MAX_THREADS];
@@ -49,7 +49,12 @@ __global__ void __launch_bounds__(FUSED_MAX_THREADS) k_tend_step(GridDev g, Fuse
   const int BX = blockDim.x;
   const int tid = ty * BX + tx;
   const int i = tx;
-  const int j = blockIdx.x * a.BYo + ty;
+  // XCD-aware mapping: workgroups b and b+8 share an XCD (round-robin dispatch), so hand every XCD a
+  // contiguous band of y-tiles of one z-chunk: neighbouring tiles then hit the same L2 for their halo rows.
+  // gridDim.x is padded to a multiple of 8; tiles past the domain fail the row tests below.
+  const int per = gridDim.x / 8;
+  const int ytile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  const int j = ytile * a.BYo + ty;
   const bool ghost = (ty == a.BYo);
   const bool col_ok = i < g.Nx;
   const bool row_ok = j < g.Ny;            // output row inside the domain
@@ -96,25 +101,25 @@ __global__ void __launch_bounds__(FUSED_MAX_THREADS) k_tend_step(GridDev g, Fuse
         // ---- fluxes through the WEST faces of the u, v, w cells ----
         double utu = sym4_o(a.u, c - sxb, sxb);       // centre i-1: between u[i-1], u[i]
         lds[buf][0][tid] = utu * recon_o<ADV>(a.u, c, sxb, utu);
-        OCN_SCHED_FENCE();
+        if (FENCE) OCN_SCHED_FENCE();
         double utv = sym4_o(a.u, c - syb, syb);       // u interpolated in y to the v row (x-face i)
         lds[buf][1][tid] = utv * recon_o<ADV>(a.v, c, sxb, utv);
-        OCN_SCHED_FENCE();
+        if (FENCE) OCN_SCHED_FENCE();
         double utw = symz(zu);                        // u interpolated in z to the w level
         lds[buf][2][tid] = utw * recon_o<ADV>(a.w, c, sxb, utw);
-        OCN_SCHED_FENCE();
+        if (FENCE) OCN_SCHED_FENCE();
       }
       if (do_y) {
         // ---- fluxes through the SOUTH faces (also on the ghost row) ----
         double vtu = sym4_o(a.v, c - sxb, sxb);       // v interpolated in x to the u column (y-face j)
         lds[buf][3][tid] = vtu * recon_o<ADV>(a.u, c, syb, vtu);
-        OCN_SCHED_FENCE();
+        if (FENCE) OCN_SCHED_FENCE();
         double vtv = sym4_o(a.v, c - syb, syb);       // centre j-1
         lds[buf][4][tid] = vtv * recon_o<ADV>(a.v, c, syb, vtv);
-        OCN_SCHED_FENCE();
+        if (FENCE) OCN_SCHED_FENCE();
         double vtw = symz(zv);
         lds[buf][5][tid] = vtw * recon_o<ADV>(a.w, c, syb, vtw);
-        OCN_SCHED_FENCE();
+        if (FENCE) OCN_SCHED_FENCE();
       }
     }
     double Fwu = 0, Fwv = 0, Fww = 0;
@@ -122,10 +127,10 @@ __global__ void __launch_bounds__(FUSED_MAX_THREADS) k_tend_step(GridDev g, Fuse
       // ---- fluxes through the BOTTOM faces at level k ----
       double wtu = sym4_o(a.w, c - sxb, sxb);         // w interpolated in x to the u column (between i-1, i)
       Fwu = wtu * reconz(zu, wtu);
-      OCN_SCHED_FENCE();
+      if (FENCE) OCN_SCHED_FENCE();
       double wtv = sym4_o(a.w, c - syb, syb);         // w interpolated in y to the v row
       Fwv = wtv * reconz(zv, wtv);
-      OCN_SCHED_FENCE();
+      if (FENCE) OCN_SCHED_FENCE();
       double wtw = symz(zw);
       Fww = wtw * reconz(zw, wtw);
     }
@@ -175,6 +180,208 @@ __global__ void __launch_bounds__(FUSED_MAX_THREADS) k_tend_step(GridDev g, Fuse
       zw[5] = ldo(a.w, c + 3 * szb);
     }
   }
+}
+
+// ---- v3: the same algorithm with the level's x/y neighbourhood staged through LDS -------------------------
+// k_tend_step issues ~50 vector-memory instructions per thread and level and all 16 waves of the workgroup
+// stall on them together (measured: VALU busy 50 %, 59 % of wave time in s_waitcnt/barrier).  Here the
+// workgroup loads the level's slab -- (BY+5) rows x (Nx+6) columns of u, v, w -- once (9 loads per thread,
+// issued one level ahead), and every x / y stencil is read from LDS with compile-time offsets from ONE
+// base address (workgroup shape is a template parameter, so row / field strides are immediates).
+//   LDS: slab 3*(BY+5)*(BX+6) + flux exchange 6*T + carry 6*T doubles  (BX = 256, BY = 4: 151.3 KB of 160)
+#define SLAB_MAXG 3
+template <int ADV, int BX, int BY>
+__global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
+  constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
+  constexpr int NG = (NR + BY - 1) / BY;   // row groups of the cooperative slab load
+  OCN_SHARED double slab[3 * NR * SX];     // [field][row][column]; element (f, r, s) <-> (j0 - 3 + r, s - 3)
+  OCN_SHARED double fx[6 * T];             // flux exchange
+  OCN_SHARED double own[6 * T];            // carry: horizontal divergence + bottom fluxes of the previous level
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tid = ty * BX + tx;
+  const int i = tx;
+  const int per = gridDim.x / 8;
+  const int ytile = (blockIdx.x % 8) * per + blockIdx.x / 8;   // XCD-aware (see k_tend_step)
+  const int j0 = ytile * (BY - 1);
+  const int j = j0 + ty;
+  const bool ghost = (ty == BY - 1);
+  const bool col_ok = i < g.Nx;
+  const bool row_ok = j < g.Ny;
+  const bool do_y = col_ok && j <= g.Ny;
+  const bool full = col_ok && row_ok && !ghost;
+  const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
+  const int k0 = blockIdx.y * a.KZ;
+  const int k1 = (k0 + a.KZ < g.Nz) ? k0 + a.KZ : g.Nz;
+  const double rdx = g.rdx, rdy = g.rdy, rdz = 1.0 / g.dz;
+  const unsigned cxy = a.org + (unsigned)(col_ok ? i : 0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
+  const int txe = (tx + 1 == g.Nx) ? 0 : tx + 1;
+  const int nid_e = ty * BX + (txe < BX ? txe : tx);
+  const int nid_n = (ty + 1 < BY ? ty + 1 : ty) * BX + tx;
+
+  // cooperative slab load: thread row ty handles slab rows r = ty + BY*gq of every field
+  const unsigned grow = a.org + (unsigned)(col_ok ? i : 0) * sxb;
+  double pf[3][NG];
+  auto prefetch = [&](int k) {
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+      int r = ty + BY * gq;
+      if (r < NR) {
+        int jg = j0 - 3 + r;
+        if (jg > g.Ny + 2) jg = g.Ny + 2;              // rows past the halo are never used
+        unsigned o = grow + (unsigned)(jg + 3) * syb - 3u * syb + (unsigned)k * szb;
+        pf[0][gq] = ldo(a.u, o);
+        pf[1][gq] = ldo(a.v, o);
+        pf[2][gq] = ldo(a.w, o);
+      }
+    }
+  };
+  const bool img_e = tx < 3, img_w = tx >= g.Nx - 3;
+  auto commit = [&]() {
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+      int r = ty + BY * gq;
+      if (r < NR && col_ok) {
+#pragma unroll
+        for (int fl = 0; fl < 3; ++fl) {
+          double* row = slab + (fl * NR + r) * SX;
+          double val = pf[fl][gq];
+          row[tx + 3] = val;
+          if (img_e) row[tx + 3 + g.Nx] = val;         // periodic images: east halo
+          if (img_w) row[tx + 3 - g.Nx] = val;         // west halo
+        }
+      }
+    }
+  };
+  // lowest corner of this thread's stencil footprint: element (f, ty + d, tx + e) = S[f*NR*SX + d*SX + e],
+  // own cell at d = e = 3.  All offsets below are compile-time constants.
+  const double* S = slab + ty * SX + tx;
+#define SLB(f, d, e) S[(f) * NR * SX + (d) * SX + (e)]
+
+  double zu[6], zv[6], zw[6];
+  {
+    const unsigned c = cxy + (unsigned)k0 * szb;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      zu[q] = ldo(a.u, c + (unsigned)(q - 3) * szb);
+      zv[q] = ldo(a.v, c + (unsigned)(q - 3) * szb);
+      zw[q] = ldo(a.w, c + (unsigned)(q - 3) * szb);
+    }
+  }
+  prefetch(k0);
+  for (int k = k0; k <= k1; ++k) {
+    const unsigned c = cxy + (unsigned)k * szb;
+    const bool last = (k == k1);
+    commit();
+    __syncthreads();
+    auto symz = [&](const double* z) {
+      double a0 = z[2] - ((z[3] - z[2]) - (z[2] - z[1])) * (1.0 / 6.0);
+      double a1 = z[3] - ((z[4] - z[3]) - (z[3] - z[2])) * (1.0 / 6.0);
+      return 0.5 * (a0 + a1);
+    };
+    auto reconz = [&](const double* z, double ut) {
+      bool pos = ut > 0.0;
+      return recon5<ADV>(pos ? z[0] : z[5], pos ? z[1] : z[4], pos ? z[2] : z[3], pos ? z[3] : z[2],
+                         pos ? z[4] : z[1], pos);
+    };
+    auto sym_v = [&](double m2, double m1, double c0, double c1) {   // midway between m1 and c0
+      double a0 = m1 - ((c0 - m1) - (m1 - m2)) * (1.0 / 6.0);
+      double a1 = c0 - ((c1 - c0) - (c0 - m1)) * (1.0 / 6.0);
+      return 0.5 * (a0 + a1);
+    };
+    auto rec_v = [&](double m3, double m2, double m1, double c0, double c1, double c2, double ut) {
+      bool pos = ut > 0.0;                                            // face between m1 and c0
+      return recon5<ADV>(pos ? m3 : c2, pos ? m2 : c1, pos ? m1 : c0, pos ? c0 : m1, pos ? c1 : m2, pos);
+    };
+#define XSYM(f) sym_v(SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4))
+#define YSYM(f) sym_v(SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3))
+#define XREC(f, ut) rec_v(SLB(f, 3, 0), SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4), SLB(f, 3, 5), ut)
+#define YREC(f, ut) rec_v(SLB(f, 0, 3), SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3), SLB(f, 5, 3), ut)
+    if (!last) {
+      if (full) {
+        double utu = XSYM(0);                          // centre i-1
+        fx[0 * T + tid] = utu * XREC(0, utu);
+        OCN_SCHED_FENCE();
+        double utv = YSYM(0);                          // u interpolated in y to the v row
+        fx[1 * T + tid] = utv * XREC(1, utv);
+        OCN_SCHED_FENCE();
+        double utw = symz(zu);                         // u interpolated in z to the w level
+        fx[2 * T + tid] = utw * XREC(2, utw);
+        OCN_SCHED_FENCE();
+      }
+      if (do_y) {
+        double vtu = XSYM(1);                          // v interpolated in x to the u column
+        fx[3 * T + tid] = vtu * YREC(0, vtu);
+        OCN_SCHED_FENCE();
+        double vtv = YSYM(1);                          // centre j-1
+        fx[4 * T + tid] = vtv * YREC(1, vtv);
+        OCN_SCHED_FENCE();
+        double vtw = symz(zv);
+        fx[5 * T + tid] = vtw * YREC(2, vtw);
+        OCN_SCHED_FENCE();
+      }
+    }
+    double Fwu = 0, Fwv = 0, Fww = 0;
+    if (full) {
+      double wtu = XSYM(2);
+      Fwu = wtu * reconz(zu, wtu);
+      OCN_SCHED_FENCE();
+      double wtv = YSYM(2);
+      Fwv = wtv * reconz(zv, wtv);
+      OCN_SCHED_FENCE();
+      double wtw = symz(zw);
+      Fww = wtw * reconz(zw, wtw);
+    }
+#undef XSYM
+#undef YSYM
+#undef XREC
+#undef YREC
+    __syncthreads();
+    if (!last) prefetch(k + 1);            // in flight during the (cheap) finalize stage; committed at the loop top
+    if (full) {
+      if (k > k0) {
+        const unsigned cm1 = c - szb;
+        double Gu = -(own[0 * T + tid] + (Fwu - own[3 * T + tid]) * rdz);
+        double Gv = -(own[1 * T + tid] + (Fwv - own[4 * T + tid]) * rdz);
+        double Gw = -(own[2 * T + tid] + (Fww - own[5 * T + tid]) * rdz);
+        sto(a.gnu, cm1, Gu);
+        sto(a.gnv, cm1, Gv);
+        sto(a.gnw, cm1, Gw);
+        double iu, iv, iw;
+        if (a.use_m) {
+          iu = a.dt * (a.cn * Gu + a.cm * ldo(a.gmu, cm1));
+          iv = a.dt * (a.cn * Gv + a.cm * ldo(a.gmv, cm1));
+          iw = a.dt * (a.cn * Gw + a.cm * ldo(a.gmw, cm1));
+        } else {
+          iu = a.dt * a.cn * Gu;
+          iv = a.dt * a.cn * Gv;
+          iw = a.dt * a.cn * Gw;
+        }
+        sto(a.us, cm1, zu[2] + iu);
+        sto(a.vs, cm1, zv[2] + iv);
+        sto(a.ws, cm1, zw[2] + iw);
+      }
+      if (!last) {
+        own[0 * T + tid] = (fx[0 * T + nid_e] - fx[0 * T + tid]) * rdx + (fx[3 * T + nid_n] - fx[3 * T + tid]) * rdy;
+        own[1 * T + tid] = (fx[1 * T + nid_e] - fx[1 * T + tid]) * rdx + (fx[4 * T + nid_n] - fx[4 * T + tid]) * rdy;
+        own[2 * T + tid] = (fx[2 * T + nid_e] - fx[2 * T + tid]) * rdx + (fx[5 * T + nid_n] - fx[5 * T + tid]) * rdy;
+        own[3 * T + tid] = Fwu;
+        own[4 * T + tid] = Fwv;
+        own[5 * T + tid] = Fww;
+      }
+    }
+    if (!last) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        zu[q] = zu[q + 1];
+        zv[q] = zv[q + 1];
+        zw[q] = zw[q + 1];
+      }
+      zu[5] = ldo(a.u, c + 3 * szb);
+      zv[5] = ldo(a.v, c + 3 * szb);
+      zw[5] = ldo(a.w, c + 3 * szb);
+    }
+  }
+#undef SLB
 }
 
 // ---- Poisson right-hand side with wrap indexing (no halo fill of the predictor) ----------------------
@@ -278,7 +485,9 @@ void fused_geometry(const ocn_model* m, dim3& block, dim3& grid, int& KZ, int& B
   if (KZ < 1) KZ = 1;
   if (KZ > g.Nz) KZ = g.Nz;
   block = dim3(BX, BY, 1);
-  grid = dim3((g.Ny + BYo - 1) / BYo, (g.Nz + KZ - 1) / KZ, 1);
+  int nty = (g.Ny + BYo - 1) / BYo;
+  nty = ((nty + 7) / 8) * 8;               // padded so that the XCD-aware remap covers every tile
+  grid = dim3(nty, (g.Nz + KZ - 1) / KZ, 1);
 }
 
 void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m) {
@@ -293,10 +502,36 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
   dim3 block, grid;
   fused_geometry(m, block, grid, a.KZ, a.BYo);
   hipStream_t s = m->ctx->stream;
+  static const bool fence = getenv("OCNHIP_FENCE") && atoi(getenv("OCNHIP_FENCE")) != 0;
+  static const int variant = getenv("OCNHIP_FUSED_VARIANT") ? atoi(getenv("OCNHIP_FUSED_VARIANT")) : 3;
+  if (variant == 3 && m->gd.Nx <= 256) {
+    // v3 is compiled for three workgroup shapes (complete x rows of up to 64 / 128 / 256 cells)
+    const GridDev& gd = m->gd;
+    int bx = gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
+    int by = bx == 256 ? 4 : 8;
+    int nty = (gd.Ny + by - 2) / (by - 1);
+    nty = ((nty + 7) / 8) * 8;
+    a.BYo = by - 1;
+    dim3 blk(bx, by, 1), grd(nty, (gd.Nz + a.KZ - 1) / a.KZ, 1);
+#define V3_CASE(ADVV)                                                                       \
+    if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4>, grd, blk, s, m->gd, a);      \
+    else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8>, grd, blk, s, m->gd, a); \
+    else ocn_launch_sync(k_tend_step3<ADVV, 64, 8>, grd, blk, s, m->gd, a);
+    switch (m->d.advection) {
+      case ADV_WENO_Z: V3_CASE(ADV_WENO_Z) break;
+      case ADV_WENO_JS: V3_CASE(ADV_WENO_JS) break;
+      default: V3_CASE(ADV_U5) break;
+    }
+#undef V3_CASE
+    return;
+  }
   switch (m->d.advection) {
-    case ADV_WENO_Z: ocn_launch_sync(k_tend_step<ADV_WENO_Z>, grid, block, s, m->gd, a); break;
-    case ADV_WENO_JS: ocn_launch_sync(k_tend_step<ADV_WENO_JS>, grid, block, s, m->gd, a); break;
-    default: ocn_launch_sync(k_tend_step<ADV_U5>, grid, block, s, m->gd, a); break;
+    case ADV_WENO_Z:
+      if (fence) ocn_launch_sync(k_tend_step<ADV_WENO_Z, true>, grid, block, s, m->gd, a);
+      else ocn_launch_sync(k_tend_step<ADV_WENO_Z, false>, grid, block, s, m->gd, a);
+      break;
+    case ADV_WENO_JS: ocn_launch_sync(k_tend_step<ADV_WENO_JS, false>, grid, block, s, m->gd, a); break;
+    default: ocn_launch_sync(k_tend_step<ADV_U5, false>, grid, block, s, m->gd, a); break;
   }
 }
 
