@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(FUSED_MAX_THREADS) k_tend_step(GridDev g, Fuse
 // base address (workgroup shape is a template parameter, so row / field strides are immediates).
 //   LDS: slab 3*(BY+5)*(BX+6) + flux exchange 6*T + carry 6*T doubles  (BX = 256, BY = 4: 151.3 KB of 160)
 #define SLAB_MAXG 3
-template <int ADV, int BX, int BY>
+template <int ADV, int BX, int BY, bool EARLY>
 __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
   constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
   constexpr int NG = (NR + BY - 1) / BY;   // row groups of the cooperative slab load
@@ -273,6 +273,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
     const bool last = (k == k1);
     commit();
     __syncthreads();
+    if (EARLY && !last) prefetch(k + 1);   // next level's slab in flight during the whole flux stage
     auto symz = [&](const double* z) {
       double a0 = z[2] - ((z[3] - z[2]) - (z[2] - z[1])) * (1.0 / 6.0);
       double a1 = z[3] - ((z[4] - z[3]) - (z[3] - z[2])) * (1.0 / 6.0);
@@ -336,7 +337,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
 #undef XREC
 #undef YREC
     __syncthreads();
-    if (!last) prefetch(k + 1);            // in flight during the (cheap) finalize stage; committed at the loop top
+    if (!EARLY && !last) prefetch(k + 1);  // in flight during the (cheap) finalize stage; committed at the loop top
     if (full) {
       if (k > k0) {
         const unsigned cm1 = c - szb;
@@ -509,14 +510,19 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
     const GridDev& gd = m->gd;
     int bx = gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
     int by = bx == 256 ? 4 : 8;
+    static const int by_env = getenv("OCNHIP_FUSED_BY") ? atoi(getenv("OCNHIP_FUSED_BY")) : 0;
+    if (bx == 256 && by_env == 3) by = 3;
+    static const bool early = !(getenv("OCNHIP_FUSED_EARLY") && atoi(getenv("OCNHIP_FUSED_EARLY")) == 0);
     int nty = (gd.Ny + by - 2) / (by - 1);
     nty = ((nty + 7) / 8) * 8;
     a.BYo = by - 1;
     dim3 blk(bx, by, 1), grd(nty, (gd.Nz + a.KZ - 1) / a.KZ, 1);
-#define V3_CASE(ADVV)                                                                       \
-    if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4>, grd, blk, s, m->gd, a);      \
-    else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8>, grd, blk, s, m->gd, a); \
-    else ocn_launch_sync(k_tend_step3<ADVV, 64, 8>, grd, blk, s, m->gd, a);
+#define V3_CASE(ADVV)                                                                               \
+    if (bx == 256 && by == 3) ocn_launch_sync(k_tend_step3<ADVV, 256, 3, true>, grd, blk, s, m->gd, a);   \
+    else if (bx == 256 && early) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true>, grd, blk, s, m->gd, a); \
+    else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, false>, grd, blk, s, m->gd, a);        \
+    else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, false>, grd, blk, s, m->gd, a);        \
+    else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, false>, grd, blk, s, m->gd, a);
     switch (m->d.advection) {
       case ADV_WENO_Z: V3_CASE(ADV_WENO_Z) break;
       case ADV_WENO_JS: V3_CASE(ADV_WENO_JS) break;
