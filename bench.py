@@ -79,7 +79,8 @@ def main():
         dist.init_process_group("gloo")     # rendezvous / barriers / max-reduce only; data path is RCCL in the library
 
     n = tuple(args.size) if args.size else (256, 256, 256)
-    ctx = ocn.Context(local_rank)
+    ndev = int(os.environ.get("OCNHIP_BENCH_NDEV", "0"))     # rehearsal on fewer GPUs than ranks (debug only)
+    ctx = ocn.Context(local_rank % ndev if ndev else local_rank)
     if world > 1:
         from importlib import import_module
         par = import_module("ocnhip.parallel")

@@ -7,6 +7,7 @@
 #ifdef OCN_HOST_EMU
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 emu_barrier g_emu_barrier;
+std::recursive_mutex g_emu_launch_mutex;
 #endif
 
 static char g_last_error[512] = {0};
@@ -74,6 +75,7 @@ int ocn_init(int device_id, ocn_ctx** out) {
 void ocn_destroy(ocn_ctx* ctx) {
   if (!ctx) return;
   prof_collect(ctx);
+  comm_destroy(ctx);
   hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -176,7 +178,7 @@ static int grid_build_dev(ocn_grid* g) {
   d.rdy = 1.0 / d.dy;
   d.zb = g->topo[2] == OCN_BOUNDED;
   d.zflat = g->topo[2] == OCN_FLAT;
-  d.dz = d.zflat ? 1.0 : (double)((long double)g->L[2] / g->N[2]);
+  d.dz = d.zflat ? 1.0 : (double)((long double)g->L[2] / (g->dist ? g->Nzg : g->N[2]));
   hipFree(g->d_dzc);
   hipFree(g->d_dzf);
   g->d_dzc = g->d_dzf = nullptr;
@@ -238,6 +240,28 @@ int ocn_grid_create(ocn_ctx* ctx, const ocn_grid_desc* desc, ocn_grid** out) {
                          "(NonhydrostaticModels.jl:18-27)");
       delete g;
       return OCN_EUNSUPPORTED;
+    }
+  }
+  g->Nzg = g->N[2];
+  g->dist = ctx->nranks > 1 || (getenv("OCNHIP_FORCE_DIST") && atoi(getenv("OCNHIP_FORCE_DIST")) != 0);
+  if (g->dist) {
+    // Distributed/multi_architectures.jl:20-47 -- here ranks = (1, 1, R): z-slabs of the global grid
+    if (g->topo[2] != OCN_PERIODIC || !g->z_regular) {
+      ocn_set_error(ctx, "slab decomposition needs a regular Periodic z direction (the reference's distributed "
+                         "solver is triply periodic too: distributed_fft_based_poisson_solver.jl)");
+      delete g;
+      return OCN_EUNSUPPORTED;
+    }
+    if (g->N[2] % ctx->nranks != 0 || g->N[1] % ctx->nranks != 0) {
+      ocn_set_error(ctx, "Nz and Ny must be divisible by the number of ranks (%d)", ctx->nranks);
+      delete g;
+      return OCN_EINVAL;
+    }
+    g->N[2] = g->Nzg / ctx->nranks;
+    if (g->N[2] < 2 * 3) {
+      ocn_set_error(ctx, "slabs thinner than twice the halo are not supported");
+      delete g;
+      return OCN_EINVAL;
     }
   }
   for (int d = 0; d < 3; ++d)
@@ -332,7 +356,8 @@ static void fill_fields(ocn_model* m, Field** fs, int n) {
   }
   // Julia's insertion sort with the non-strict `fill_first` comparator visits all-periodic directions in
   // the order z, y, x; for periodic fills over full parent extents any order gives the same halos.
-  if (m->g->topo[2] == OCN_PERIODIC) launch_fill_periodic(m, F, 2);
+  if (m->g->dist) comm_halo_exchange_z(m, fs, n);
+  else if (m->g->topo[2] == OCN_PERIODIC) launch_fill_periodic(m, F, 2);
   launch_fill_periodic(m, F, 1);
   launch_fill_periodic(m, F, 0);
 }
@@ -384,10 +409,17 @@ static void zero_Gm(ocn_model* m) {
 // one fused (sub)step of the fast path: tendencies + update, rhs, solve, projection + halo images
 static int fused_substep(ocn_model* m, double dt_full, double cn, double cm, int use_m, double dt_stage, bool swap) {
   launch_fused_tend_step(m, dt_full, cn, cm, use_m);
+  int rc = OCN_OK;
+  if (m->g->dist && (rc = fused_exchange_ws(m))) return rc;        // w* of the level above the slab
   launch_rhs_wrap(m, dt_stage, poisson_rhs_buffer(m->solver));
-  int rc = poisson_run(m);
+  rc = poisson_run(m);
   if (rc) return rc;
+  if (m->g->dist && (rc = fused_exchange_phi(m, poisson_rhs_buffer(m->solver)))) return rc;   // p below the slab
   launch_project(m, dt_stage, poisson_rhs_buffer(m->solver));
+  if (m->g->dist) {
+    Field* fs[4] = {&m->u, &m->v, &m->w, &m->pNHS};
+    if ((rc = comm_halo_exchange_z(m, fs, 4))) return rc;
+  }
   if (swap)
     for (int f = 0; f < 3; ++f) std::swap(m->Gn[f], m->Gm[f]);   // store_tendencies! as a pointer swap
   return OCN_OK;
@@ -540,6 +572,10 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
       fld->bc[s] = bd;
     }
   }
+  if (g->dist && hipMalloc((void**)&m->phi_below, (size_t)g->N[0] * g->N[1] * sizeof(double)) != hipSuccess) {
+    ocn_model_destroy(m);
+    return OCN_ENOMEM;
+  }
   if (hipMalloc((void**)&m->d_red, 64) != hipSuccess) {
     ocn_model_destroy(m);
     return OCN_ENOMEM;
@@ -579,6 +615,7 @@ void ocn_model_destroy(ocn_model* m) {
   }
   for (double* p : m->owned) hipFree(p);
   hipFree(m->d_red);
+  hipFree(m->phi_below);
   poisson_destroy(m->solver);
   delete m;
 }
@@ -765,26 +802,7 @@ int ocn_max_abs_divergence(ocn_model* m, double* out) {
   return OCN_OK;
 }
 
-// ---- multi-GPU (comm.hip replaces these when built with RCCL) ------------------------------------------------------
-#ifndef OCN_WITH_RCCL
-int ocn_comm_unique_id(void* out128) {
-  (void)out128;
-  ocn_set_error(nullptr, "libocnhip was built without RCCL");
-  return OCN_EUNSUPPORTED;
-}
-int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* id) {
-  (void)id;
-  if (!ctx) return OCN_EINVAL;
-  if (nranks == 1) {
-    ctx->rank = 0;
-    ctx->nranks = 1;
-    return OCN_OK;
-  }
-  (void)rank;
-  ocn_set_error(ctx, "libocnhip was built without RCCL");
-  return OCN_EUNSUPPORTED;
-}
-#endif
+// ---- multi-GPU: ocn_comm_unique_id / ocn_comm_init live in comm.hip -----------------------------------------------
 int ocn_comm_rank(const ocn_ctx* ctx, int* rank, int* nranks) {
   if (!ctx) return OCN_EINVAL;
   if (rank) *rank = ctx->rank;

@@ -48,6 +48,7 @@ struct dim3 {
   dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
 };
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+extern std::recursive_mutex g_emu_launch_mutex;   // one emulated kernel at a time (static "LDS" arrays are shared)
 
 #define __global__
 #define __device__
@@ -91,6 +92,7 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
 // barrier-free kernels: plain nested loops
 template <class K, class... A>
 static inline void ocn_launch(K kern, dim3 grid, dim3 block, hipStream_t, A... args) {
+  std::lock_guard<std::recursive_mutex> lk(g_emu_launch_mutex);
   gridDim = grid;
   blockDim = block;
   for (unsigned bz = 0; bz < grid.z; ++bz)
@@ -123,6 +125,7 @@ static inline void __syncthreads() { g_emu_barrier.wait(); }
 
 template <class K, class... A>
 static inline void ocn_launch_sync(K kern, dim3 grid, dim3 block, hipStream_t, A... args) {
+  std::lock_guard<std::recursive_mutex> lk(g_emu_launch_mutex);
   unsigned nt = block.x * block.y * block.z;
   g_emu_barrier.n = nt;
   g_emu_barrier.count = 0;

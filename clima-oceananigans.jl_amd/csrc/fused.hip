@@ -406,6 +406,7 @@ struct ProjArgs {
   const double* phi;              // compact (Nx,Ny,Nz) solver output
   const double *us, *vs, *ws;     // predictor (interior-origin pointers)
   double *u, *v, *w, *p;          // destination fields (interior-origin pointers)
+  const double* phi_below;        // (Nx,Ny) pressure of the level below the slab (slab runs), else null
   double dt;
   int zwrap;                      // 1: z Periodic on this rank (write z images too)
 };
@@ -446,7 +447,7 @@ __global__ void k_project(GridDev g, ProjArgs a) {
   double pb;
   if (k > 0) pb = a.phi[pc - Nx * Ny];
   else if (a.zwrap) pb = a.phi[pc + Nx * Ny * (g.Nz - 1)];
-  else pb = a.p[c - g.sz];
+  else pb = a.phi_below[i + Nx * j];
   double un = a.us[c] - (p0 - a.phi[pw_]) * g.rdx * a.dt;
   double vn = a.vs[c] - (p0 - a.phi[ps_]) * g.rdy * a.dt;
   double wn = a.ws[c] - (p0 - pb) / g.dz * a.dt;
@@ -546,7 +547,7 @@ void launch_rhs_wrap(ocn_model* m, double dt, double* rhs) {
   const GridDev& g = m->gd;
   dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
   ocn_launch(k_rhs_wrap, gr, b, m->ctx->stream, g, (const double*)m->us.interior(), (const double*)m->vs.interior(),
-             (const double*)m->ws.interior(), 1.0 / dt, 1, rhs);
+             (const double*)m->ws.interior(), 1.0 / dt, m->g->dist ? 0 : 1, rhs);
 }
 
 void launch_project(ocn_model* m, double dt, const double* phi) {
@@ -557,7 +558,32 @@ void launch_project(ocn_model* m, double dt, const double* phi) {
   a.us = m->us.interior(); a.vs = m->vs.interior(); a.ws = m->ws.interior();
   a.u = m->u.interior(); a.v = m->v.interior(); a.w = m->w.interior(); a.p = m->pNHS.interior();
   a.dt = dt;
-  a.zwrap = 1;
+  a.zwrap = m->g->dist ? 0 : 1;
+  a.phi_below = m->phi_below;
   dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
   ocn_launch(k_project, gr, b, m->ctx->stream, g, a);
+}
+
+// ---- slab runs: the two one-plane exchanges the fused path needs besides the z-halo exchange -----------------
+// (a) w* of the first level above the slab (for div U* at the top level)
+int fused_exchange_ws(ocn_model* m) {
+  ocn_ctx* c = m->ctx;
+  ProfScope ps(c, "halo_exchange");
+  const int R = c->nranks, r = c->rank, up = (r + 1) % R, dn = (r + R - 1) % R;
+  Field& f = m->ws;
+  const size_t plane = (size_t)f.sz * sizeof(double);
+  char* base = (char*)f.d;
+  std::vector<CommOp> s{{base + plane * (size_t)f.Hz, plane, dn, 7}};
+  std::vector<CommOp> q{{base + plane * (size_t)(m->gd.Nz + f.Hz), plane, up, 7}};
+  return comm_exchange(c, s, q);
+}
+// (b) pressure of the last level below the slab (for dp/dz at the first level)
+int fused_exchange_phi(ocn_model* m, const double* phi) {
+  ocn_ctx* c = m->ctx;
+  ProfScope ps(c, "halo_exchange");
+  const int R = c->nranks, r = c->rank, up = (r + 1) % R, dn = (r + R - 1) % R;
+  const size_t plane = (size_t)m->gd.Nx * m->gd.Ny * sizeof(double);
+  std::vector<CommOp> s{{(char*)phi + plane * (size_t)(m->gd.Nz - 1), plane, up, 8}};
+  std::vector<CommOp> q{{(void*)m->phi_below, plane, dn, 8}};
+  return comm_exchange(c, s, q);
 }

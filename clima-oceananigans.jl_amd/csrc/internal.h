@@ -29,8 +29,17 @@ struct ocn_ctx {
 
 void ocn_set_error(ocn_ctx* ctx, const char* fmt, ...);
 
+struct CommOp {
+  void* buf;
+  size_t bytes;
+  int peer;
+  int tag;
+};
+
 struct ocn_grid {
   ocn_ctx* ctx;
+  int Nzg = 0;          // global Nz (N[2] is this rank's slab)
+  bool dist = false;    // z-slab decomposition active (also forced with one rank by OCNHIP_FORCE_DIST=1)
   ocn_grid_desc d;
   int N[3], H[3], topo[3];
   double L[3], x0[3];
@@ -81,6 +90,7 @@ struct ocn_model {
   int stage = 1;
   double* d_red = nullptr;  // reduction scratch
   int fast_path = 0;        // 1: fused periodic WENO kernels usable
+  double* phi_below = nullptr;   // (Nx,Ny): top plane of the lower neighbour's pressure (slab runs)
   bool gn_alias_gm = false; // after a fused AB2 step G^n and G^- are the same buffer (pointer swap instead of a copy)
 };
 
@@ -109,6 +119,8 @@ bool fused_available(const ocn_model* m);
 void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m);
 void launch_rhs_wrap(ocn_model* m, double dt, double* rhs);
 void launch_project(ocn_model* m, double dt, const double* phi);
+int fused_exchange_ws(ocn_model* m);
+int fused_exchange_phi(ocn_model* m, const double* phi);
 int poisson_run(ocn_model* m);   // transforms + spectral solve on the solver's rhs buffer, in place
 
 // ---- poisson.hip ------------------------------------------------------------------------------------
@@ -117,6 +129,12 @@ void poisson_destroy(PoissonSolver* s);
 int poisson_solve(ocn_model* m, double dt);             // rhs from velocities -> pNHS interior
 int poisson_solve_rhs(ocn_model* m, const double* rhs_dev, double* phi_dev);  // generic (tests)
 double* poisson_rhs_buffer(PoissonSolver* s);
+
+// ---- comm.hip ---------------------------------------------------------------------------------------------
+int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs);
+int comm_halo_exchange_z(ocn_model* m, Field** fs, int n);
+int comm_alltoall(ocn_ctx* c, const void* send, void* recv, size_t block_bytes);
+void comm_destroy(ocn_ctx* c);
 
 // ---- profiling ----------------------------------------------------------------------------------------
 struct ProfScope {

@@ -22,13 +22,16 @@ struct double2_ {
 
 struct PoissonSolver {
   int kind;        // 0: 3-D FFT (z Periodic)   1: 2-D FFT (+ tridiagonal if z Bounded, plain divide if z Flat)
+                   // 2: z-slabs: 2-D FFT per plane, all-to-all to ky-slabs, 1-D FFT along z, and back
   int Nx, Ny, Nz, Nxh;
+  int R = 1, rank = 0, Nzg = 0, Nyl = 0;   // slab decomposition
+  double2_ *ta = nullptr, *tb = nullptr;   // transpose buffers (same size as spec)
   double* rhs = nullptr;      // real (Nx,Ny,Nz)
   double2_* spec = nullptr;   // complex (Nxh,Ny,Nz)
   double* tscr = nullptr;     // Thomas scratch (Nxh*Ny, Nz)
   double *lx = nullptr, *ly = nullptr, *lz = nullptr;  // eigenvalues on the device
 #ifndef OCN_HOST_EMU
-  hipfftHandle fwd = 0, inv = 0;
+  hipfftHandle fwd = 0, inv = 0, zplan = 0;
 #endif
 };
 
@@ -59,6 +62,13 @@ PoissonSolver* poisson_create(ocn_model* m) {
   s->Nz = g->N[2];
   s->Nxh = s->Nx / 2 + 1;
   s->kind = (g->topo[2] == OCN_PERIODIC) ? 0 : 1;
+  if (g->dist) {
+    s->kind = 2;
+    s->R = m->ctx->nranks;
+    s->rank = m->ctx->rank;
+    s->Nzg = g->Nzg;
+    s->Nyl = s->Ny / s->R;
+  }
   size_t nr = (size_t)s->Nx * s->Ny * s->Nz, nc = (size_t)s->Nxh * s->Ny * s->Nz;
   if (hipMalloc((void**)&s->rhs, nr * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&s->spec, nc * sizeof(double2_)) != hipSuccess) {
@@ -73,9 +83,29 @@ PoissonSolver* poisson_create(ocn_model* m) {
   }
   s->lx = upload(eigenvalues_periodic(s->Nx, g->L[0]));
   s->ly = upload(eigenvalues_periodic(s->Ny, g->L[1]));
-  if (g->topo[2] == OCN_PERIODIC) s->lz = upload(eigenvalues_periodic(s->Nz, g->L[2]));
+  if (g->topo[2] == OCN_PERIODIC) s->lz = upload(eigenvalues_periodic(g->dist ? g->Nzg : s->Nz, g->L[2]));
+  if (s->kind == 2) {
+    if (hipMalloc((void**)&s->ta, nc * sizeof(double2_)) != hipSuccess ||
+        hipMalloc((void**)&s->tb, nc * sizeof(double2_)) != hipSuccess) {
+      poisson_destroy(s);
+      return nullptr;
+    }
+  }
 #ifndef OCN_HOST_EMU
   hipfftResult r1, r2;
+  hipfftResult r3 = HIPFFT_SUCCESS;
+  if (s->kind == 2) {
+    // batched 1-D transforms along z of the ky-slab (Nxh, Nyl, Nzg): stride Nxh*Nyl, consecutive batches 1 apart
+    int nz[1] = {s->Nzg};
+    int st = s->Nxh * s->Nyl;
+    r3 = hipfftPlanMany(&s->zplan, 1, nz, nz, st, 1, nz, st, 1, HIPFFT_Z2Z, st);
+    if (r3 == HIPFFT_SUCCESS) hipfftSetStream(s->zplan, m->ctx->stream);
+  }
+  if (r3 != HIPFFT_SUCCESS) {
+    ocn_set_error(m->ctx, "hipfft z-plan creation failed (%d)", (int)r3);
+    poisson_destroy(s);
+    return nullptr;
+  }
   if (s->kind == 0) {
     r1 = hipfftPlan3d(&s->fwd, s->Nz, s->Ny, s->Nx, HIPFFT_D2Z);
     r2 = hipfftPlan3d(&s->inv, s->Nz, s->Ny, s->Nx, HIPFFT_Z2D);
@@ -100,7 +130,10 @@ void poisson_destroy(PoissonSolver* s) {
 #ifndef OCN_HOST_EMU
   if (s->fwd) hipfftDestroy(s->fwd);
   if (s->inv) hipfftDestroy(s->inv);
+  if (s->zplan) hipfftDestroy(s->zplan);
 #endif
+  hipFree(s->ta);
+  hipFree(s->tb);
   hipFree(s->rhs);
   hipFree(s->spec);
   hipFree(s->tscr);
@@ -171,6 +204,53 @@ static void emu_backward(PoissonSolver* s) {
   for (size_t i = 0; i < a.size(); ++i) s->rhs[i] = a[i].real();
 }
 #endif
+
+#ifdef OCN_HOST_EMU
+static void emu_zfft(PoissonSolver* s, int sign) {
+  int n0 = s->Nxh, n1 = s->Nyl, n2 = s->Nzg;
+  std::vector<cplx> a((size_t)n0 * n1 * n2);
+  for (size_t i = 0; i < a.size(); ++i) a[i] = cplx(s->tb[i].x, s->tb[i].y);
+  emu_dft_axis(a, n0, n1, n2, 2, sign);
+  for (size_t i = 0; i < a.size(); ++i) s->tb[i] = {a[i].real(), a[i].imag()};
+}
+#endif
+
+// ---- slab <-> ky-slab reordering around the all-to-all ------------------------------------------------------
+// spec [zl][ky][kx]  <->  t [q][zl][kyl][kx]   with ky = q*Nyl + kyl
+__global__ void k_pack_slab(int Nxh, int Ny, int Nzl, int Nyl, const double2_* __restrict__ spec,
+                            double2_* __restrict__ t, int unpack) {
+  const int kx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ky = blockIdx.y * blockDim.y + threadIdx.y;
+  const int zl = blockIdx.z;
+  if (kx >= Nxh || ky >= Ny || zl >= Nzl) return;
+  const int q = ky / Nyl, kyl = ky - q * Nyl;
+  const size_t is = kx + (size_t)Nxh * (ky + (size_t)Ny * zl);
+  const size_t it = kx + (size_t)Nxh * (kyl + (size_t)Nyl * (zl + (size_t)Nzl * q));
+  if (unpack) const_cast<double2_*>(spec)[is] = t[it];
+  else t[it] = spec[is];
+}
+
+// ky-slab (Nxh, Nyl, Nzg): phi^ = -b^ / (lx + ly + lz) * norm, zero mode on the rank that owns ky = 0
+__global__ void k_scale_spectrum_slab(int Nxh, int Nyl, int Nzg, int ky0, const double* __restrict__ lx,
+                                      const double* __restrict__ ly, const double* __restrict__ lz, double norm,
+                                      double2_* __restrict__ a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= Nxh || j >= Nyl || k >= Nzg) return;
+  const size_t c = i + (size_t)Nxh * (j + (size_t)Nyl * k);
+  double lam = lx[i] + ly[ky0 + j] + lz[k];
+  double2_ v = a[c];
+  if (i == 0 && ky0 + j == 0 && k == 0) {
+    v.x = 0;
+    v.y = 0;
+  } else {
+    double f = -norm / lam;
+    v.x *= f;
+    v.y *= f;
+  }
+  a[c] = v;
+}
 
 // ---- spectral kernels ------------------------------------------------------------------------------------------
 // phi^ = -b^ / (lx + ly + lz) * norm ; zero mode := 0   (fft_based_poisson_solver.jl:106-111)
@@ -269,7 +349,47 @@ static int run_solver(ocn_model* m) {
     emu_forward(s);
 #endif
   }
-  {
+  if (s->kind == 2) {
+    dim3 b(64, 4, 1);
+    const size_t blk = (size_t)s->Nxh * s->Nyl * s->Nz * sizeof(double2_);
+    {
+      ProfScope ps(m->ctx, "spectral_solve");
+      dim3 gr((s->Nxh + 63) / 64, (s->Ny + 3) / 4, s->Nz);
+      ocn_launch(k_pack_slab, gr, b, st, s->Nxh, s->Ny, s->Nz, s->Nyl, (const double2_*)s->spec, s->ta, 0);
+    }
+    int rc = comm_alltoall(m->ctx, s->ta, s->tb, blk);
+    if (rc) return rc;
+    {
+      ProfScope ps(m->ctx, "spectral_solve");
+#ifndef OCN_HOST_EMU
+      if (hipfftExecZ2Z(s->zplan, (hipfftDoubleComplex*)s->tb, (hipfftDoubleComplex*)s->tb, HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
+        ocn_set_error(m->ctx, "hipfftExecZ2Z failed");
+        return OCN_EHIP;
+      }
+#else
+      emu_zfft(s, -1);
+#endif
+      dim3 gr((s->Nxh + 63) / 64, (s->Nyl + 3) / 4, s->Nzg);
+      double norm = 1.0 / ((double)s->Nx * s->Ny * s->Nzg);
+      ocn_launch(k_scale_spectrum_slab, gr, b, st, s->Nxh, s->Nyl, s->Nzg, s->rank * s->Nyl, (const double*)s->lx,
+                 (const double*)s->ly, (const double*)s->lz, norm, s->tb);
+#ifndef OCN_HOST_EMU
+      if (hipfftExecZ2Z(s->zplan, (hipfftDoubleComplex*)s->tb, (hipfftDoubleComplex*)s->tb, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) {
+        ocn_set_error(m->ctx, "hipfftExecZ2Z failed");
+        return OCN_EHIP;
+      }
+#else
+      emu_zfft(s, +1);
+#endif
+    }
+    rc = comm_alltoall(m->ctx, s->tb, s->ta, blk);
+    if (rc) return rc;
+    {
+      ProfScope ps(m->ctx, "spectral_solve");
+      dim3 gr((s->Nxh + 63) / 64, (s->Ny + 3) / 4, s->Nz);
+      ocn_launch(k_pack_slab, gr, b, st, s->Nxh, s->Ny, s->Nz, s->Nyl, (const double2_*)s->spec, s->ta, 1);
+    }
+  } else {
     ProfScope ps(m->ctx, "spectral_solve");
     dim3 b(64, 4, 1);
     if (m->g->topo[2] == OCN_BOUNDED) {
