@@ -243,7 +243,10 @@ int ocn_grid_create(ocn_ctx* ctx, const ocn_grid_desc* desc, ocn_grid** out) {
     }
   }
   g->Nzg = g->N[2];
-  g->dist = ctx->nranks > 1 || (getenv("OCNHIP_FORCE_DIST") && atoi(getenv("OCNHIP_FORCE_DIST")) != 0);
+  // OCNHIP_FORCE_DIST=1 exercises the slab code path (pack / z-plan / self exchange) on one rank, where eligible
+  const bool forced = getenv("OCNHIP_FORCE_DIST") && atoi(getenv("OCNHIP_FORCE_DIST")) != 0 &&
+                      g->topo[2] == OCN_PERIODIC && g->z_regular && g->N[2] >= 6;
+  g->dist = ctx->nranks > 1 || forced;
   if (g->dist) {
     // Distributed/multi_architectures.jl:20-47 -- here ranks = (1, 1, R): z-slabs of the global grid
     if (g->topo[2] != OCN_PERIODIC || !g->z_regular) {

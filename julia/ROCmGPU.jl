@@ -1,0 +1,122 @@
+# ROCmGPU.jl -- the shim a maintainer adds to Oceananigans to route the NonhydrostaticModel hot path to
+# libocnhip.so.  NOT executed in this repository (no Julia toolchain in the build image); it documents the
+# reference-side binding of every entry point of include/ocnhip.h.
+#
+# Strategy (SURVEY.md section 8b): `ROCmGPU <: AbstractArchitecture` owns a context; the *model* is mirrored
+# by an `ocn_model` handle whose device arrays are aliased by the Julia `Field`s (same parent layout), and
+# the phase-level functions are overloaded so that no KernelAbstractions kernel is ever launched.
+
+module ROCmGPUShim
+
+using Oceananigans
+using Oceananigans.Architectures: AbstractArchitecture
+using OffsetArrays
+import Oceananigans.Architectures: device, array_type, arch_array, device_event, architecture
+import Oceananigans.TimeSteppers: time_step!, ab2_step!, rk3_substep!, store_tendencies!, update_state!,
+                                  calculate_tendencies!, calculate_pressure_correction!, pressure_correct_velocities!
+import Oceananigans.BoundaryConditions: fill_halo_regions!
+import Oceananigans.Fields: set!
+
+const libocnhip = get(ENV, "OCNHIP_LIB", "libocnhip.so")
+
+check(rc, ctx=C_NULL) = rc == 0 ? nothing :
+    error("libocnhip: ", unsafe_string(ccall((:ocn_last_error, libocnhip), Cstring, (Ptr{Cvoid},), ctx)))
+
+# ---- architecture (src/Architectures.jl:53-142) ---------------------------------------------------------
+mutable struct ROCmGPU <: AbstractArchitecture
+    ctx :: Ptr{Cvoid}
+end
+
+function ROCmGPU(device_id::Integer = 0)
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ocn_init, libocnhip), Cint, (Cint, Ref{Ptr{Cvoid}}), device_id, ctx))
+    arch = ROCmGPU(ctx[])
+    finalizer(a -> ccall((:ocn_destroy, libocnhip), Cvoid, (Ptr{Cvoid},), a.ctx), arch)
+    return arch
+end
+
+# A device array = library-owned memory + the parent size; host copies go through upload / download.
+struct ROCArray{T, N} <: AbstractArray{T, N}
+    ptr  :: Ptr{T}
+    dims :: NTuple{N, Int}
+end
+Base.size(a::ROCArray) = a.dims
+array_type(::ROCmGPU) = ROCArray
+device_event(::ROCmGPU) = nothing                     # one in-order stream replaces KA events
+Base.wait(::ROCmGPU, ::Nothing) = nothing
+
+# ---- grid + model handles ----------------------------------------------------------------------------------
+struct GridDesc                                        # mirrors `ocn_grid_desc` field by field
+    N::NTuple{3, Int32}; H::NTuple{3, Int32}; topology::NTuple{3, Int32}
+    x0::NTuple{3, Float64}; L::NTuple{3, Float64}; z_faces::Ptr{Float64}; rank::Int32; nranks::Int32
+end
+
+topo_code(::Type{Periodic}) = Int32(0); topo_code(::Type{Bounded}) = Int32(1); topo_code(::Type{Flat}) = Int32(2)
+
+function ocn_grid(arch::ROCmGPU, grid::RectilinearGrid)
+    TX, TY, TZ = topology(grid)
+    zf = grid.Δzᵃᵃᶜ isa Number ? C_NULL : pointer(collect(Float64, grid.zᵃᵃᶠ[1:grid.Nz+1]))
+    desc = GridDesc((grid.Nx, grid.Ny, grid.Nz), (grid.Hx, grid.Hy, grid.Hz), topo_code.((TX, TY, TZ)),
+                    (grid.xᶠᵃᵃ[1], grid.yᵃᶠᵃ[1], grid.zᵃᵃᶠ[1]), (grid.Lx, grid.Ly, grid.Lz), zf, 0, 1)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ocn_grid_create, libocnhip), Cint, (Ptr{Cvoid}, Ref{GridDesc}, Ref{Ptr{Cvoid}}), arch.ctx, desc, h), arch.ctx)
+    return h[]
+end
+
+# `ocn_model_desc` is filled from model.advection / closure / coriolis / buoyancy / boundary_conditions;
+# forcings, Stokes drift, background fields and function-valued BCs are rejected here (not representable).
+# ... (field-by-field, as clima-oceananigans.jl_amd/api.py does for the Python mirror)
+
+# Field data alias the library's parent arrays (same layout as Grids/new_data.jl:33-61):
+function alias_field_data(model_handle, field_id, grid, loc)
+    p = ccall((:ocn_field_device_ptr, libocnhip), Ptr{Float64}, (Ptr{Cvoid}, Cint), model_handle, field_id)
+    T = Oceananigans.Grids.total_size(loc, grid)
+    return Oceananigans.Grids.offset_data(ROCArray{Float64, 3}(p, T), grid, loc)
+end
+
+# ---- phase-level overloads (each is ONE ccall) ---------------------------------------------------------------
+const RM = NonhydrostaticModel{<:Any, <:Any, <:ROCmGPU}   # models living on ROCmGPU (handle kept in model.auxiliary_fields.ocn)
+handle(m) = m.auxiliary_fields.ocn
+
+# TimeSteppers/quasi_adams_bashforth_2.jl:70-104 and runge_kutta_3.jl:81-152 -- preferred, coarsest overload
+function time_step!(model::RM, Δt; euler=false)
+    check(ccall((:ocn_time_step, libocnhip), Cint, (Ptr{Cvoid}, Cdouble, Cint), handle(model), Δt, euler), model.architecture.ctx)
+    # clock mirrors ocn_clock (TimeSteppers/clock.jl:48-60)
+    t = Ref(0.0); it = Ref(Int64(0)); st = Ref(Int32(0))
+    ccall((:ocn_clock, libocnhip), Cint, (Ptr{Cvoid}, Ref{Float64}, Ref{Int64}, Ref{Int32}), handle(model), t, it, st)
+    model.clock.time, model.clock.iteration, model.clock.stage = t[], it[], st[]
+    return nothing
+end
+
+# finer-grained overloads, for callers that drive the phases themselves
+update_state!(model::RM) = check(ccall((:ocn_update_state, libocnhip), Cint, (Ptr{Cvoid},), handle(model)))                        # update_nonhydrostatic_model_state.jl:14
+calculate_tendencies!(model::RM) = check(ccall((:ocn_compute_tendencies, libocnhip), Cint, (Ptr{Cvoid},), handle(model)))           # calculate_nonhydrostatic_tendencies.jl:12
+ab2_step!(model::RM, Δt, χ) = check(ccall((:ocn_ab2_step, libocnhip), Cint, (Ptr{Cvoid}, Cdouble, Cdouble), handle(model), Δt, χ))  # quasi_adams_bashforth_2.jl:116
+rk3_substep!(model::RM, Δt, γ, ζ) = check(ccall((:ocn_rk3_substep, libocnhip), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Cint),
+                                                handle(model), Δt, γ, something(ζ, 0.0), ζ !== nothing))                            # runge_kutta_3.jl:161
+store_tendencies!(model::RM) = check(ccall((:ocn_store_tendencies, libocnhip), Cint, (Ptr{Cvoid},), handle(model)))                 # store_tendencies.jl:14
+calculate_pressure_correction!(model::RM, Δt) = check(ccall((:ocn_pressure_correction, libocnhip), Cint, (Ptr{Cvoid}, Cdouble), handle(model), Δt))           # pressure_correction.jl:10
+pressure_correct_velocities!(model::RM, Δt) = check(ccall((:ocn_pressure_correct_velocities, libocnhip), Cint, (Ptr{Cvoid}, Cdouble), handle(model), Δt))     # pressure_correction.jl:43
+
+# set!(model; ...) : host arrays -> ocn_field_set_interior per field, then the epilogue (set_nonhydrostatic_model.jl:45-58)
+function set!(model::RM; enforce_incompressibility=true, kwargs...)
+    for (name, value) in kwargs
+        host = Array{Float64}(undef, size(getproperty(merge(model.velocities, model.tracers), name)))
+        set!(CPUField(name, model), value); host .= interior(CPUField(name, model))     # stage on the CPU exactly like Fields/set!.jl:21-27
+        check(ccall((:ocn_field_set_interior, libocnhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), handle(model), field_id(model, name), host))
+    end
+    check(ccall((:ocn_set_epilogue, libocnhip), Cint, (Ptr{Cvoid}, Cint), handle(model), enforce_incompressibility))
+end
+
+# Output / checkpoint fetch (OutputWriters/fetch_output.jl:26, checkpointer.jl:158-180): parent arrays incl. G^n, G^-
+function arch_array(::CPU, a::OffsetArray{T, 3, <:ROCArray}) where T
+    host = Array{T}(undef, size(parent(a)))
+    # the owning model + field id travel with the wrapper in the real shim; shown here for one field:
+    # check(ccall((:ocn_field_download, libocnhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), model_handle, field_id, host))
+    return OffsetArray(host, a.offsets...)
+end
+
+# Distributed: MultiArch(ROCmGPU(); ranks=(1, 1, R)) -> ocn_comm_init(ctx, rank, R, id) with the ncclUniqueId
+# broadcast over MPI (Distributed/multi_architectures.jl:20-47); everything else is unchanged.
+
+end # module
