@@ -86,11 +86,7 @@ __global__ void __launch_bounds__(FUSED_MAX_THREADS) k_tend_step(GridDev g, Fuse
     const int buf = (k - k0) & 1;
     const bool last = (k == k1);           // only bottom fluxes are needed at the level above the chunk
     // 4th-order interpolation from the z window: midway between levels k-1 and k
-    auto symz = [&](const double* z) {
-      double a0 = z[2] - ((z[3] - z[2]) - (z[2] - z[1])) * (1.0 / 6.0);
-      double a1 = z[3] - ((z[4] - z[3]) - (z[3] - z[2])) * (1.0 / 6.0);
-      return 0.5 * (a0 + a1);
-    };
+    auto symz = [&](const double* z) { return sym4_v(z[1], z[2], z[3], z[4]); };
     auto reconz = [&](const double* z, double ut) {
       bool pos = ut > 0.0;
       return recon5<ADV>(pos ? z[0] : z[5], pos ? z[1] : z[4], pos ? z[2] : z[3], pos ? z[3] : z[2],
@@ -190,7 +186,7 @@ __global__ void __launch_bounds__(FUSED_MAX_THREADS) k_tend_step(GridDev g, Fuse
 // base address (workgroup shape is a template parameter, so row / field strides are immediates).
 //   LDS: slab 3*(BY+5)*(BX+6) + flux exchange 6*T + carry 6*T doubles  (BX = 256, BY = 4: 151.3 KB of 160)
 #define SLAB_MAXG 3
-template <int ADV, int BX, int BY, bool EARLY>
+template <int ADV, int BX, int BY, bool EARLY, bool FENCE3>
 __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
   constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
   constexpr int NG = (NR + BY - 1) / BY;   // row groups of the cooperative slab load
@@ -274,21 +270,19 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
     commit();
     __syncthreads();
     if (EARLY && !last) prefetch(k + 1);   // next level's slab in flight during the whole flux stage
-    auto symz = [&](const double* z) {
-      double a0 = z[2] - ((z[3] - z[2]) - (z[2] - z[1])) * (1.0 / 6.0);
-      double a1 = z[3] - ((z[4] - z[3]) - (z[3] - z[2])) * (1.0 / 6.0);
-      return 0.5 * (a0 + a1);
-    };
+    double gm0 = 0, gm1 = 0, gm2 = 0;      // G^- of the level finalized below, also fetched early
+    if (EARLY && a.use_m && full && k > k0) {
+      gm0 = ldo(a.gmu, c - szb);
+      gm1 = ldo(a.gmv, c - szb);
+      gm2 = ldo(a.gmw, c - szb);
+    }
+    auto symz = [&](const double* z) { return sym4_v(z[1], z[2], z[3], z[4]); };
     auto reconz = [&](const double* z, double ut) {
       bool pos = ut > 0.0;
       return recon5<ADV>(pos ? z[0] : z[5], pos ? z[1] : z[4], pos ? z[2] : z[3], pos ? z[3] : z[2],
                          pos ? z[4] : z[1], pos);
     };
-    auto sym_v = [&](double m2, double m1, double c0, double c1) {   // midway between m1 and c0
-      double a0 = m1 - ((c0 - m1) - (m1 - m2)) * (1.0 / 6.0);
-      double a1 = c0 - ((c1 - c0) - (c0 - m1)) * (1.0 / 6.0);
-      return 0.5 * (a0 + a1);
-    };
+    auto sym_v = [&](double m2, double m1, double c0, double c1) { return sym4_v(m2, m1, c0, c1); };  // midway m1|c0
     auto rec_v = [&](double m3, double m2, double m1, double c0, double c1, double c2, double ut) {
       bool pos = ut > 0.0;                                            // face between m1 and c0
       return recon5<ADV>(pos ? m3 : c2, pos ? m2 : c1, pos ? m1 : c0, pos ? c0 : m1, pos ? c1 : m2, pos);
@@ -301,34 +295,34 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
       if (full) {
         double utu = XSYM(0);                          // centre i-1
         fx[0 * T + tid] = utu * XREC(0, utu);
-        OCN_SCHED_FENCE();
+        if (FENCE3) OCN_SCHED_FENCE();
         double utv = YSYM(0);                          // u interpolated in y to the v row
         fx[1 * T + tid] = utv * XREC(1, utv);
-        OCN_SCHED_FENCE();
+        if (FENCE3) OCN_SCHED_FENCE();
         double utw = symz(zu);                         // u interpolated in z to the w level
         fx[2 * T + tid] = utw * XREC(2, utw);
-        OCN_SCHED_FENCE();
+        if (FENCE3) OCN_SCHED_FENCE();
       }
       if (do_y) {
         double vtu = XSYM(1);                          // v interpolated in x to the u column
         fx[3 * T + tid] = vtu * YREC(0, vtu);
-        OCN_SCHED_FENCE();
+        if (FENCE3) OCN_SCHED_FENCE();
         double vtv = YSYM(1);                          // centre j-1
         fx[4 * T + tid] = vtv * YREC(1, vtv);
-        OCN_SCHED_FENCE();
+        if (FENCE3) OCN_SCHED_FENCE();
         double vtw = symz(zv);
         fx[5 * T + tid] = vtw * YREC(2, vtw);
-        OCN_SCHED_FENCE();
+        if (FENCE3) OCN_SCHED_FENCE();
       }
     }
     double Fwu = 0, Fwv = 0, Fww = 0;
     if (full) {
       double wtu = XSYM(2);
       Fwu = wtu * reconz(zu, wtu);
-      OCN_SCHED_FENCE();
+      if (FENCE3) OCN_SCHED_FENCE();
       double wtv = YSYM(2);
       Fwv = wtv * reconz(zv, wtv);
-      OCN_SCHED_FENCE();
+      if (FENCE3) OCN_SCHED_FENCE();
       double wtw = symz(zw);
       Fww = wtw * reconz(zw, wtw);
     }
@@ -349,9 +343,14 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
         sto(a.gnw, cm1, Gw);
         double iu, iv, iw;
         if (a.use_m) {
-          iu = a.dt * (a.cn * Gu + a.cm * ldo(a.gmu, cm1));
-          iv = a.dt * (a.cn * Gv + a.cm * ldo(a.gmv, cm1));
-          iw = a.dt * (a.cn * Gw + a.cm * ldo(a.gmw, cm1));
+          if (!EARLY) {
+            gm0 = ldo(a.gmu, cm1);
+            gm1 = ldo(a.gmv, cm1);
+            gm2 = ldo(a.gmw, cm1);
+          }
+          iu = a.dt * (a.cn * Gu + a.cm * gm0);
+          iv = a.dt * (a.cn * Gv + a.cm * gm1);
+          iw = a.dt * (a.cn * Gw + a.cm * gm2);
         } else {
           iu = a.dt * a.cn * Gu;
           iv = a.dt * a.cn * Gv;
@@ -519,11 +518,12 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
     a.BYo = by - 1;
     dim3 blk(bx, by, 1), grd(nty, (gd.Nz + a.KZ - 1) / a.KZ, 1);
 #define V3_CASE(ADVV)                                                                               \
-    if (bx == 256 && by == 3) ocn_launch_sync(k_tend_step3<ADVV, 256, 3, true>, grd, blk, s, m->gd, a);   \
-    else if (bx == 256 && early) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true>, grd, blk, s, m->gd, a); \
-    else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, false>, grd, blk, s, m->gd, a);        \
-    else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, false>, grd, blk, s, m->gd, a);        \
-    else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, false>, grd, blk, s, m->gd, a);
+    if (bx == 256 && by == 3) ocn_launch_sync(k_tend_step3<ADVV, 256, 3, true, false>, grd, blk, s, m->gd, a);   \
+    else if (bx == 256 && early && fence) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, true>, grd, blk, s, m->gd, a); \
+    else if (bx == 256 && early) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false>, grd, blk, s, m->gd, a); \
+    else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, false, true>, grd, blk, s, m->gd, a);        \
+    else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false>, grd, blk, s, m->gd, a);        \
+    else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false>, grd, blk, s, m->gd, a);
     switch (m->d.advection) {
       case ADV_WENO_Z: V3_CASE(ADV_WENO_Z) break;
       case ADV_WENO_JS: V3_CASE(ADV_WENO_JS) break;

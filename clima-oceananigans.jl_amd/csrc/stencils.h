@@ -34,7 +34,11 @@ OCN_DEVFN double g_dzf(const GridDev& g, int k) { return g.dzf ? g.dzf[k + g.Hz 
 OCN_DEVFN double sym2(const double* p, long s) { return 0.5 * (p[0] + p[s]); }
 // I3 of centered_fourth_order.jl:17-24:  f - delta(delta f)/6
 OCN_DEVFN double i3(const double* p, long s) { return p[0] - ((p[s] - p[0]) - (p[0] - p[-s])) * (1.0 / 6.0); }
-OCN_DEVFN double sym4(const double* p, long s) { return 0.5 * (i3(p, s) + i3(p + s, s)); }
+// 0.5 (I3(p) + I3(p+s)) == (7 (p[0] + p[s]) - (p[-s] + p[2s])) / 12
+OCN_DEVFN double sym4_v(double m2, double m1, double c0, double c1) {
+  return fma(7.0 / 12.0, m1 + c0, (-1.0 / 12.0) * (m2 + c1));
+}
+OCN_DEVFN double sym4(const double* p, long s) { return sym4_v(p[-s], p[0], p[s], p[2 * s]); }
 
 // ---- fast reciprocal for the WENO weights: one hardware rcp + 2 Newton steps (<= 1 ulp-ish) -------
 OCN_DEVFN double fast_rcp(double x) {
@@ -60,34 +64,43 @@ OCN_DEVFN double recon5(double A3, double A2, double A1, double A0, double B1, b
   if (ADV == ADV_U5) {
     return (2.0 * A3 - 13.0 * A2 + 47.0 * A1 + 27.0 * A0 - 3.0 * B1) * (1.0 / 60.0);
   } else {
-    const double cL = pos ? 3.0 : 1.0, cR = pos ? 1.0 : 3.0;
-    double t0 = A1 - 2.0 * A0 + B1, u0 = cL * A1 - 4.0 * A0 + cR * B1;   // nearest stencil (optimal weight 3/10)
-    double t1 = A2 - 2.0 * A1 + A0, u1 = A2 - A0;                         // middle  stencil (3/5)
-    double t2 = A3 - 2.0 * A2 + A1, u2 = cR * A3 - 4.0 * A2 + cL * A1;   // farthest stencil (1/10)
-    double b0 = (13.0 / 12.0) * t0 * t0 + 0.25 * u0 * u0;
-    double b1 = (13.0 / 12.0) * t1 * t1 + 0.25 * u1 * u1;
-    double b2 = (13.0 / 12.0) * t2 * t2 + 0.25 * u2 * u2;
-    double p0 = (1.0 / 3.0) * A1 + (5.0 / 6.0) * A0 - (1.0 / 6.0) * B1;
-    double p1 = -(1.0 / 6.0) * A2 + (5.0 / 6.0) * A1 + (1.0 / 3.0) * A0;
-    double p2 = (1.0 / 3.0) * A3 - (7.0 / 6.0) * A2 + (11.0 / 6.0) * A1;
+    // Everything is expressed through the four first differences of the stencil (fewer FP64 operations than
+    // the textbook form; the kernel that uses this is FP64-issue bound):
+    //   second differences        t_k  (the 13/12 terms)
+    //   biased first differences  u_k  (the 1/4 terms; the as-written right-biased variants differ from the
+    //                                   mirrored left-biased ones only in which end carries the factor 3)
+    //   candidate values          p_k = A1 + (linear combination of differences)
+    const double e1 = A2 - A3, e2 = A1 - A2, e3 = A0 - A1, e4 = B1 - A0;
+    const double t0 = e4 - e3, t1 = e3 - e2, t2 = e2 - e1;
+    const double s2 = pos ? 2.0 : -2.0;
+    const double u0 = fma(-s2, pos ? e3 : e4, t0);   // pos: e4 - 3 e3 = 3A1-4A0+B1 ; neg: 3 e4 - e3 = A1-4A0+3B1
+    const double u1 = e2 + e3;                       // (A0 - A2); enters squared
+    const double u2 = fma(s2, pos ? e2 : e1, t2);    // pos: 3 e2 - e1 = A3-4A2+3A1 ; neg: e2 - 3 e1 = 3A3-4A2+A1
     const double eps = 1e-6;
-    double d0 = b0 + eps, d1 = b1 + eps, d2 = b2 + eps;
+    // d_k = beta_k + eps = 13/12 t^2 + (1/4 u^2 + eps)
+    const double d0 = fma(13.0 / 12.0, t0 * t0, fma(0.25, u0 * u0, eps));
+    const double d1 = fma(13.0 / 12.0, t1 * t1, fma(0.25, u1 * u1, eps));
+    const double d2 = fma(13.0 / 12.0, t2 * t2, fma(0.25, u2 * u2, eps));
+    // p_k - A1
+    const double p0 = fma(2.0 / 3.0, e3, (-1.0 / 6.0) * e4);
+    const double p1 = fma(1.0 / 3.0, e3, (1.0 / 6.0) * e2);
+    const double p2 = fma(5.0 / 6.0, e2, (-1.0 / 3.0) * e1);
+    const double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
     double a0, a1, a2;
     if (ADV == ADV_WENO_Z) {
-      // alpha_k = C_k (1 + (tau/d_k)^2) = C_k (d_k^2 + tau^2) / d_k^2 ; common denominator d0^2 d1^2 d2^2
-      double tau = fabs(b2 - b0), tt = tau * tau;
-      double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
-      a0 = 0.3 * (q0 + tt) * (q1 * q2);
-      a1 = 0.6 * (q1 + tt) * (q0 * q2);
-      a2 = 0.1 * (q2 + tt) * (q0 * q1);
+      // alpha_k = C_k (1 + (tau/d_k)^2) ~ C_k (q_k + tau^2) prod_{j != k} q_j   with C = (3, 6, 1)/10
+      const double tau = d2 - d0, tt = tau * tau, tt3 = 3.0 * tt;
+      a0 = fma(3.0, q0, tt3) * (q1 * q2);
+      a1 = fma(6.0, q1, tt3 + tt3) * (q0 * q2);
+      a2 = (q2 + tt) * (q0 * q1);
     } else {
       // alpha_k = C_k / d_k^2
-      double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
-      a0 = 0.3 * (q1 * q2);
-      a1 = 0.6 * (q0 * q2);
-      a2 = 0.1 * (q0 * q1);
+      a0 = 3.0 * (q1 * q2);
+      a1 = 6.0 * (q0 * q2);
+      a2 = q0 * q1;
     }
-    return (a0 * p0 + a1 * p1 + a2 * p2) * fast_rcp(a0 + a1 + a2);
+    const double num = fma(a0, p0, fma(a1, p1, a2 * p2));
+    return fma(num, fast_rcp(a0 + a1 + a2), A1);
   }
 }
 
@@ -146,10 +159,7 @@ OCN_DEVFN double i3_o(const double* b, unsigned o, unsigned s) {
 }
 // midway between elements at byte offsets o and o + s
 OCN_DEVFN double sym4_o(const double* b, unsigned o, unsigned s) {
-  double m1 = ldo(b, o - s), c0 = ldo(b, o), c1 = ldo(b, o + s), c2 = ldo(b, o + 2 * s);
-  double a0 = c0 - ((c1 - c0) - (c0 - m1)) * (1.0 / 6.0);
-  double a1 = c1 - ((c2 - c1) - (c1 - c0)) * (1.0 / 6.0);
-  return 0.5 * (a0 + a1);
+  return sym4_v(ldo(b, o - s), ldo(b, o), ldo(b, o + s), ldo(b, o + 2 * s));
 }
 // upwind reconstruction at the face between elements o - s and o
 template <int ADV>
