@@ -302,6 +302,10 @@ class NonhydrostaticModel:
         self.pNHS = FieldView(self, L.F_PNHS, "p")
         self.pHY = FieldView(self, L.F_PHY, "p") if grid.topo[2] != Flat else None
         self.tracers = {n: FieldView(self, L.F_TRACER + i, n) for i, n in enumerate(self.tracer_names)}
+        self.nu_e = self.kappa_e = None
+        if isinstance(closure, AnisotropicMinimumDissipation):
+            self.nu_e = FieldView(self, L.F_NU, "nu")
+            self.kappa_e = {n: FieldView(self, L.F_KAPPA + i, n) for i, n in enumerate(self.tracer_names)}
         self.Gn = {n: FieldView(self, L.F_GN + i, n) for i, n in enumerate(names)}
         self.Gm = {n: FieldView(self, L.F_GM + i, n) for i, n in enumerate(names)}
 

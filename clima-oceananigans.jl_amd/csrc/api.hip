@@ -501,8 +501,8 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
   ocn_ctx* ctx = g->ctx;
   if (desc->n_tracers < 0 || desc->n_tracers > OCN_MAX_TRACERS) return OCN_EINVAL;
   if (desc->advection < OCN_ADV_NONE || desc->advection > OCN_ADV_WENO5_JS) return OCN_EINVAL;
-  if (desc->closure == OCN_CLOSURE_AMD) {
-    ocn_set_error(ctx, "AnisotropicMinimumDissipation is not implemented yet");
+  if (desc->closure == OCN_CLOSURE_AMD && g->topo[2] == OCN_FLAT) {
+    ocn_set_error(ctx, "AnisotropicMinimumDissipation on a Flat z direction is outside the path");
     return OCN_EUNSUPPORTED;
   }
   // halo inflation (nonhydrostatic_model.jl:140-148; Advection.jl:40)
@@ -532,6 +532,11 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
   rc |= field_alloc(m, m->pNHS, OCN_CENTER, OCN_CENTER, OCN_CENTER);
   if (g->topo[2] != OCN_FLAT) rc |= field_alloc(m, m->pHY, OCN_CENTER, OCN_CENTER, OCN_CENTER);
   for (int t = 0; t < m->nt; ++t) rc |= field_alloc(m, m->tr[t], OCN_CENTER, OCN_CENTER, OCN_CENTER);
+  if (desc->closure == OCN_CLOSURE_AMD) {
+    // DiffusivityFields(grid, tracers, bcs, ::AMD): nu_e and kappa_e per tracer, CenterFields with default BCs
+    rc |= field_alloc(m, m->nu_e, OCN_CENTER, OCN_CENTER, OCN_CENTER);
+    for (int t = 0; t < m->nt; ++t) rc |= field_alloc(m, m->kappa_e[t], OCN_CENTER, OCN_CENTER, OCN_CENTER);
+  }
   for (int f = 0; f < 3 + m->nt; ++f) {
     int lx = f == 0, ly = f == 1, lz = f == 2;
     rc |= field_alloc(m, m->Gn[f], lx, ly, lz);
@@ -547,6 +552,10 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
   default_bcs(m, m->pNHS, true);
   if (m->pHY.present) default_bcs(m, m->pHY, true);
   for (int t = 0; t < m->nt; ++t) default_bcs(m, m->tr[t], false);
+  if (m->nu_e.present) {
+    default_bcs(m, m->nu_e, true);
+    for (int t = 0; t < m->nt; ++t) default_bcs(m, m->kappa_e[t], true);
+  }
   // user boundary conditions (only z sides can be non-periodic here)
   for (int f = 0; f < 3 + m->nt; ++f) {
     Field* fld = f == 0 ? &m->u : f == 1 ? &m->v : f == 2 ? &m->w : &m->tr[f - 3];

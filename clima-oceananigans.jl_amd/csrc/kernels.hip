@@ -512,4 +512,134 @@ void launch_maxdiv(ocn_model* m, double* out_dev) {
              (const double*)m->w.interior(), out_dev);
 }
 
-void launch_amd(ocn_model* m) { (void)m; }
+// ---- AnisotropicMinimumDissipation predictors (anisotropic_minimum_dissipation.jl:138-178,229-344) --------
+// One thread per cell; every quantity is the reference's index function evaluated at the calling index
+// (filter widths are always 2 x the *centre* spacing at that index, :213-226; norm_dx_u etc. are the plain
+// gradients, velocity_tracer_gradients.jl:126-128; cy_uy uses I_xz on norm_dy_w as written, :326).
+struct AmdCtx {
+  GridDev g;
+  const double *u, *v, *w;
+  long sy, sz;
+  double rdx, rdy, Dx, Dy;
+};
+OCN_DEVFN double amd_Dz(const AmdCtx& a, int k) { return 2.0 * g_dzc(a.g, k); }
+OCN_DEVFN double amd_dxu(const AmdCtx& a, long p) { return (a.u[p + 1] - a.u[p]) * a.rdx; }
+OCN_DEVFN double amd_dyv(const AmdCtx& a, long p) { return (a.v[p + a.sy] - a.v[p]) * a.rdy; }
+OCN_DEVFN double amd_dzw(const AmdCtx& a, long p, int k) { return (a.w[p + a.sz] - a.w[p]) / g_dzc(a.g, k); }
+OCN_DEVFN double amd_ndxv(const AmdCtx& a, long p) { return a.Dx / a.Dy * ((a.v[p] - a.v[p - 1]) * a.rdx); }
+OCN_DEVFN double amd_ndyu(const AmdCtx& a, long p) { return a.Dy / a.Dx * ((a.u[p] - a.u[p - a.sy]) * a.rdy); }
+OCN_DEVFN double amd_ndxw(const AmdCtx& a, long p, int k) { return a.Dx / amd_Dz(a, k) * ((a.w[p] - a.w[p - 1]) * a.rdx); }
+OCN_DEVFN double amd_ndzu(const AmdCtx& a, long p, int k) { return amd_Dz(a, k) / a.Dx * ((a.u[p] - a.u[p - a.sz]) / g_dzf(a.g, k)); }
+OCN_DEVFN double amd_ndyw(const AmdCtx& a, long p, int k) { return a.Dy / amd_Dz(a, k) * ((a.w[p] - a.w[p - a.sy]) * a.rdy); }
+OCN_DEVFN double amd_ndzv(const AmdCtx& a, long p, int k) { return amd_Dz(a, k) / a.Dy * ((a.v[p] - a.v[p - a.sz]) / g_dzf(a.g, k)); }
+OCN_DEVFN double amd_S12(const AmdCtx& a, long p) { return 0.5 * (amd_ndyu(a, p) + amd_ndxv(a, p)); }
+OCN_DEVFN double amd_S13(const AmdCtx& a, long p, int k) { return 0.5 * (amd_ndzu(a, p, k) + amd_ndxw(a, p, k)); }
+OCN_DEVFN double amd_S23(const AmdCtx& a, long p, int k) { return 0.5 * (amd_ndzv(a, p, k) + amd_ndyw(a, p, k)); }
+// double interpolations to ccc of a function f(p, k): I_y(I_x f), I_z(I_x f), I_z(I_y f)
+template <class F> OCN_DEVFN double amd_Ixy(const AmdCtx& a, long p, int k, F f) {
+  return 0.5 * (0.5 * (f(p, k) + f(p + 1, k)) + 0.5 * (f(p + a.sy, k) + f(p + 1 + a.sy, k)));
+}
+template <class F> OCN_DEVFN double amd_Ixz(const AmdCtx& a, long p, int k, F f) {
+  return 0.5 * (0.5 * (f(p, k) + f(p + 1, k)) + 0.5 * (f(p + a.sz, k + 1) + f(p + 1 + a.sz, k + 1)));
+}
+template <class F> OCN_DEVFN double amd_Iyz(const AmdCtx& a, long p, int k, F f) {
+  return 0.5 * (0.5 * (f(p, k) + f(p + a.sy, k)) + 0.5 * (f(p + a.sz, k + 1) + f(p + a.sy + a.sz, k + 1)));
+}
+
+__global__ void k_amd_nu(AmdCtx a, double Cnu, double* __restrict__ nu) {
+  const GridDev& g = a.g;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  const long c = i + j * a.sy + k * a.sz;
+  auto sq = [](double x) { return x * x; };
+  auto ndxv = [&](long p, int) { return amd_ndxv(a, p); };
+  auto ndyu = [&](long p, int) { return amd_ndyu(a, p); };
+  auto ndxw = [&](long p, int kk) { return amd_ndxw(a, p, kk); };
+  auto ndzu = [&](long p, int kk) { return amd_ndzu(a, p, kk); };
+  auto ndyw = [&](long p, int kk) { return amd_ndyw(a, p, kk); };
+  auto ndzv = [&](long p, int kk) { return amd_ndzv(a, p, kk); };
+  auto S12 = [&](long p, int) { return amd_S12(a, p); };
+  auto S13 = [&](long p, int kk) { return amd_S13(a, p, kk); };
+  auto S23 = [&](long p, int kk) { return amd_S23(a, p, kk); };
+  const double dxu = amd_dxu(a, c), dyv = amd_dyv(a, c), dzw = amd_dzw(a, c, k);
+  const double S11 = dxu, S22 = dyv, S33 = dzw;
+  // squares and products interpolated to ccc
+  const double xy_dxv2 = amd_Ixy(a, c, k, [&](long p, int kk) { return sq(ndxv(p, kk)); });
+  const double xy_dyu2 = amd_Ixy(a, c, k, [&](long p, int kk) { return sq(ndyu(p, kk)); });
+  const double xz_dxw2 = amd_Ixz(a, c, k, [&](long p, int kk) { return sq(ndxw(p, kk)); });
+  const double xz_dzu2 = amd_Ixz(a, c, k, [&](long p, int kk) { return sq(ndzu(p, kk)); });
+  const double yz_dyw2 = amd_Iyz(a, c, k, [&](long p, int kk) { return sq(ndyw(p, kk)); });
+  const double yz_dzv2 = amd_Iyz(a, c, k, [&](long p, int kk) { return sq(ndzv(p, kk)); });
+  const double q = sq(dxu) + sq(dyv) + sq(dzw) + xy_dxv2 + xy_dyu2 + xz_dxw2 + xz_dzu2 + yz_dyw2 + yz_dzv2;
+  double nus = 0.0;
+  if (q != 0.0) {
+    const double r1 = S11 * sq(dxu) + S22 * xy_dxv2 + S33 * xz_dxw2 +
+                      2 * dxu * amd_Ixy(a, c, k, [&](long p, int kk) { return ndxv(p, kk) * S12(p, kk); }) +
+                      2 * dxu * amd_Ixz(a, c, k, [&](long p, int kk) { return ndxw(p, kk) * S13(p, kk); }) +
+                      2 * amd_Ixy(a, c, k, ndxv) * amd_Ixz(a, c, k, ndxw) * amd_Iyz(a, c, k, S23);
+    const double r2 = S11 * xy_dyu2 + S22 * sq(dyv) + S33 * yz_dyw2 +
+                      2 * dyv * amd_Ixy(a, c, k, [&](long p, int kk) { return ndyu(p, kk) * S12(p, kk); }) +
+                      2 * amd_Ixy(a, c, k, ndyu) * amd_Iyz(a, c, k, ndyw) * amd_Ixz(a, c, k, S13) +
+                      2 * dyv * amd_Iyz(a, c, k, [&](long p, int kk) { return ndyw(p, kk) * S23(p, kk); });
+    const double r3 = S11 * xz_dzu2 + S22 * yz_dzv2 + S33 * sq(dzw) +
+                      2 * amd_Ixz(a, c, k, ndzu) * amd_Iyz(a, c, k, ndzv) * amd_Ixy(a, c, k, S12) +
+                      2 * dzw * amd_Ixz(a, c, k, [&](long p, int kk) { return ndzu(p, kk) * S13(p, kk); }) +
+                      2 * dzw * amd_Iyz(a, c, k, [&](long p, int kk) { return ndzv(p, kk) * S23(p, kk); });
+    const double Dz = amd_Dz(a, k);
+    const double d2 = 3.0 / (1.0 / (a.Dx * a.Dx) + 1.0 / (a.Dy * a.Dy) + 1.0 / (Dz * Dz));
+    nus = -Cnu * d2 * (r1 + r2 + r3) / q;
+  }
+  nu[c] = fmax(0.0, nus);
+}
+
+__global__ void k_amd_kappa(AmdCtx a, const double* __restrict__ q_, double Ck, double* __restrict__ kap) {
+  const GridDev& g = a.g;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  const long c = i + j * a.sy + k * a.sz, sy = a.sy, sz = a.sz;
+  auto sq = [](double x) { return x * x; };
+  // normalised tracer gradients at fcc / cfc / ccf
+  auto nx = [&](long p) { return a.Dx * ((q_[p] - q_[p - 1]) * a.rdx); };
+  auto ny = [&](long p) { return a.Dy * ((q_[p] - q_[p - sy]) * a.rdy); };
+  auto nz = [&](long p, int kk) { return amd_Dz(a, kk) * ((q_[p] - q_[p - sz]) / g_dzf(g, kk)); };
+  const double x0 = nx(c), x1 = nx(c + 1), y0 = ny(c), y1 = ny(c + sy), z0 = nz(c, k), z1 = nz(c + sz, k + 1);
+  const double Ix_c = 0.5 * (x0 + x1), Iy_c = 0.5 * (y0 + y1), Iz_c = 0.5 * (z0 + z1);
+  const double Ix_c2 = 0.5 * (sq(x0) + sq(x1)), Iy_c2 = 0.5 * (sq(y0) + sq(y1)), Iz_c2 = 0.5 * (sq(z0) + sq(z1));
+  const double sigma = Ix_c2 + Iy_c2 + Iz_c2;
+  double ks = 0.0;
+  if (sigma != 0.0) {
+    auto ndxv = [&](long p, int) { return amd_ndxv(a, p); };
+    auto ndyu = [&](long p, int) { return amd_ndyu(a, p); };
+    auto ndxw = [&](long p, int kk) { return amd_ndxw(a, p, kk); };
+    auto ndzu = [&](long p, int kk) { return amd_ndzu(a, p, kk); };
+    auto ndyw = [&](long p, int kk) { return amd_ndyw(a, p, kk); };
+    auto ndzv = [&](long p, int kk) { return amd_ndzv(a, p, kk); };
+    const double cx = amd_dxu(a, c) * Ix_c2 + amd_Ixy(a, c, k, ndxv) * Ix_c * Iy_c + amd_Ixz(a, c, k, ndxw) * Ix_c * Iz_c;
+    const double cy = amd_Ixy(a, c, k, ndyu) * Iy_c * Ix_c + amd_dyv(a, c) * Iy_c2 + amd_Ixz(a, c, k, ndyw) * Iy_c * Iz_c;
+    const double cz = amd_Ixz(a, c, k, ndzu) * Iz_c * Ix_c + amd_Iyz(a, c, k, ndzv) * Iz_c * Iy_c + amd_dzw(a, c, k) * Iz_c2;
+    const double Dz = amd_Dz(a, k);
+    const double d2 = 3.0 / (1.0 / (a.Dx * a.Dx) + 1.0 / (a.Dy * a.Dy) + 1.0 / (Dz * Dz));
+    ks = -Ck * d2 * (cx + cy + cz) / sigma;
+  }
+  kap[c] = fmax(0.0, ks);
+}
+
+// calculate_diffusivities!(diffusivity_fields, closure::AMD, model)  (anisotropic_minimum_dissipation.jl:180-205)
+void launch_amd(ocn_model* m) {
+  ProfScope ps(m->ctx, "amd_diffusivities");
+  const GridDev& g = m->gd;
+  AmdCtx a;
+  a.g = g;
+  a.u = m->u.interior(); a.v = m->v.interior(); a.w = m->w.interior();
+  a.sy = g.sy; a.sz = g.sz; a.rdx = g.rdx; a.rdy = g.rdy;
+  a.Dx = 2.0 * g.dx; a.Dy = 2.0 * g.dy;
+  dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+  ocn_launch(k_amd_nu, gr, b, m->ctx->stream, a, m->d.amd_Cnu, m->nu_e.interior());
+  for (int t = 0; t < m->nt; ++t)
+    ocn_launch(k_amd_kappa, gr, b, m->ctx->stream, a, (const double*)m->tr[t].interior(), m->d.amd_Ckappa[t],
+               m->kappa_e[t].interior());
+}

@@ -42,6 +42,15 @@ CASES = {
     "ppb_stretched_c2": dict(size=(6, 7, 8), topo=(P, P, B), xy=((0, 1), (0, 1)),
                              zfaces=[0, 1, 2, 4, 7, 11, 16, 22, 29], adv="C2", stepper="AB2", steps=2, dt=1e-2,
                              tracers=("b",), buoyancy="b", closure=(1e-2, 1e-2)),
+    # BASELINE config 3 in miniature: stretched bounded z, T/S, FPlane, linear EOS, AMD, flux/gradient BCs, WENO5, RK3
+    "ppb_amd_config3": dict(size=(8, 8, 8), topo=(P, P, B), xy=((0, 2), (0, 2)),
+                            zfaces=[-1.0, -0.8, -0.62, -0.46, -0.32, -0.2, -0.1, -0.04, 0.0],
+                            adv="WENO5", stepper="RK3", steps=2, dt=2e-3, tracers=("T", "S"), closure="amd",
+                            coriolis=1e-2, buoyancy="TS",
+                            bcs={"u": {"top": ("flux", -1e-2)}, "T": {"top": ("flux", 2e-3), "bottom": ("gradient", 0.01)},
+                                 "S": {"top": ("flux", -1e-3)}}),
+    "ppb_amd_regular_c2": dict(size=(8, 6, 7), topo=(P, P, B), extent=(1, 1, 1), adv="C2", stepper="AB2", steps=2,
+                               dt=2e-3, tracers=("b",), closure="amd", buoyancy="b"),
     # two-dimensional turbulence (BASELINE config 1): Flat z
     "ppf_weno_rk3": dict(size=(16, 16), topo=(P, P, F), extent=(2 * np.pi, 2 * np.pi), adv="WENO5", stepper="RK3",
                          steps=2, dt=0.05, closure=(1e-5, 0.0)),
@@ -60,7 +69,9 @@ def build(mod, cfg, rng_seed=1234):
         kw["halo"] = cfg["halo"]
     g = mod.RectilinearGrid(size=cfg["size"], topology=cfg["topo"], **kw)
     mk = {}
-    if cfg.get("closure"):
+    if cfg.get("closure") == "amd":
+        mk["closure"] = mod.AnisotropicMinimumDissipation()
+    elif cfg.get("closure"):
         mk["closure"] = mod.ScalarDiffusivity(nu=cfg["closure"][0], kappa=cfg["closure"][1])
     if cfg.get("coriolis"):
         mk["coriolis"] = mod.FPlane(cfg["coriolis"])
@@ -101,6 +112,14 @@ def fields_of(m, oracle):
     out["pNHS"] = m.pNHS.data.copy() if oracle else m.pNHS.parent()
     if m.pHY is not None:
         out["pHY"] = m.pHY.data.copy() if oracle else m.pHY.parent()
+    if oracle and m.closure_impl.nu_e is not None:
+        out["nu_e"] = m.closure_impl.nu_e.data.copy()
+        for n, f in m.closure_impl.kappa_e.items():
+            out["kappa_e_" + n] = f.data.copy()
+    elif not oracle and getattr(m, "nu_e", None) is not None:
+        out["nu_e"] = m.nu_e.parent()
+        for n, f in m.kappa_e.items():
+            out["kappa_e_" + n] = f.parent()
     return out
 
 

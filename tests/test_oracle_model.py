@@ -219,3 +219,19 @@ def test_advection_scheme_convergence(scheme, order, tol):
     e = errs[512]
     assert np.isclose(e[0]["c"], e[1]["c"]) and np.isclose(e[0]["c"], e[2]["c"])
     assert np.isclose(e[1]["u"], e[2]["u"]) and np.isclose(e[0]["v"], e[2]["v"]) and np.isclose(e[0]["w"], e[1]["w"])
+
+
+# ---- AMD closure: vanishes for laminar flows (pure strain, uniform shear), positive for a turbulent-like field --
+def test_amd_predictor_properties():
+    g = O.RectilinearGrid(size=(8, 8, 8), extent=(1, 1, 1), topology=(P, P, B))
+    m = O.NonhydrostaticModel(g, closure=O.AnisotropicMinimumDissipation(), tracers=("b",), buoyancy=O.BuoyancyTracer())
+    # uniform shear in z of u (periodic in x, y): du/dz = 1  -> r = 0 -> nu_e = 0
+    m.u.set(lambda x, y, z: z + 0 * x)
+    update_state(m)
+    assert np.abs(m.closure_impl.nu_e.interior()[:, :, 1:-1]).max() < 1e-12
+    rng = np.random.default_rng(0)
+    O.set_model(m, u=rng.random((8, 8, 8)) - 0.5, v=rng.random((8, 8, 8)) - 0.5, b=rng.random((8, 8, 8)))
+    nu = m.closure_impl.nu_e.interior()
+    assert (nu >= 0).all() and nu.max() > 0 and np.isfinite(nu).all()
+    kap = m.closure_impl.kappa_e["b"].interior()
+    assert (kap >= 0).all() and kap.max() > 0
