@@ -130,6 +130,11 @@ int poisson_solve(ocn_model* m, double dt);             // rhs from velocities -
 int poisson_solve_rhs(ocn_model* m, const double* rhs_dev, double* phi_dev);  // generic (tests)
 double* poisson_rhs_buffer(PoissonSolver* s);
 
+// ---- zfft.hip ---------------------------------------------------------------------------------------------
+void* zsolve_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::vector<double>& ly_local);
+void zsolve_destroy(void* z);
+void zsolve_run(ocn_ctx* ctx, void* z, void* spec, const double* lz, double norm, long zero_col);
+
 // ---- comm.hip ---------------------------------------------------------------------------------------------
 int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs);
 int comm_halo_exchange_z(ocn_model* m, Field** fs, int n);

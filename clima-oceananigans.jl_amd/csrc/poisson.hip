@@ -26,6 +26,7 @@ struct PoissonSolver {
   int Nx, Ny, Nz, Nxh;
   int R = 1, rank = 0, Nzg = 0, Nyl = 0;   // slab decomposition
   double2_ *ta = nullptr, *tb = nullptr;   // transpose buffers (same size as spec)
+  void* zs = nullptr;                      // fused z-transform + eigenvalue division + inverse (zfft.hip), Nz == 256
   double* rhs = nullptr;      // real (Nx,Ny,Nz)
   double2_* spec = nullptr;   // complex (Nxh,Ny,Nz)
   double* tscr = nullptr;     // Thomas scratch (Nxh*Ny, Nz)
@@ -81,6 +82,20 @@ PoissonSolver* poisson_create(ocn_model* m) {
       return nullptr;
     }
   }
+  const bool want_zs = g->topo[2] == OCN_PERIODIC && (g->dist ? g->Nzg : s->Nz) == 256 &&
+                       !(getenv("OCNHIP_NO_ZSOLVE") && atoi(getenv("OCNHIP_NO_ZSOLVE")) != 0);
+  if (want_zs) {
+    std::vector<double> lxh = eigenvalues_periodic(s->Nx, g->L[0]);
+    lxh.resize(s->Nxh);
+    std::vector<double> lyv = eigenvalues_periodic(s->Ny, g->L[1]);
+    if (g->dist) lyv = std::vector<double>(lyv.begin() + s->rank * s->Nyl, lyv.begin() + (s->rank + 1) * s->Nyl);
+    s->zs = zsolve_create(m->ctx, lxh, lyv);
+    if (!s->zs) {
+      poisson_destroy(s);
+      return nullptr;
+    }
+    if (s->kind == 0) s->kind = 3;   // 2-D transforms per plane + fused z stage
+  }
   s->lx = upload(eigenvalues_periodic(s->Nx, g->L[0]));
   s->ly = upload(eigenvalues_periodic(s->Ny, g->L[1]));
   if (g->topo[2] == OCN_PERIODIC) s->lz = upload(eigenvalues_periodic(g->dist ? g->Nzg : s->Nz, g->L[2]));
@@ -94,7 +109,7 @@ PoissonSolver* poisson_create(ocn_model* m) {
 #ifndef OCN_HOST_EMU
   hipfftResult r1, r2;
   hipfftResult r3 = HIPFFT_SUCCESS;
-  if (s->kind == 2) {
+  if (s->kind == 2 && !s->zs) {
     // batched 1-D transforms along z of the ky-slab (Nxh, Nyl, Nzg): stride Nxh*Nyl, consecutive batches 1 apart
     int nz[1] = {s->Nzg};
     int st = s->Nxh * s->Nyl;
@@ -134,6 +149,7 @@ void poisson_destroy(PoissonSolver* s) {
 #endif
   hipFree(s->ta);
   hipFree(s->tb);
+  zsolve_destroy(s->zs);
   hipFree(s->rhs);
   hipFree(s->spec);
   hipFree(s->tscr);
@@ -359,6 +375,10 @@ static int run_solver(ocn_model* m) {
     }
     int rc = comm_alltoall(m->ctx, s->ta, s->tb, blk);
     if (rc) return rc;
+    if (s->zs) {
+      ProfScope ps(m->ctx, "spectral_solve");
+      zsolve_run(m->ctx, s->zs, s->tb, s->lz, 1.0 / ((double)s->Nx * s->Ny * s->Nzg), s->rank == 0 ? 0 : -1);
+    } else
     {
       ProfScope ps(m->ctx, "spectral_solve");
 #ifndef OCN_HOST_EMU
@@ -389,6 +409,9 @@ static int run_solver(ocn_model* m) {
       dim3 gr((s->Nxh + 63) / 64, (s->Ny + 3) / 4, s->Nz);
       ocn_launch(k_pack_slab, gr, b, st, s->Nxh, s->Ny, s->Nz, s->Nyl, (const double2_*)s->spec, s->ta, 1);
     }
+  } else if (s->kind == 3) {
+    ProfScope ps(m->ctx, "spectral_solve");
+    zsolve_run(m->ctx, s->zs, s->spec, s->lz, 1.0 / ((double)s->Nx * s->Ny * s->Nz), 0);
   } else {
     ProfScope ps(m->ctx, "spectral_solve");
     dim3 b(64, 4, 1);
