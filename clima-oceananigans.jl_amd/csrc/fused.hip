@@ -36,6 +36,7 @@ struct FusedArgs {
   int use_m;
   int KZ;                         // levels per z-chunk
   int BYo;                        // output rows per workgroup (= blockDim.y - 1)
+  int ntiles;                     // y-tiles (v3: segment decomposition)
 };
 
 OCN_DEVFN void sto(double* base, unsigned boff, double v) { *(double*)((char*)base + boff) = v; }
@@ -196,23 +197,32 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int tid = ty * BX + tx;
   const int i = tx;
-  const int per = gridDim.x / 8;
-  const int ytile = (blockIdx.x % 8) * per + blockIdx.x / 8;   // XCD-aware (see k_tend_step)
-  const int j0 = ytile * (BY - 1);
-  const int j = j0 + ty;
-  const bool ghost = (ty == BY - 1);
-  const bool col_ok = i < g.Nx;
-  const bool row_ok = j < g.Ny;
-  const bool do_y = col_ok && j <= g.Ny;
-  const bool full = col_ok && row_ok && !ghost;
   const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
-  const int k0 = blockIdx.y * a.KZ;
-  const int k1 = (k0 + a.KZ < g.Nz) ? k0 + a.KZ : g.Nz;
   const double rdx = g.rdx, rdy = g.rdy, rdz = 1.0 / g.dz;
-  const unsigned cxy = a.org + (unsigned)(col_ok ? i : 0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
+  const bool col_ok = i < g.Nx;
+  const bool ghost = (ty == BY - 1);
   const int txe = (tx + 1 == g.Nx) ? 0 : tx + 1;
   const int nid_e = ty * BX + (txe < BX ? txe : tx);
   const int nid_n = (ty + 1 < BY ? ty + 1 : ty) * BX + tx;
+  // Work decomposition: the (y-tile, level) space is cut into gridDim.x equal segments of consecutive levels
+  // (tile-major), so every workgroup marches the same number of levels whatever Ny/(BY-1) is -- no partial
+  // last round.  XCD-aware: workgroups b and b+8 share an L2, so each XCD gets a contiguous band of segments.
+  const int nseg = gridDim.x, per = nseg / 8;
+  const long seg = (long)(blockIdx.x % 8) * per + blockIdx.x / 8;
+  const long total = (long)a.ntiles * g.Nz;
+  long lo = seg * total / nseg;
+  const long hi = (seg + 1) * total / nseg;
+  while (lo < hi) {
+  const int ytile = (int)(lo / g.Nz);
+  const int k0 = (int)(lo - (long)ytile * g.Nz);
+  const int k1 = (k0 + (hi - lo) < g.Nz) ? (int)(k0 + (hi - lo)) : g.Nz;
+  lo += k1 - k0;
+  const int j0 = ytile * (BY - 1);
+  const int j = j0 + ty;
+  const bool row_ok = j < g.Ny;
+  const bool do_y = col_ok && j <= g.Ny;
+  const bool full = col_ok && row_ok && !ghost;
+  const unsigned cxy = a.org + (unsigned)(col_ok ? i : 0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
 
   // cooperative slab load: thread row ty handles slab rows r = ty + BY*gq of every field
   const unsigned grow = a.org + (unsigned)(col_ok ? i : 0) * sxb;
@@ -381,6 +391,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
       zw[5] = ldo(a.w, c + 3 * szb);
     }
   }
+  }  // segments
 #undef SLB
 }
 
@@ -513,10 +524,23 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
     static const int by_env = getenv("OCNHIP_FUSED_BY") ? atoi(getenv("OCNHIP_FUSED_BY")) : 0;
     if (bx == 256 && by_env == 3) by = 3;
     static const bool early = !(getenv("OCNHIP_FUSED_EARLY") && atoi(getenv("OCNHIP_FUSED_EARLY")) == 0);
-    int nty = (gd.Ny + by - 2) / (by - 1);
-    nty = ((nty + 7) / 8) * 8;
     a.BYo = by - 1;
-    dim3 blk(bx, by, 1), grd(nty, (gd.Nz + a.KZ - 1) / a.KZ, 1);
+    a.ntiles = (gd.Ny + by - 2) / (by - 1);
+    static const int segs_env = getenv("OCNHIP_FUSED_SEGS") ? atoi(getenv("OCNHIP_FUSED_SEGS")) : 0;
+    static int ncu = 0;
+    if (!ncu) {
+#ifndef OCN_HOST_EMU
+      hipDeviceProp_t prop;
+      ncu = (hipGetDeviceProperties(&prop, m->ctx->device) == hipSuccess) ? prop.multiProcessorCount : 256;
+#else
+      ncu = 8;
+#endif
+    }
+    int nseg = segs_env > 0 ? segs_env : ncu;           // one equal march per CU (one workgroup is resident per CU)
+    long total = (long)a.ntiles * gd.Nz;
+    if (nseg > total / 4) nseg = (int)(total / 4 > 8 ? total / 4 : 8);
+    nseg = ((nseg + 7) / 8) * 8;
+    dim3 blk(bx, by, 1), grd(nseg, 1, 1);
 #define V3_CASE(ADVV)                                                                               \
     if (bx == 256 && by == 3) ocn_launch_sync(k_tend_step3<ADVV, 256, 3, true, false>, grd, blk, s, m->gd, a);   \
     else if (bx == 256 && early && fence) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, true>, grd, blk, s, m->gd, a); \
