@@ -135,6 +135,11 @@ void* zsolve_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std:
 void zsolve_destroy(void* z);
 void zsolve_run(ocn_ctx* ctx, void* z, void* spec, const double* lz, double norm, long zero_col);
 
+// ---- zslab.hip --------------------------------------------------------------------------------------------
+void* zslab_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::vector<double>& ly, int n, int R, int rank);
+void zslab_destroy(void* z);
+int zslab_run(ocn_ctx* ctx, void* z, void* spec, double dz2, double scale);
+
 // ---- comm.hip ---------------------------------------------------------------------------------------------
 int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs);
 int comm_halo_exchange_z(ocn_model* m, Field** fs, int n);

@@ -27,6 +27,8 @@ struct PoissonSolver {
   int R = 1, rank = 0, Nzg = 0, Nyl = 0;   // slab decomposition
   double2_ *ta = nullptr, *tb = nullptr;   // transpose buffers (same size as spec)
   void* zs = nullptr;                      // fused z-transform + eigenvalue division + inverse (zfft.hip), Nz == 256
+  void* zsl = nullptr;                     // slab runs: transpose-free z stage (zslab.hip)
+  double dz2 = 0;
   double* rhs = nullptr;      // real (Nx,Ny,Nz)
   double2_* spec = nullptr;   // complex (Nxh,Ny,Nz)
   double* tscr = nullptr;     // Thomas scratch (Nxh*Ny, Nz)
@@ -82,7 +84,20 @@ PoissonSolver* poisson_create(ocn_model* m) {
       return nullptr;
     }
   }
-  const bool want_zs = g->topo[2] == OCN_PERIODIC && (g->dist ? g->Nzg : s->Nz) == 256 &&
+  const char* dsolver = getenv("OCNHIP_DIST_SOLVER");
+  const bool use_slab = g->dist && !(dsolver && strcmp(dsolver, "transpose") == 0);
+  if (use_slab) {
+    std::vector<double> lxh = eigenvalues_periodic(s->Nx, g->L[0]);
+    lxh.resize(s->Nxh);
+    s->zsl = zslab_create(m->ctx, lxh, eigenvalues_periodic(s->Ny, g->L[1]), s->Nz, s->R, s->rank);
+    if (!s->zsl) {
+      poisson_destroy(s);
+      return nullptr;
+    }
+    double dz = g->L[2] / g->Nzg;
+    s->dz2 = dz * dz;
+  }
+  const bool want_zs = !use_slab && g->topo[2] == OCN_PERIODIC && (g->dist ? g->Nzg : s->Nz) == 256 &&
                        !(getenv("OCNHIP_NO_ZSOLVE") && atoi(getenv("OCNHIP_NO_ZSOLVE")) != 0);
   if (want_zs) {
     std::vector<double> lxh = eigenvalues_periodic(s->Nx, g->L[0]);
@@ -99,7 +114,7 @@ PoissonSolver* poisson_create(ocn_model* m) {
   s->lx = upload(eigenvalues_periodic(s->Nx, g->L[0]));
   s->ly = upload(eigenvalues_periodic(s->Ny, g->L[1]));
   if (g->topo[2] == OCN_PERIODIC) s->lz = upload(eigenvalues_periodic(g->dist ? g->Nzg : s->Nz, g->L[2]));
-  if (s->kind == 2) {
+  if (s->kind == 2 && !s->zsl) {
     if (hipMalloc((void**)&s->ta, nc * sizeof(double2_)) != hipSuccess ||
         hipMalloc((void**)&s->tb, nc * sizeof(double2_)) != hipSuccess) {
       poisson_destroy(s);
@@ -109,7 +124,7 @@ PoissonSolver* poisson_create(ocn_model* m) {
 #ifndef OCN_HOST_EMU
   hipfftResult r1, r2;
   hipfftResult r3 = HIPFFT_SUCCESS;
-  if (s->kind == 2 && !s->zs) {
+  if (s->kind == 2 && !s->zs && !s->zsl) {
     // batched 1-D transforms along z of the ky-slab (Nxh, Nyl, Nzg): stride Nxh*Nyl, consecutive batches 1 apart
     int nz[1] = {s->Nzg};
     int st = s->Nxh * s->Nyl;
@@ -150,6 +165,7 @@ void poisson_destroy(PoissonSolver* s) {
   hipFree(s->ta);
   hipFree(s->tb);
   zsolve_destroy(s->zs);
+  zslab_destroy(s->zsl);
   hipFree(s->rhs);
   hipFree(s->spec);
   hipFree(s->tscr);
@@ -365,7 +381,10 @@ static int run_solver(ocn_model* m) {
     emu_forward(s);
 #endif
   }
-  if (s->kind == 2) {
+  if (s->kind == 2 && s->zsl) {
+    int rc = zslab_run(m->ctx, s->zsl, s->spec, s->dz2, 1.0 / ((double)s->Nx * s->Ny));
+    if (rc) return rc;
+  } else if (s->kind == 2) {
     dim3 b(64, 4, 1);
     const size_t blk = (size_t)s->Nxh * s->Nyl * s->Nz * sizeof(double2_);
     {

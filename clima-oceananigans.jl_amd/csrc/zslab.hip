@@ -1,0 +1,220 @@
+// zslab.hip -- z-direction stage of the Poisson solve on z-slabs WITHOUT transposing the spectrum.
+//
+// After the per-plane 2-D transforms each (kx,ky) column satisfies the periodic three-point system
+//     phi[k-1] + beta phi[k] + phi[k+1] = f[k],   beta = -(2 + (lx+ly) dz^2),  f = dz^2 b^      (k global, periodic)
+// which is exactly what the reference's z-FFT + eigenvalue division solves (fft_based_poisson_solver.jl:93-111:
+// lz are the eigenvalues of this very operator, poisson_eigenvalues.jl:8-11).  Its inverse is a convolution with
+// the periodic Green's function C rho^|d| (rho + 1/rho = -beta, 0 < rho < 1, C = rho / (rho^2 - 1)), i.e. two
+// first-order recursive sweeps along z.  On a slab each rank runs the sweeps on its own levels and only needs
+// two numbers per column from every other rank (the weighted sums of their levels):
+//     SP_r = sum_j rho^(n-1-j) f_j      SQ_r = sum_j rho^j f_j
+// so the per-solve communication is ~1 MB to each peer instead of two all-to-all transposes of the whole
+// half spectrum (2 x 118 MB per GPU at 256^3 per GPU).  xGMI links are point-to-point and per-link bound: this
+// is the formulation that fits them.  The (0,0) column (rho = 1, singular) is gathered whole and solved with
+// the zero-mean gauge of the reference (phi^[1,1,1] = 0).
+#include "internal.h"
+
+struct zc {
+  double x, y;
+};
+
+OCN_DEVFN double col_rho(double lam_dz2) {
+  // roots of rho^2 + beta rho + 1 = 0 with -beta = 2 + s:  rho = 2 / (-beta + sqrt(beta^2 - 4))
+  const double nb = 2.0 + lam_dz2;
+  return 2.0 / (nb + sqrt(nb * nb - 4.0));
+}
+
+// pass 1 (upward): P_i = rho P_{i-1} + f_i stored in place; SP = P_{n-1}; SQ = sum rho^i f_i
+__global__ void k_zslab_up(zc* __restrict__ a, long ncol, int n, const double* __restrict__ lxy, double dz2,
+                           zc* __restrict__ sums /* [2][ncol] */) {
+  const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncol) return;
+  const double lam = lxy[col] * dz2;
+  if (lam == 0.0) {   // the singular column is handled by k_zslab_mean
+    sums[col] = {0, 0};
+    sums[ncol + col] = {0, 0};
+    return;
+  }
+  const double rho = col_rho(lam);
+  zc P = {0, 0}, SQ = {0, 0};
+  double pw = 1.0;
+  for (int i = 0; i < n; ++i) {
+    zc f = a[col + ncol * i];
+    P.x = fma(rho, P.x, f.x);
+    P.y = fma(rho, P.y, f.y);
+    SQ.x = fma(pw, f.x, SQ.x);
+    SQ.y = fma(pw, f.y, SQ.y);
+    pw *= rho;
+    a[col + ncol * i] = P;
+  }
+  sums[col] = P;
+  sums[ncol + col] = SQ;
+}
+
+// pass 2 (downward): x_i = scale * C [P_i + rho Q_{i+1} + rho^(i+1) cinP + rho^(n-i) cinQ]
+// gathered: [R][2][ncol] sums of every rank (own included)
+__global__ void k_zslab_down(zc* __restrict__ a, long ncol, int n, int R, int rank, const double* __restrict__ lxy,
+                             double dz2, double scale, const zc* __restrict__ gathered) {
+  const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncol) return;
+  const double lam = lxy[col] * dz2;
+  if (lam == 0.0) return;
+  const double rho = col_rho(lam);
+  const double lnr = log(rho);
+  const double rn = exp(lnr * n);                 // rho^n (may underflow to 0: then the images vanish, as they should)
+  const double geo = 1.0 / (1.0 - exp(lnr * ((double)n * R)));
+  // carries from the slabs below (P) and above (Q), all periodic images included
+  zc cP = {0, 0}, cQ = {0, 0};
+  double w = 1.0;
+  for (int mm = 1; mm <= R; ++mm) {
+    const int rb = ((rank - mm) % R + R) % R, ra = (rank + mm) % R;
+    zc sp = gathered[((size_t)rb * 2 + 0) * ncol + col];
+    zc sq = gathered[((size_t)ra * 2 + 1) * ncol + col];
+    cP.x = fma(w, sp.x, cP.x);
+    cP.y = fma(w, sp.y, cP.y);
+    cQ.x = fma(w, sq.x, cQ.x);
+    cQ.y = fma(w, sq.y, cQ.y);
+    w *= rn;
+  }
+  cP.x *= geo; cP.y *= geo; cQ.x *= geo; cQ.y *= geo;
+  const double C = rho / (rho * rho - 1.0) * scale;
+  zc Q = {0, 0};                                   // Q_{i+1}
+  zc Pi = a[col + ncol * (size_t)(n - 1)];
+  double pq = rho;                                 // rho^(n-i) at i = n-1
+  for (int i = n - 1; i >= 0; --i) {
+    zc Pm = (i > 0) ? a[col + ncol * (size_t)(i - 1)] : zc{0, 0};
+    const double pp = exp(lnr * (i + 1));          // rho^(i+1)
+    zc x;
+    x.x = C * (Pi.x + rho * Q.x + pp * cP.x + pq * cQ.x);
+    x.y = C * (Pi.y + rho * Q.y + pp * cP.y + pq * cQ.y);
+    // f_i = P_i - rho P_{i-1};  Q_i = rho Q_{i+1} + f_i
+    Q.x = fma(rho, Q.x, Pi.x - rho * Pm.x);
+    Q.y = fma(rho, Q.y, Pi.y - rho * Pm.y);
+    a[col + ncol * (size_t)i] = x;
+    Pi = Pm;
+    pq *= rho;
+  }
+}
+
+// the singular column (lx + ly = 0): second difference of x equals f - mean(f), zero-mean solution.
+// fcol: [R][n] values of the column on every rank (global order); writes this rank's slice back into `a`.
+__global__ void k_zslab_mean(zc* __restrict__ a, long ncol, long col0, int n, int R, int rank,
+                             const zc* __restrict__ fcol, double scale, zc* __restrict__ work /* [R*n] */) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const int N = n * R;
+  zc mean = {0, 0};
+  for (int k = 0; k < N; ++k) { mean.x += fcol[k].x; mean.y += fcol[k].y; }
+  mean.x /= N; mean.y /= N;
+  // c_k = inclusive prefix sum of (f - mean);  d_k = d_{-1} + c_k with sum_k d_k = 0
+  zc c = {0, 0}, cs = {0, 0};
+  for (int k = 0; k < N; ++k) {
+    c.x += fcol[k].x - mean.x; c.y += fcol[k].y - mean.y;
+    work[k] = c;
+    cs.x += c.x; cs.y += c.y;
+  }
+  const zc dm1 = {-cs.x / N, -cs.y / N};
+  // x_k = x_0 + sum_{j<k} d_j ; choose x_0 for zero mean
+  zc acc = {0, 0}, tot = {0, 0};
+  for (int k = 0; k < N; ++k) {
+    zc d = {dm1.x + work[k].x, dm1.y + work[k].y};
+    work[k] = acc;                // x_k - x_0
+    tot.x += acc.x; tot.y += acc.y;
+    acc.x += d.x; acc.y += d.y;
+  }
+  const zc x0 = {-tot.x / N, -tot.y / N};
+  for (int i = 0; i < n; ++i) {
+    zc v = work[rank * n + i];
+    a[col0 + ncol * (size_t)i] = {(v.x + x0.x) * scale, (v.y + x0.y) * scale};
+  }
+}
+
+// copy column col0 of this rank's slab to a contiguous buffer (before pass 1 overwrites it)
+__global__ void k_zslab_getcol(const zc* __restrict__ a, long ncol, long col0, int n, zc* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[col0 + ncol * (size_t)i];
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+struct ZSlab {
+  long ncol = 0;
+  int n = 0, R = 1, rank = 0;
+  double* lxy = nullptr;
+  zc* send = nullptr;      // [2][ncol] sums + [n] singular column
+  zc* gathered = nullptr;  // [R] x that
+  zc* gsums = nullptr;     // [R][2][ncol] (compact view used by pass 2)
+  zc* fcol = nullptr;      // [R][n]
+  zc* work = nullptr;
+  size_t msg = 0;          // elements per rank message
+};
+
+void* zslab_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::vector<double>& ly, int n, int R, int rank) {
+  ZSlab* z = new ZSlab;
+  const size_t Nxh = lx_half.size(), Ny = ly.size();
+  z->ncol = (long)(Nxh * Ny);
+  z->n = n; z->R = R; z->rank = rank;
+  std::vector<double> lxy(Nxh * Ny);
+  for (size_t j = 0; j < Ny; ++j)
+    for (size_t i = 0; i < Nxh; ++i) lxy[i + Nxh * j] = lx_half[i] + ly[j];
+  z->msg = 2 * (size_t)z->ncol + (size_t)n;
+  bool ok = hipMalloc((void**)&z->lxy, sizeof(double) * lxy.size()) == hipSuccess &&
+            hipMalloc((void**)&z->send, sizeof(zc) * z->msg) == hipSuccess &&
+            hipMalloc((void**)&z->gathered, sizeof(zc) * z->msg * R) == hipSuccess &&
+            hipMalloc((void**)&z->gsums, sizeof(zc) * 2 * z->ncol * R) == hipSuccess &&
+            hipMalloc((void**)&z->fcol, sizeof(zc) * (size_t)n * R) == hipSuccess &&
+            hipMalloc((void**)&z->work, sizeof(zc) * (size_t)n * R) == hipSuccess;
+  if (!ok) {
+    ocn_set_error(ctx, "zslab: allocation failed");
+    delete z;
+    return nullptr;
+  }
+  hipMemcpy(z->lxy, lxy.data(), sizeof(double) * lxy.size(), hipMemcpyHostToDevice);
+  return z;
+}
+
+void zslab_destroy(void* p) {
+  ZSlab* z = (ZSlab*)p;
+  if (!z) return;
+  hipFree(z->lxy); hipFree(z->send); hipFree(z->gathered); hipFree(z->gsums); hipFree(z->fcol); hipFree(z->work);
+  delete z;
+}
+
+// in place on this rank's (ncol, n) half spectrum.  dz2 = dz^2, scale = FFT normalisation 1/(Nx Ny).
+int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale) {
+  ZSlab* z = (ZSlab*)p;
+  hipStream_t st = ctx->stream;
+  zc* a = (zc*)spec;
+  const int TB = 64;
+  dim3 b(TB, 1, 1), g((unsigned)((z->ncol + TB - 1) / TB), 1, 1);
+  {
+    ProfScope ps(ctx, "spectral_solve");
+    ocn_launch(k_zslab_getcol, dim3((z->n + 63) / 64), dim3(64), st, (const zc*)a, z->ncol, 0L, z->n, z->send + 2 * z->ncol);
+    ocn_launch(k_zslab_up, g, b, st, a, z->ncol, z->n, (const double*)z->lxy, dz2, z->send);
+  }
+  // all-gather (the same message to every peer)
+  {
+    ProfScope ps(ctx, "transpose");
+    std::vector<CommOp> sends, recvs;
+    const size_t bytes = z->msg * sizeof(zc);
+    for (int q = 0; q < z->R; ++q) {
+      sends.push_back({z->send, bytes, q, 2000});
+      recvs.push_back({z->gathered + z->msg * q, bytes, q, 2000});
+    }
+    int rc = comm_exchange(ctx, sends, recvs);
+    if (rc) return rc;
+    // compact views: sums [R][2][ncol] and the singular column [R][n]
+    for (int q = 0; q < z->R; ++q) {
+      hipMemcpyAsync(z->gsums + (size_t)q * 2 * z->ncol, z->gathered + z->msg * q, sizeof(zc) * 2 * z->ncol,
+                     hipMemcpyDeviceToDevice, st);
+      hipMemcpyAsync(z->fcol + (size_t)q * z->n, z->gathered + z->msg * q + 2 * z->ncol, sizeof(zc) * z->n,
+                     hipMemcpyDeviceToDevice, st);
+    }
+  }
+  {
+    ProfScope ps(ctx, "spectral_solve");
+    ocn_launch(k_zslab_down, g, b, st, a, z->ncol, z->n, z->R, z->rank, (const double*)z->lxy, dz2, scale * dz2,
+               (const zc*)z->gsums);
+    ocn_launch(k_zslab_mean, dim3(1), dim3(64), st, a, z->ncol, 0L, z->n, z->R, z->rank, (const zc*)z->fcol, scale * dz2,
+               z->work);
+  }
+  return OCN_OK;
+}

@@ -66,10 +66,13 @@ def test_slab_trajectory_matches_single_domain_oracle(ocn, backend, R, stepper, 
             assert err < 1e-11, (r, n, err)
 
 
-def test_slab_poisson_residual(ocn, backend):
-    """test_distributed_poisson_solvers.jl:101-116: R == lap(phi) for a random source on 4 ranks."""
+@pytest.mark.parametrize("solver", ["green", "transpose"])
+def test_slab_poisson_residual(ocn, backend, solver, monkeypatch):
+    """test_distributed_poisson_solvers.jl:101-116: R == lap(phi) for a random source on 4 ranks, with the
+    transpose-free Green's-function z stage (default) and with the all-to-all transposed z-FFT."""
     if backend != "hostemu":
         pytest.skip("host-emulation run only")
+    monkeypatch.setenv("OCNHIP_DIST_SOLVER", solver)
     R, N = 4, (12, 8, 24)
     rng = np.random.default_rng(9)
     src = rng.random(N)
