@@ -24,46 +24,79 @@ OCN_DEVFN double col_rho(double lam_dz2) {
   return 2.0 / (nb + sqrt(nb * nb - 4.0));
 }
 
-// pass 1 (upward): P_i = rho P_{i-1} + f_i stored in place; SP = P_{n-1}; SQ = sum rho^i f_i
-__global__ void k_zslab_up(zc* __restrict__ a, long ncol, int n, const double* __restrict__ lxy, double dz2,
-                           zc* __restrict__ sums /* [2][ncol] */) {
+// Each column's levels are split into SZ segments of m = n / SZ levels handled by different threads (the same
+// carry algebra that couples ranks couples segments), so a sweep has ncol * SZ independent recurrences.
+//
+// pass 1 (upward, per segment): P_i = rho P_{i-1} + f_i stored in place (zero carry-in);
+//   segment sums  SP_s = P_{m-1},  SQ_s = sum_i rho^i f_i          -> segs[(s*2 + {0,1}) * ncol + col]
+__global__ void k_zslab_up(zc* __restrict__ a, long ncol, int m, int SZ, const double* __restrict__ lxy, double dz2,
+                           zc* __restrict__ segs) {
   const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
   if (col >= ncol) return;
   const double lam = lxy[col] * dz2;
   if (lam == 0.0) {   // the singular column is handled by k_zslab_mean
-    sums[col] = {0, 0};
-    sums[ncol + col] = {0, 0};
+    segs[((size_t)s * 2 + 0) * ncol + col] = {0, 0};
+    segs[((size_t)s * 2 + 1) * ncol + col] = {0, 0};
     return;
   }
   const double rho = col_rho(lam);
   zc P = {0, 0}, SQ = {0, 0};
   double pw = 1.0;
-  for (int i = 0; i < n; ++i) {
-    zc f = a[col + ncol * i];
+  zc* p = a + col + ncol * (size_t)s * m;
+  for (int i = 0; i < m; ++i) {
+    zc f = p[ncol * (size_t)i];
     P.x = fma(rho, P.x, f.x);
     P.y = fma(rho, P.y, f.y);
     SQ.x = fma(pw, f.x, SQ.x);
     SQ.y = fma(pw, f.y, SQ.y);
     pw *= rho;
-    a[col + ncol * i] = P;
+    p[ncol * (size_t)i] = P;
   }
-  sums[col] = P;
+  segs[((size_t)s * 2 + 0) * ncol + col] = P;
+  segs[((size_t)s * 2 + 1) * ncol + col] = SQ;
+}
+
+// rank sums from the segment sums: SP_r = sum_s rho^((SZ-1-s) m) SP_s,  SQ_r = sum_s rho^(s m) SQ_s
+__global__ void k_zslab_ranksums(long ncol, int m, int SZ, const double* __restrict__ lxy, double dz2,
+                                 const zc* __restrict__ segs, zc* __restrict__ sums /* [2][ncol] */) {
+  const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncol) return;
+  const double lam = lxy[col] * dz2;
+  zc SP = {0, 0}, SQ = {0, 0};
+  if (lam != 0.0) {
+    const double rm = exp(log(col_rho(lam)) * m);
+    double w = 1.0;
+    for (int s = 0; s < SZ; ++s) {      // Horner for SP, running power for SQ
+      zc sp = segs[((size_t)s * 2 + 0) * ncol + col], sq = segs[((size_t)s * 2 + 1) * ncol + col];
+      SP.x = fma(rm, SP.x, sp.x);
+      SP.y = fma(rm, SP.y, sp.y);
+      SQ.x = fma(w, sq.x, SQ.x);
+      SQ.y = fma(w, sq.y, SQ.y);
+      w *= rm;
+    }
+  }
+  sums[col] = SP;
   sums[ncol + col] = SQ;
 }
 
-// pass 2 (downward): x_i = scale * C [P_i + rho Q_{i+1} + rho^(i+1) cinP + rho^(n-i) cinQ]
-// gathered: [R][2][ncol] sums of every rank (own included)
-__global__ void k_zslab_down(zc* __restrict__ a, long ncol, int n, int R, int rank, const double* __restrict__ lxy,
-                             double dz2, double scale, const zc* __restrict__ gathered) {
+// pass 2 (downward, per segment): x_i = scale C [P_i + rho Q_{i+1} + rho^(i+1) cP + rho^(m-i) cQ], i local to the
+// segment; cP / cQ collect everything below / above the segment: the rank's other segments and, through the
+// gathered rank sums [R][2][ncol], every other slab with all periodic images.
+__global__ void k_zslab_down(zc* __restrict__ a, long ncol, int m, int SZ, int R, int rank, const double* __restrict__ lxy,
+                             double dz2, double scale, const zc* __restrict__ segs, const zc* __restrict__ gathered) {
   const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
   if (col >= ncol) return;
   const double lam = lxy[col] * dz2;
   if (lam == 0.0) return;
   const double rho = col_rho(lam);
   const double lnr = log(rho);
-  const double rn = exp(lnr * n);                 // rho^n (may underflow to 0: then the images vanish, as they should)
+  const int n = m * SZ;
+  const double rm = exp(lnr * m);                 // rho^m (may underflow to 0: then the images vanish, as they should)
+  const double rn = exp(lnr * n);
   const double geo = 1.0 / (1.0 - exp(lnr * ((double)n * R)));
-  // carries from the slabs below (P) and above (Q), all periodic images included
+  // rank-level carries: slabs below (P) and above (Q), all periodic images included
   zc cP = {0, 0}, cQ = {0, 0};
   double w = 1.0;
   for (int mm = 1; mm <= R; ++mm) {
@@ -77,12 +110,30 @@ __global__ void k_zslab_down(zc* __restrict__ a, long ncol, int n, int R, int ra
     w *= rn;
   }
   cP.x *= geo; cP.y *= geo; cQ.x *= geo; cQ.y *= geo;
+  // segment-level: add the rank's own segments below / above this one
+  {
+    zc lo = {cP.x, cP.y};                         // carry entering segment 0 from below
+    for (int t = 0; t < s; ++t) {
+      zc sp = segs[((size_t)t * 2 + 0) * ncol + col];
+      lo.x = fma(rm, lo.x, sp.x);
+      lo.y = fma(rm, lo.y, sp.y);
+    }
+    zc hi = {cQ.x, cQ.y};                         // carry entering segment SZ-1 from above
+    for (int t = SZ - 1; t > s; --t) {
+      zc sq = segs[((size_t)t * 2 + 1) * ncol + col];
+      hi.x = fma(rm, hi.x, sq.x);
+      hi.y = fma(rm, hi.y, sq.y);
+    }
+    cP = lo;
+    cQ = hi;
+  }
   const double C = rho / (rho * rho - 1.0) * scale;
+  zc* p = a + col + ncol * (size_t)s * m;
   zc Q = {0, 0};                                   // Q_{i+1}
-  zc Pi = a[col + ncol * (size_t)(n - 1)];
-  double pq = rho;                                 // rho^(n-i) at i = n-1
-  for (int i = n - 1; i >= 0; --i) {
-    zc Pm = (i > 0) ? a[col + ncol * (size_t)(i - 1)] : zc{0, 0};
+  zc Pi = p[ncol * (size_t)(m - 1)];
+  double pq = rho;                                 // rho^(m-i) at i = m-1
+  for (int i = m - 1; i >= 0; --i) {
+    zc Pm = (i > 0) ? p[ncol * (size_t)(i - 1)] : zc{0, 0};
     const double pp = exp(lnr * (i + 1));          // rho^(i+1)
     zc x;
     x.x = C * (Pi.x + rho * Q.x + pp * cP.x + pq * cQ.x);
@@ -90,7 +141,7 @@ __global__ void k_zslab_down(zc* __restrict__ a, long ncol, int n, int R, int ra
     // f_i = P_i - rho P_{i-1};  Q_i = rho Q_{i+1} + f_i
     Q.x = fma(rho, Q.x, Pi.x - rho * Pm.x);
     Q.y = fma(rho, Q.y, Pi.y - rho * Pm.y);
-    a[col + ncol * (size_t)i] = x;
+    p[ncol * (size_t)i] = x;
     Pi = Pm;
     pq *= rho;
   }
@@ -144,6 +195,8 @@ struct ZSlab {
   zc* gsums = nullptr;     // [R][2][ncol] (compact view used by pass 2)
   zc* fcol = nullptr;      // [R][n]
   zc* work = nullptr;
+  zc* segs = nullptr;      // [SZ][2][ncol] segment sums
+  int SZ = 1, m = 0;
   size_t msg = 0;          // elements per rank message
 };
 
@@ -155,13 +208,18 @@ void* zslab_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::
   std::vector<double> lxy(Nxh * Ny);
   for (size_t j = 0; j < Ny; ++j)
     for (size_t i = 0; i < Nxh; ++i) lxy[i + Nxh * j] = lx_half[i] + ly[j];
+  z->SZ = 1;
+  for (int cand : {32, 16, 8, 4, 2})
+    if (n % cand == 0 && n / cand >= 8) { z->SZ = cand; break; }
+  z->m = n / z->SZ;
   z->msg = 2 * (size_t)z->ncol + (size_t)n;
   bool ok = hipMalloc((void**)&z->lxy, sizeof(double) * lxy.size()) == hipSuccess &&
             hipMalloc((void**)&z->send, sizeof(zc) * z->msg) == hipSuccess &&
             hipMalloc((void**)&z->gathered, sizeof(zc) * z->msg * R) == hipSuccess &&
             hipMalloc((void**)&z->gsums, sizeof(zc) * 2 * z->ncol * R) == hipSuccess &&
             hipMalloc((void**)&z->fcol, sizeof(zc) * (size_t)n * R) == hipSuccess &&
-            hipMalloc((void**)&z->work, sizeof(zc) * (size_t)n * R) == hipSuccess;
+            hipMalloc((void**)&z->work, sizeof(zc) * (size_t)n * R) == hipSuccess &&
+            hipMalloc((void**)&z->segs, sizeof(zc) * 2 * z->ncol * z->SZ) == hipSuccess;
   if (!ok) {
     ocn_set_error(ctx, "zslab: allocation failed");
     delete z;
@@ -174,7 +232,7 @@ void* zslab_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::
 void zslab_destroy(void* p) {
   ZSlab* z = (ZSlab*)p;
   if (!z) return;
-  hipFree(z->lxy); hipFree(z->send); hipFree(z->gathered); hipFree(z->gsums); hipFree(z->fcol); hipFree(z->work);
+  hipFree(z->lxy); hipFree(z->send); hipFree(z->gathered); hipFree(z->gsums); hipFree(z->fcol); hipFree(z->work); hipFree(z->segs);
   delete z;
 }
 
@@ -184,11 +242,12 @@ int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale) {
   hipStream_t st = ctx->stream;
   zc* a = (zc*)spec;
   const int TB = 64;
-  dim3 b(TB, 1, 1), g((unsigned)((z->ncol + TB - 1) / TB), 1, 1);
+  dim3 b(TB, 1, 1), g((unsigned)((z->ncol + TB - 1) / TB), (unsigned)z->SZ, 1), g1((unsigned)((z->ncol + TB - 1) / TB), 1, 1);
   {
     ProfScope ps(ctx, "spectral_solve");
     ocn_launch(k_zslab_getcol, dim3((z->n + 63) / 64), dim3(64), st, (const zc*)a, z->ncol, 0L, z->n, z->send + 2 * z->ncol);
-    ocn_launch(k_zslab_up, g, b, st, a, z->ncol, z->n, (const double*)z->lxy, dz2, z->send);
+    ocn_launch(k_zslab_up, g, b, st, a, z->ncol, z->m, z->SZ, (const double*)z->lxy, dz2, z->segs);
+    ocn_launch(k_zslab_ranksums, g1, b, st, z->ncol, z->m, z->SZ, (const double*)z->lxy, dz2, (const zc*)z->segs, z->send);
   }
   // all-gather (the same message to every peer)
   {
@@ -211,8 +270,8 @@ int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale) {
   }
   {
     ProfScope ps(ctx, "spectral_solve");
-    ocn_launch(k_zslab_down, g, b, st, a, z->ncol, z->n, z->R, z->rank, (const double*)z->lxy, dz2, scale * dz2,
-               (const zc*)z->gsums);
+    ocn_launch(k_zslab_down, g, b, st, a, z->ncol, z->m, z->SZ, z->R, z->rank, (const double*)z->lxy, dz2, scale * dz2,
+               (const zc*)z->segs, (const zc*)z->gsums);
     ocn_launch(k_zslab_mean, dim3(1), dim3(64), st, a, z->ncol, 0L, z->n, z->R, z->rank, (const zc*)z->fcol, scale * dz2,
                z->work);
   }
