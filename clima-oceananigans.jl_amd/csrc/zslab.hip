@@ -44,14 +44,25 @@ __global__ void k_zslab_up(zc* __restrict__ a, long ncol, int m, int SZ, const d
   zc P = {0, 0}, SQ = {0, 0};
   double pw = 1.0;
   zc* p = a + col + ncol * (size_t)s * m;
-  for (int i = 0; i < m; ++i) {
-    zc f = p[ncol * (size_t)i];
-    P.x = fma(rho, P.x, f.x);
-    P.y = fma(rho, P.y, f.y);
-    SQ.x = fma(pw, f.x, SQ.x);
-    SQ.y = fma(pw, f.y, SQ.y);
-    pw *= rho;
-    p[ncol * (size_t)i] = P;
+  // batches of 8 levels: all loads of a batch are issued before the (serial) recurrence consumes them
+  for (int i0 = 0; i0 < m; i0 += 8) {
+    zc f[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (i0 + q < m) f[q] = p[ncol * (size_t)(i0 + q)];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (i0 + q < m) {
+        P.x = fma(rho, P.x, f[q].x);
+        P.y = fma(rho, P.y, f[q].y);
+        SQ.x = fma(pw, f[q].x, SQ.x);
+        SQ.y = fma(pw, f[q].y, SQ.y);
+        pw *= rho;
+        f[q] = P;
+      }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (i0 + q < m) p[ncol * (size_t)(i0 + q)] = f[q];
   }
   segs[((size_t)s * 2 + 0) * ncol + col] = P;
   segs[((size_t)s * 2 + 1) * ncol + col] = SQ;
@@ -84,7 +95,8 @@ __global__ void k_zslab_ranksums(long ncol, int m, int SZ, const double* __restr
 // segment; cP / cQ collect everything below / above the segment: the rank's other segments and, through the
 // gathered rank sums [R][2][ncol], every other slab with all periodic images.
 __global__ void k_zslab_down(zc* __restrict__ a, long ncol, int m, int SZ, int R, int rank, const double* __restrict__ lxy,
-                             double dz2, double scale, const zc* __restrict__ segs, const zc* __restrict__ gathered) {
+                             double dz2, double scale, const zc* __restrict__ segs, const zc* __restrict__ gathered,
+                             size_t msg) {
   const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
   if (col >= ncol) return;
@@ -101,8 +113,8 @@ __global__ void k_zslab_down(zc* __restrict__ a, long ncol, int m, int SZ, int R
   double w = 1.0;
   for (int mm = 1; mm <= R; ++mm) {
     const int rb = ((rank - mm) % R + R) % R, ra = (rank + mm) % R;
-    zc sp = gathered[((size_t)rb * 2 + 0) * ncol + col];
-    zc sq = gathered[((size_t)ra * 2 + 1) * ncol + col];
+    zc sp = gathered[(size_t)rb * msg + col];
+    zc sq = gathered[(size_t)ra * msg + ncol + col];
     cP.x = fma(w, sp.x, cP.x);
     cP.y = fma(w, sp.y, cP.y);
     cQ.x = fma(w, sq.x, cQ.x);
@@ -130,50 +142,109 @@ __global__ void k_zslab_down(zc* __restrict__ a, long ncol, int m, int SZ, int R
   const double C = rho / (rho * rho - 1.0) * scale;
   zc* p = a + col + ncol * (size_t)s * m;
   zc Q = {0, 0};                                   // Q_{i+1}
-  zc Pi = p[ncol * (size_t)(m - 1)];
   double pq = rho;                                 // rho^(m-i) at i = m-1
-  for (int i = m - 1; i >= 0; --i) {
-    zc Pm = (i > 0) ? p[ncol * (size_t)(i - 1)] : zc{0, 0};
-    const double pp = exp(lnr * (i + 1));          // rho^(i+1)
-    zc x;
-    x.x = C * (Pi.x + rho * Q.x + pp * cP.x + pq * cQ.x);
-    x.y = C * (Pi.y + rho * Q.y + pp * cP.y + pq * cQ.y);
-    // f_i = P_i - rho P_{i-1};  Q_i = rho Q_{i+1} + f_i
-    Q.x = fma(rho, Q.x, Pi.x - rho * Pm.x);
-    Q.y = fma(rho, Q.y, Pi.y - rho * Pm.y);
-    p[ncol * (size_t)i] = x;
-    Pi = Pm;
-    pq *= rho;
+  // batches of 8 levels, top down; v[q] = P_{i1-q}, v[8] = P_{i1-8} (the next batch's first value)
+  for (int i1 = m - 1; i1 >= 0; i1 -= 8) {
+    zc v[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int i = i1 - q;
+      v[q] = (i >= 0) ? p[ncol * (size_t)i] : zc{0, 0};
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i1 - q;
+      if (i >= 0) {
+        const zc Pi = v[q], Pm = v[q + 1];
+        const double pp = exp(lnr * (i + 1));      // rho^(i+1)
+        zc x;
+        x.x = C * (Pi.x + rho * Q.x + pp * cP.x + pq * cQ.x);
+        x.y = C * (Pi.y + rho * Q.y + pp * cP.y + pq * cQ.y);
+        // f_i = P_i - rho P_{i-1};  Q_i = rho Q_{i+1} + f_i
+        Q.x = fma(rho, Q.x, Pi.x - rho * Pm.x);
+        Q.y = fma(rho, Q.y, Pi.y - rho * Pm.y);
+        v[q] = x;
+        pq *= rho;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i1 - q;
+      if (i >= 0) p[ncol * (size_t)i] = v[q];
+    }
   }
 }
 
-// the singular column (lx + ly = 0): second difference of x equals f - mean(f), zero-mean solution.
-// fcol: [R][n] values of the column on every rank (global order); writes this rank's slice back into `a`.
-__global__ void k_zslab_mean(zc* __restrict__ a, long ncol, long col0, int n, int R, int rank,
-                             const zc* __restrict__ fcol, double scale, zc* __restrict__ work /* [R*n] */) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// the singular column (lx + ly = 0): second difference of x equals g = f - mean(f), zero-mean solution:
+//   x_k - x_0 = k d_{-1} + sum_{j<k} c_j,  c = inclusive prefix sum of g,  d_{-1} = -mean(c),  x_0 from zero mean.
+// One workgroup; every thread owns a contiguous chunk; the two prefix sums are chunk-local scans plus a
+// Hillis-Steele scan of the chunk totals in LDS.  `gathered` holds every rank's message; the column's levels of
+// rank q start at gathered[q * msg + 2 * ncol].
+#define ZM_T 256
+OCN_DEVFN zc zadd(zc a, zc b) { return {a.x + b.x, a.y + b.y}; }
+OCN_DEVFN zc block_scan_excl(zc v, zc* sh /* [2][ZM_T] */, zc* total) {
+  const int t = threadIdx.x;
+  int cur = 0;
+  sh[t] = v;
+  __syncthreads();
+  for (int off = 1; off < ZM_T; off <<= 1) {
+    zc mine = sh[cur * ZM_T + t];
+    if (t >= off) mine = zadd(mine, sh[cur * ZM_T + t - off]);
+    sh[(1 - cur) * ZM_T + t] = mine;
+    cur = 1 - cur;
+    __syncthreads();
+  }
+  zc incl = sh[cur * ZM_T + t];
+  *total = sh[cur * ZM_T + ZM_T - 1];
+  __syncthreads();
+  return {incl.x - v.x, incl.y - v.y};
+}
+
+__global__ void __launch_bounds__(ZM_T) k_zslab_mean(zc* __restrict__ a, long ncol, long col0, int n, int R, int rank,
+                                                     const zc* __restrict__ gathered, size_t msg, double scale,
+                                                     zc* __restrict__ work /* [R*n] */) {
+  OCN_SHARED zc sh[2 * ZM_T];
+  const int t = threadIdx.x;
   const int N = n * R;
-  zc mean = {0, 0};
-  for (int k = 0; k < N; ++k) { mean.x += fcol[k].x; mean.y += fcol[k].y; }
-  mean.x /= N; mean.y /= N;
-  // c_k = inclusive prefix sum of (f - mean);  d_k = d_{-1} + c_k with sum_k d_k = 0
-  zc c = {0, 0}, cs = {0, 0};
-  for (int k = 0; k < N; ++k) {
-    c.x += fcol[k].x - mean.x; c.y += fcol[k].y - mean.y;
+  const int chunk = (N + ZM_T - 1) / ZM_T;
+  const int k0 = t * chunk, k1 = (k0 + chunk < N) ? k0 + chunk : N;
+  auto F = [&](int k) { return gathered[(size_t)(k / n) * msg + 2 * (size_t)ncol + (k % n)]; };
+  // mean of f
+  zc part = {0, 0}, tot;
+  for (int k = k0; k < k1; ++k) part = zadd(part, F(k));
+  block_scan_excl(part, sh, &tot);
+  const zc mean = {tot.x / N, tot.y / N};
+  // c = inclusive prefix sum of g  (stored in work), and its total
+  zc loc = {0, 0};
+  for (int k = k0; k < k1; ++k) {
+    zc f = F(k);
+    loc = {loc.x + f.x - mean.x, loc.y + f.y - mean.y};
+  }
+  zc base = block_scan_excl(loc, sh, &tot);
+  zc c = base, csum = {0, 0};
+  for (int k = k0; k < k1; ++k) {
+    zc f = F(k);
+    c = {c.x + f.x - mean.x, c.y + f.y - mean.y};
     work[k] = c;
-    cs.x += c.x; cs.y += c.y;
+    csum = zadd(csum, c);
   }
-  const zc dm1 = {-cs.x / N, -cs.y / N};
-  // x_k = x_0 + sum_{j<k} d_j ; choose x_0 for zero mean
-  zc acc = {0, 0}, tot = {0, 0};
-  for (int k = 0; k < N; ++k) {
-    zc d = {dm1.x + work[k].x, dm1.y + work[k].y};
-    work[k] = acc;                // x_k - x_0
-    tot.x += acc.x; tot.y += acc.y;
-    acc.x += d.x; acc.y += d.y;
+  zc ctot;
+  zc cbase = block_scan_excl(csum, sh, &ctot);      // sum of c over earlier chunks
+  const zc dm1 = {-ctot.x / N, -ctot.y / N};
+  // y_k = x_k - x_0 = k d_{-1} + sum_{j<k} c_j ; then the mean of y
+  zc run = cbase, ysum = {0, 0};
+  for (int k = k0; k < k1; ++k) {
+    zc ck = work[k];
+    zc y = {k * dm1.x + run.x, k * dm1.y + run.y};
+    work[k] = y;
+    ysum = zadd(ysum, y);
+    run = zadd(run, ck);
   }
-  const zc x0 = {-tot.x / N, -tot.y / N};
-  for (int i = 0; i < n; ++i) {
+  zc ytot;
+  block_scan_excl(ysum, sh, &ytot);
+  const zc x0 = {-ytot.x / N, -ytot.y / N};
+  __syncthreads();
+  for (int i = t; i < n; i += ZM_T) {
     zc v = work[rank * n + i];
     a[col0 + ncol * (size_t)i] = {(v.x + x0.x) * scale, (v.y + x0.y) * scale};
   }
@@ -260,20 +331,13 @@ int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale) {
     }
     int rc = comm_exchange(ctx, sends, recvs);
     if (rc) return rc;
-    // compact views: sums [R][2][ncol] and the singular column [R][n]
-    for (int q = 0; q < z->R; ++q) {
-      hipMemcpyAsync(z->gsums + (size_t)q * 2 * z->ncol, z->gathered + z->msg * q, sizeof(zc) * 2 * z->ncol,
-                     hipMemcpyDeviceToDevice, st);
-      hipMemcpyAsync(z->fcol + (size_t)q * z->n, z->gathered + z->msg * q + 2 * z->ncol, sizeof(zc) * z->n,
-                     hipMemcpyDeviceToDevice, st);
-    }
   }
   {
     ProfScope ps(ctx, "spectral_solve");
     ocn_launch(k_zslab_down, g, b, st, a, z->ncol, z->m, z->SZ, z->R, z->rank, (const double*)z->lxy, dz2, scale * dz2,
-               (const zc*)z->segs, (const zc*)z->gsums);
-    ocn_launch(k_zslab_mean, dim3(1), dim3(64), st, a, z->ncol, 0L, z->n, z->R, z->rank, (const zc*)z->fcol, scale * dz2,
-               z->work);
+               (const zc*)z->segs, (const zc*)z->gathered, z->msg);
+    ocn_launch_sync(k_zslab_mean, dim3(1), dim3(ZM_T), st, a, z->ncol, 0L, z->n, z->R, z->rank, (const zc*)z->gathered, z->msg,
+                    scale * dz2, z->work);
   }
   return OCN_OK;
 }
