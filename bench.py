@@ -51,6 +51,39 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"{steps} AB2 WENO5 steps at {n}^3 (same workload, 1/64 of the cells), NumPy oracle"}
 
 
+def build_config3(ocn, ctx, args):
+    """BASELINE config 3: 256x256x128 (Periodic, Periodic, Bounded), the stretched z of
+    examples/ocean_wind_mixing_and_convection.jl:38-60 with Nz = 128, T and S, FPlane, linear EOS, AMD, wind stress /
+    heat flux / (constant) evaporation / bottom gradient BCs, RK3, WENO5 in place of the script's U5."""
+    Nx, Ny, Nz = tuple(args.size) if args.size else (256, 256, 128)
+    Lz, refinement, stretching = 32.0, 1.2, 12.0
+    k = np.arange(1, Nz + 2)
+    h = (k - 1) / Nz
+    zf = Lz * ((1 + (h - 1) / refinement) * (1 - np.exp(-stretching * h)) / (1 - np.exp(-stretching)) - 1)
+    grid = ocn.RectilinearGrid(ctx, size=(Nx, Ny, Nz), x=(0.0, 2.0 * Nx), y=(0.0, 2.0 * Ny), z=zf,
+                               topology=("Periodic", "Periodic", "Bounded"))
+    QT = 200.0 / (1026.0 * 3991.0)
+    Qu = -1.225 / 1026.0 * 2.5e-3 * 10 * 10
+    dTdz = 0.01
+    bcs = {"u": {"top": ocn.FluxBC(Qu)}, "T": {"top": ocn.FluxBC(QT), "bottom": ocn.GradientBC(dTdz)},
+           "S": {"top": ocn.FluxBC(-1e-3 / 3600 * 35.0)}}
+    model = ocn.NonhydrostaticModel(grid, advection=ocn.WENO5(), timestepper="RungeKutta3", tracers=("T", "S"),
+                                    coriolis=ocn.FPlane(1e-4), closure=ocn.AnisotropicMinimumDissipation(),
+                                    buoyancy=ocn.SeawaterBuoyancy(thermal_expansion=2e-4, haline_contraction=8e-4),
+                                    boundary_conditions=bcs)
+    rng = np.random.default_rng(3)
+    zc = 0.5 * (zf[1:] + zf[:-1]).reshape(1, 1, -1)
+    zw = zf.reshape(1, 1, -1)
+    noise = lambda z, shape: rng.standard_normal(shape) * z / Lz * (1 + z / Lz)   # noqa: E731
+    T0 = 20 + dTdz * zc + dTdz * Lz * 1e-6 * noise(zc, (Nx, Ny, Nz))
+    u0 = np.sqrt(abs(Qu)) * 1e-3 * noise(zc, (Nx, Ny, Nz))
+    w0 = np.sqrt(abs(Qu)) * 1e-3 * noise(zw, (Nx, Ny, Nz + 1))
+    w0[:, :, 0] = 0
+    w0[:, :, -1] = 0
+    ocn.set_model(model, u=u0, w=w0, T=T0, S=35.0)
+    return model, 1.0, (Nx, Ny, Nz), (Nx, Ny, Nz)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +92,7 @@ def main():
     ap.add_argument("--size", type=int, nargs=3, default=None, help="override per-GPU size (debug)")
     ap.add_argument("--stepper", default="AB2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (headline, default) or 3 (ocean LES)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,11 +120,14 @@ def main():
         par = import_module("ocnhip.parallel")
         par.init_comm(ctx, dist, rank, world)
     Nglobal = (n[0], n[1], n[2] * world)
-    grid = ocn.RectilinearGrid(ctx, size=Nglobal, extent=(1, 1, float(world)), topology=("Periodic",) * 3)
-    model = ocn.NonhydrostaticModel(grid, advection=ocn.WENO5(), timestepper=args.stepper)
-    rng = np.random.default_rng(1 + rank)
-    local = model.u.size
-    ocn.set_model(model, u=rng.random(local) - 0.5, v=rng.random(local) - 0.5, w=rng.random(local) - 0.5)
+    if args.config == 3:
+        model, dt3, Nglobal, n = build_config3(ocn, ctx, args)
+    else:
+        grid = ocn.RectilinearGrid(ctx, size=Nglobal, extent=(1, 1, float(world)), topology=("Periodic",) * 3)
+        model = ocn.NonhydrostaticModel(grid, advection=ocn.WENO5(), timestepper=args.stepper)
+        rng = np.random.default_rng(1 + rank)
+        local = model.u.size
+        ocn.set_model(model, u=rng.random(local) - 0.5, v=rng.random(local) - 0.5, w=rng.random(local) - 0.5)
     umax = np.abs(model.u.interior()).max()
     if dist is not None:
         import torch
@@ -98,6 +135,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         umax = float(t[0])
     dt = 0.2 * (1.0 / n[0]) / umax
+    if args.config == 3:
+        dt = dt3
 
     for _ in range(args.warmup):
         ocn.time_step(model, dt)
@@ -127,7 +166,8 @@ def main():
     value = cells * args.steps / el
 
     phases = {}
-    for ph in list(B_ALG_PHASE) + ["fill_halos", "store", "copy_pressure", "time_step", "halo_exchange", "transpose"]:
+    for ph in list(B_ALG_PHASE) + ["fill_halos", "store", "copy_pressure", "time_step", "halo_exchange", "transpose",
+                                   "amd_diffusivities", "hydrostatic"]:
         avg, cnt = ctx.profile_read(ph)
         if cnt:
             phases[ph] = {"avg_ms": avg, "launches": cnt}
@@ -147,8 +187,11 @@ def main():
             "metric": "cell-updates/sec per time_step!, 256^3 Nonhydrostatic WENO5", "value": value,
             "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} triply-periodic RectilinearGrid, "
-                                   f"NonhydrostaticModel WENO5(zweno) + FFT Poisson, {args.stepper}, halo 3, no tracers",
+            "config": {"workload": (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} triply-periodic RectilinearGrid, "
+                                    f"NonhydrostaticModel WENO5(zweno) + FFT Poisson, {args.stepper}, halo 3, no tracers")
+                       if args.config == 2 else
+                       (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} (Periodic,Periodic,Bounded) stretched z, WENO5, RK3, T+S, "
+                        "FPlane, linear EOS, AMD, flux/gradient BCs, Fourier-tridiagonal Poisson (BASELINE config 3)"),
                        "decomposition": f"z-slabs x{world}", "dt": dt},
             "roofline": roofline,
             "step_roofline": {"alg_bytes_per_cell_update": B_ALG_STEP, "frac_of_hbm_peak": step_frac},

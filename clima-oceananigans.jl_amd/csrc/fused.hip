@@ -569,7 +569,8 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
 void launch_rhs_wrap(ocn_model* m, double dt, double* rhs) {
   ProfScope ps(m->ctx, "rhs");
   const GridDev& g = m->gd;
-  dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+  static const int bxr = getenv("OCNHIP_PROJ_BX") ? atoi(getenv("OCNHIP_PROJ_BX")) : 256;
+  dim3 b(bxr, 256 / bxr, 1), gr((g.Nx + b.x - 1) / b.x, (g.Ny + b.y - 1) / b.y, g.Nz);
   ocn_launch(k_rhs_wrap, gr, b, m->ctx->stream, g, (const double*)m->us.interior(), (const double*)m->vs.interior(),
              (const double*)m->ws.interior(), 1.0 / dt, m->g->dist ? 0 : 1, rhs);
 }
@@ -584,7 +585,8 @@ void launch_project(ocn_model* m, double dt, const double* phi) {
   a.dt = dt;
   a.zwrap = m->g->dist ? 0 : 1;
   a.phi_below = m->phi_below;
-  dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+  static const int bxp = getenv("OCNHIP_PROJ_BX") ? atoi(getenv("OCNHIP_PROJ_BX")) : 256;
+  dim3 b(bxp, 256 / bxp, 1), gr((g.Nx + b.x - 1) / b.x, (g.Ny + b.y - 1) / b.y, g.Nz);
   ocn_launch(k_project, gr, b, m->ctx->stream, g, a);
 }
 

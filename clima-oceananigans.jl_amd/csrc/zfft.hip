@@ -67,7 +67,7 @@ template <int S> OCN_DEVFN void dft16(cd* v) {
 __global__ void __launch_bounds__(256) k_zsolve256(cd* __restrict__ a, long ncol, const double* __restrict__ lxy,
                                                    const double* __restrict__ lz, const cd* __restrict__ tw256,
                                                    double norm, long zero_col) {
-  OCN_SHARED cd sm[16 * 16 * 17];           // [col][p][q] with q padded to 17
+  OCN_SHARED cd sm[16 * 16 * 16];           // [p][q][col], column fastest: conflict-free b128 writes and reads
   const int t = threadIdx.x;
   const int col = t & 15, r = t >> 4;       // r plays n2 (loads / stores) and k1 (spectral side)
   const long gcol = (long)blockIdx.x * 16 + col;
@@ -81,10 +81,10 @@ __global__ void __launch_bounds__(256) k_zsolve256(cd* __restrict__ a, long ncol
 #pragma unroll
   for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], tw256[(r * k1) & 255]);
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) sm[(col * 16 + k1) * 17 + r] = v[k1];
+  for (int k1 = 0; k1 < 16; ++k1) sm[(k1 * 16 + r) * 16 + col] = v[k1];
   __syncthreads();
 #pragma unroll
-  for (int n2 = 0; n2 < 16; ++n2) v[n2] = sm[(col * 16 + r) * 17 + n2];   // now r = k1
+  for (int n2 = 0; n2 < 16; ++n2) v[n2] = sm[(r * 16 + n2) * 16 + col];   // now r = k1
   dft16<1>(v);                                                            // v[k2] = X[k1 + 16 k2]
   // ---- eigenvalue division (fft_based_poisson_solver.jl:106-111) ----
   const double lc = ok ? lxy[gcol] : 1.0;
@@ -106,10 +106,10 @@ __global__ void __launch_bounds__(256) k_zsolve256(cd* __restrict__ a, long ncol
   }
   __syncthreads();                           // everyone finished reading the forward transpose
 #pragma unroll
-  for (int n2 = 0; n2 < 16; ++n2) sm[(col * 16 + n2) * 17 + r] = v[n2];   // r = k1
+  for (int n2 = 0; n2 < 16; ++n2) sm[(n2 * 16 + r) * 16 + col] = v[n2];   // r = k1
   __syncthreads();
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) v[k1] = sm[(col * 16 + r) * 17 + k1];   // now r = n2
+  for (int k1 = 0; k1 < 16; ++k1) v[k1] = sm[(r * 16 + k1) * 16 + col];   // now r = n2
   dft16<-1>(v);                                                           // v[n1] = x[n2 + 16 n1]
   if (ok) {
 #pragma unroll
