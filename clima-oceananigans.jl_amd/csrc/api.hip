@@ -414,8 +414,12 @@ static int fused_substep(ocn_model* m, double dt_full, double cn, double cm, int
   launch_fused_tend_step(m, dt_full, cn, cm, use_m);
   int rc = OCN_OK;
   if (m->g->dist && (rc = fused_exchange_ws(m))) return rc;        // w* of the level above the slab
-  launch_rhs_wrap(m, dt_stage, poisson_rhs_buffer(m->solver));
-  rc = poisson_run(m);
+  if (poisson_custom_xy(m)) {
+    rc = poisson_run_from_predictor(m, dt_stage);                  // rhs fused into the x transform
+  } else {
+    launch_rhs_wrap(m, dt_stage, poisson_rhs_buffer(m->solver));
+    rc = poisson_run(m);
+  }
   if (rc) return rc;
   if (m->g->dist && (rc = fused_exchange_phi(m, poisson_rhs_buffer(m->solver)))) return rc;   // p below the slab
   launch_project(m, dt_stage, poisson_rhs_buffer(m->solver));

@@ -134,6 +134,10 @@ double* poisson_rhs_buffer(PoissonSolver* s);
 void* zsolve_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::vector<double>& ly_local);
 void zsolve_destroy(void* z);
 void zsolve_run(ocn_ctx* ctx, void* z, void* spec, const double* lz, double norm, long zero_col);
+void yfft256_run(ocn_ctx* ctx, void* z, void* spec, int Nxh, int Nz, int inverse);
+void xfft_rhs256_run(ocn_model* m, void* z, void* spec, double dt);
+bool poisson_custom_xy(const ocn_model* m);
+int poisson_run_from_predictor(ocn_model* m, double dt);   // fused rhs + custom x/y passes (fast path)
 
 // ---- zslab.hip --------------------------------------------------------------------------------------------
 void* zslab_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::vector<double>& ly, int n, int R, int rank);

@@ -29,12 +29,14 @@ struct PoissonSolver {
   void* zs = nullptr;                      // fused z-transform + eigenvalue division + inverse (zfft.hip), Nz == 256
   void* zsl = nullptr;                     // slab runs: transpose-free z stage (zslab.hip)
   double dz2 = 0;
+  bool cxy = false;                        // custom x / y passes (zfft.hip): rhs fused into the x transform
+  void* tw = nullptr;                      // twiddle holder for the custom passes
   double* rhs = nullptr;      // real (Nx,Ny,Nz)
   double2_* spec = nullptr;   // complex (Nxh,Ny,Nz)
   double* tscr = nullptr;     // Thomas scratch (Nxh*Ny, Nz)
   double *lx = nullptr, *ly = nullptr, *lz = nullptr;  // eigenvalues on the device
 #ifndef OCN_HOST_EMU
-  hipfftHandle fwd = 0, inv = 0, zplan = 0;
+  hipfftHandle fwd = 0, inv = 0, zplan = 0, xinv = 0;
 #endif
 };
 
@@ -111,6 +113,21 @@ PoissonSolver* poisson_create(ocn_model* m) {
     }
     if (s->kind == 0) s->kind = 3;   // 2-D transforms per plane + fused z stage
   }
+  // custom x / y passes: 256-point transforms in x and y, triply periodic, any z stage
+  if (s->Nx == 256 && s->Ny == 256 && g->topo[2] == OCN_PERIODIC && g->z_regular &&
+      !(getenv("OCNHIP_NO_CUSTOM_XY") && atoi(getenv("OCNHIP_NO_CUSTOM_XY")) != 0)) {
+    if (!s->zs && !s->zsl) {
+      // no fused z kernel for this Nz: the Green's-function z stage works for any Nz (one "slab")
+      std::vector<double> lxh = eigenvalues_periodic(s->Nx, g->L[0]);
+      lxh.resize(s->Nxh);
+      s->zsl = zslab_create(m->ctx, lxh, eigenvalues_periodic(s->Ny, g->L[1]), s->Nz, 1, 0);
+      double dz = g->L[2] / g->Nzg;
+      s->dz2 = dz * dz;
+    }
+    std::vector<double> one(1, 0.0);
+    s->tw = zsolve_create(m->ctx, one, one);
+    s->cxy = s->tw != nullptr && (s->zs || s->zsl);
+  }
   s->lx = upload(eigenvalues_periodic(s->Nx, g->L[0]));
   s->ly = upload(eigenvalues_periodic(s->Ny, g->L[1]));
   if (g->topo[2] == OCN_PERIODIC) s->lz = upload(eigenvalues_periodic(g->dist ? g->Nzg : s->Nz, g->L[2]));
@@ -151,6 +168,15 @@ PoissonSolver* poisson_create(ocn_model* m) {
   }
   hipfftSetStream(s->fwd, m->ctx->stream);
   hipfftSetStream(s->inv, m->ctx->stream);
+  if (s->cxy) {
+    int nx[1] = {s->Nx}, ie[1] = {s->Nxh}, oe[1] = {s->Nx};
+    if (hipfftPlanMany(&s->xinv, 1, nx, ie, 1, s->Nxh, oe, 1, s->Nx, HIPFFT_Z2D, s->Ny * s->Nz) != HIPFFT_SUCCESS) {
+      ocn_set_error(m->ctx, "hipfft x-inverse plan creation failed");
+      poisson_destroy(s);
+      return nullptr;
+    }
+    hipfftSetStream(s->xinv, m->ctx->stream);
+  }
 #endif
   return s;
 }
@@ -161,7 +187,9 @@ void poisson_destroy(PoissonSolver* s) {
   if (s->fwd) hipfftDestroy(s->fwd);
   if (s->inv) hipfftDestroy(s->inv);
   if (s->zplan) hipfftDestroy(s->zplan);
+  if (s->xinv) hipfftDestroy(s->xinv);
 #endif
+  zsolve_destroy(s->tw);
   hipFree(s->ta);
   hipFree(s->tb);
   zsolve_destroy(s->zs);
@@ -461,6 +489,62 @@ static int run_solver(ocn_model* m) {
 }
 
 int poisson_run(ocn_model* m) { return run_solver(m); }
+
+bool poisson_custom_xy(const ocn_model* m) { return m->solver && m->solver->cxy; }
+
+#ifdef OCN_HOST_EMU
+// x-inverse of the half spectrum, line by line (emulation of the batched 1-D Z2D plan)
+static void emu_xinv(PoissonSolver* s) {
+  const int Nx = s->Nx, Nxh = s->Nxh;
+  const size_t lines = (size_t)s->Ny * s->Nz;
+  std::vector<cplx> full(Nx);
+  for (size_t L = 0; L < lines; ++L) {
+    for (int i = 0; i < Nx; ++i) {
+      double2_ q = s->spec[(i < Nxh ? i : Nx - i) + Nxh * L];
+      full[i] = cplx(q.x, i < Nxh ? q.y : -q.y);
+    }
+    for (int n = 0; n < Nx; ++n) {
+      cplx acc = 0;
+      for (int i = 0; i < Nx; ++i) {
+        double ang = 2.0 * M_PI * ((long)i * n % Nx) / Nx;
+        acc += full[i] * cplx(cos(ang), sin(ang));
+      }
+      s->rhs[n + Nx * L] = acc.real();
+    }
+  }
+}
+#endif
+
+// fast path: rhs + x transform fused, custom y transform, z stage, custom inverse y, library inverse x.
+// Leaves the solution in the solver's real buffer (like run_solver).
+int poisson_run_from_predictor(ocn_model* m, double dt) {
+  PoissonSolver* s = m->solver;
+  {
+    ProfScope ps(m->ctx, "fft_forward");
+    xfft_rhs256_run(m, s->tw, s->spec, dt);
+    yfft256_run(m->ctx, s->tw, s->spec, s->Nxh, s->Nz, 0);
+  }
+  if (s->zs) {
+    ProfScope ps(m->ctx, "spectral_solve");
+    zsolve_run(m->ctx, s->zs, s->spec, s->lz, 1.0 / ((double)s->Nx * s->Ny * s->Nz), 0);
+  } else {
+    int rc = zslab_run(m->ctx, s->zsl, s->spec, s->dz2, 1.0 / ((double)s->Nx * s->Ny));
+    if (rc) return rc;
+  }
+  {
+    ProfScope ps(m->ctx, "fft_backward");
+    yfft256_run(m->ctx, s->tw, s->spec, s->Nxh, s->Nz, 1);
+#ifndef OCN_HOST_EMU
+    if (hipfftExecZ2D(s->xinv, (hipfftDoubleComplex*)s->spec, s->rhs) != HIPFFT_SUCCESS) {
+      ocn_set_error(m->ctx, "hipfftExecZ2D (x inverse) failed");
+      return OCN_EHIP;
+    }
+#else
+    emu_xinv(s);
+#endif
+  }
+  return OCN_OK;
+}
 
 // solve_for_pressure!(pNHS, solver, dt, U*)  (solve_for_pressure.jl:55-89)
 int poisson_solve(ocn_model* m, double dt) {

@@ -117,6 +117,95 @@ __global__ void __launch_bounds__(256) k_zsolve256(cd* __restrict__ a, long ncol
   }
 }
 
+// ---- y-direction pass: in-place 256-point FFT along ky of the half spectrum (Nxh, 256, Nz) -------------------
+// Tiles of 16 columns.  Main tiles: 16 consecutive kx of one z-plane (256 contiguous bytes per ky).  The
+// Nxh % 16 left-over kx columns are tiled over the flattened (kx_left, z) index.
+template <int S>
+__global__ void __launch_bounds__(256) k_yfft256(cd* __restrict__ a, int Nxh, int Nz, const cd* __restrict__ tw256) {
+  OCN_SHARED cd sm[16 * 16 * 16];
+  const int t = threadIdx.x;
+  const int col = t & 15, r = t >> 4;
+  const int nfull = Nxh / 16, left = Nxh - 16 * nfull;
+  const long plane = (long)Nxh * 256;
+  const long nmain = (long)nfull * Nz;
+  long base;
+  bool ok = true;
+  if ((long)blockIdx.x < nmain) {
+    const int tile = blockIdx.x % nfull, zz = blockIdx.x / nfull;
+    base = 16 * tile + col + plane * zz;
+  } else {
+    const long c = ((long)blockIdx.x - nmain) * 16 + col;      // flattened (kx_left, z)
+    ok = left > 0 && c < (long)left * Nz;
+    const long zz = ok ? c / left : 0, kl = ok ? c - zz * left : 0;
+    base = 16 * nfull + kl + plane * zz;
+  }
+  cd v[16];
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) v[n1] = ok ? a[base + (long)Nxh * (r + 16 * n1)] : cd{0, 0};
+  dft16<S>(v);
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) {
+    cd w = tw256[(r * k1) & 255];
+    if (S < 0) w.y = -w.y;
+    v[k1] = cmul(v[k1], w);
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) sm[(k1 * 16 + r) * 16 + col] = v[k1];
+  __syncthreads();
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) v[n2] = sm[(r * 16 + n2) * 16 + col];   // r = k1 now
+  dft16<S>(v);                                                            // v[k2] = X[k1 + 16 k2]
+  if (ok) {
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) a[base + (long)Nxh * (r + 16 * k2)] = v[k2];
+  }
+}
+
+// ---- x-direction forward pass fused with the Poisson right-hand side ----------------------------------------------
+// rhs = div(U*) / dt (solve_for_pressure.jl:15-18) is formed on the fly from the predictor with periodic wrap
+// indexing and transformed along x (256 real points as a complex FFT with zero imaginary part); the half
+// spectrum kx = 0..128 is written once.  One workgroup = 16 consecutive x-lines (flattened j + Ny k).
+__global__ void __launch_bounds__(256) k_xfft_rhs256(GridDev g, const double* __restrict__ us, const double* __restrict__ vs,
+                                                     const double* __restrict__ ws, double rdt, int zwrap,
+                                                     cd* __restrict__ spec, const cd* __restrict__ tw256) {
+  OCN_SHARED cd sm[16 * 16 * 16];
+  const int t = threadIdx.x;
+  const int r = t & 15, ln = t >> 4;              // r = x mod 16 (loads) / k1 (stores); ln = line inside the tile
+  const long L = (long)blockIdx.x * 16 + ln;      // line index j + Ny k
+  const long nlines = (long)g.Ny * g.Nz;
+  const bool ok = L < nlines;
+  const int k = ok ? (int)(L / g.Ny) : 0, j = ok ? (int)(L - (long)k * g.Ny) : 0;
+  const long sy = g.sy, sz = g.sz;
+  const long row = j * sy + k * sz;
+  const long rown = ((j + 1 == g.Ny) ? 0 : j + 1) * sy + k * sz;
+  const long rowt = (zwrap && k + 1 == g.Nz) ? j * sy : j * sy + (k + 1) * sz;
+  const double rdz = 1.0 / g.dz;
+  cd v[16];
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    const int i = r + 16 * n1;
+    const int ie = (i + 1 == g.Nx) ? 0 : i + 1;
+    double d = 0.0;
+    if (ok) d = ((us[row + ie] - us[row + i]) * g.rdx + (vs[rown + i] - vs[row + i]) * g.rdy + (ws[rowt + i] - ws[row + i]) * rdz) * rdt;
+    v[n1] = {d, 0.0};
+  }
+  dft16<1>(v);
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], tw256[(r * k1) & 255]);
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) sm[(k1 * 16 + r) * 16 + ln] = v[k1];
+  __syncthreads();
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) v[n2] = sm[(r * 16 + n2) * 16 + ln];
+  dft16<1>(v);                                    // v[k2] = X[k1 + 16 k2], k1 = r
+  if (ok) {
+    cd* out = spec + L * 129;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) out[r + 16 * k2] = v[k2];
+    if (r == 0) out[128] = v[8];
+  }
+}
+
 // host side ---------------------------------------------------------------------------------------------------
 struct ZSolve {
   cd* tw = nullptr;
@@ -151,6 +240,25 @@ void zsolve_destroy(void* p) {
   hipFree(z->tw);
   hipFree(z->lxy);
   delete z;
+}
+
+// forward / inverse y pass (in place), and the fused rhs + x pass; all unnormalised
+void yfft256_run(ocn_ctx* ctx, void* p, void* spec, int Nxh, int Nz, int inverse) {
+  ZSolve* z = (ZSolve*)p;
+  const int nfull = Nxh / 16, left = Nxh - 16 * nfull;
+  const long nblk = (long)nfull * Nz + ((long)left * Nz + 15) / 16;
+  dim3 b(256, 1, 1), g((unsigned)nblk, 1, 1);
+  if (inverse) ocn_launch_sync(k_yfft256<-1>, g, b, ctx->stream, (cd*)spec, Nxh, Nz, (const cd*)z->tw);
+  else ocn_launch_sync(k_yfft256<1>, g, b, ctx->stream, (cd*)spec, Nxh, Nz, (const cd*)z->tw);
+}
+
+void xfft_rhs256_run(ocn_model* m, void* p, void* spec, double dt) {
+  ZSolve* z = (ZSolve*)p;
+  const GridDev& g = m->gd;
+  const long nlines = (long)g.Ny * g.Nz;
+  dim3 b(256, 1, 1), gr((unsigned)((nlines + 15) / 16), 1, 1);
+  ocn_launch_sync(k_xfft_rhs256, gr, b, m->ctx->stream, g, (const double*)m->us.interior(), (const double*)m->vs.interior(),
+                  (const double*)m->ws.interior(), 1.0 / dt, m->g->dist ? 0 : 1, (cd*)spec, (const cd*)z->tw);
 }
 
 // in place on the (ncol, 256) spectrum; `zero_col` < 0 when this rank does not own the mean mode
