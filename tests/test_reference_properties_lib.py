@@ -1,0 +1,163 @@
+"""The reference's own property / known-answer tests driven through the C ABI (host emulation of the kernel
+sources on CPU, HIP on the GPU box): test/test_time_stepping.jl:112-146 (incompressibility), test/test_dynamics.jl:
+170-258 (Taylor-Green decay, Gaussian tracer advection), test/test_halo_regions.jl:22-41,
+test/test_poisson_solvers*.jl (lap(phi) == R), test_nonhydrostatic_models.jl:55-60 (halo inflation)."""
+import numpy as np
+import pytest
+
+P, B = "Periodic", "Bounded"
+
+
+def _run(ocn, backend, marker_gpu):
+    if marker_gpu and backend != "gpu":
+        pytest.skip("HIP run only")
+    if not marker_gpu and backend != "hostemu":
+        pytest.skip("host-emulation run only")
+
+
+def _incompressible(ocn, N, stepper, Nt):
+    S = 1.3
+    grids = [dict(x=(0, 1), y=(0, 1), z=(-1.0, 1.0)),
+             dict(x=(0, 1), y=(0, 1), z=lambda k: np.tanh(S * (2 * (k - 1) / N - 1)) / np.tanh(S)),
+             dict(x=(0, 1), y=(0, 1), z=np.linspace(0, 1, N + 1))]
+    for kw in grids:
+        g = ocn.RectilinearGrid(size=(N, N, N), **kw)
+        m = ocn.NonhydrostaticModel(g, timestepper=stepper, buoyancy=ocn.SeawaterBuoyancy(), tracers=("T", "S"))
+        T = np.zeros((N, N, N))
+        a, b = N // 4, 3 * N // 4
+        T[a:b, a:b, a:b] += 0.01
+        ocn.set_model(m, T=T, enforce_incompressibility=False)
+        for _ in range(Nt):
+            ocn.time_step(m, 0.05)
+        assert np.abs(m.w.interior()).max() > 0
+        assert m.max_abs_divergence() < 5e-8
+
+
+def _taylor_green(ocn, N, stepper):
+    nu, Nt = 1.0, 10
+    g = ocn.RectilinearGrid(size=(N, N, 2), extent=(1, 1, 1))
+    dt = (1 / (10 * np.pi)) * (1 / N) ** 2 / nu
+    m = ocn.NonhydrostaticModel(g, timestepper=stepper, closure=ocn.ScalarDiffusivity(nu=nu))
+    ocn.set_model(m, u=lambda x, y, z: -np.sin(2 * np.pi * y), v=lambda x, y, z: np.sin(2 * np.pi * x))
+    for _ in range(Nt):
+        ocn.time_step(m, dt)
+    decay = np.exp(-4 * np.pi ** 2 * nu * m.time)
+    X, Y, _ = m.nodes("u")
+    ua = -np.sin(2 * np.pi * Y) * decay + 0 * X
+    X, Y, _ = m.nodes("v")
+    va = np.sin(2 * np.pi * X) * decay + 0 * Y
+    assert np.abs((m.u.interior() - ua) / ua).max() < 5e-6
+    assert np.abs((m.v.interior() - va) / va).max() < 5e-6
+
+
+def _tracer_advection(ocn, N, stepper):
+    Nt, kap = 100, 1e-12
+    L, U, V = 1.0, 0.5, 0.8
+    dl, x0, y0 = L / 15, L / 2, L / 2
+    dt = 0.05 * L / N / np.sqrt(U ** 2 + V ** 2)
+
+    def T(x, y, t):
+        return np.exp(-((x - U * t - x0) ** 2 + (y - V * t - y0) ** 2) / (2 * dl ** 2))
+    g = ocn.RectilinearGrid(size=(N, N, 2), extent=(L, L, L))
+    m = ocn.NonhydrostaticModel(g, closure=ocn.ScalarDiffusivity(nu=kap, kappa=kap), timestepper=stepper,
+                                buoyancy=ocn.SeawaterBuoyancy(), tracers=("T", "S"))
+    ocn.set_model(m, u=U, v=V, T=lambda x, y, z: T(x, y, 0) + 0 * z)
+    for _ in range(Nt):
+        ocn.time_step(m, dt)
+    X, Y, _ = m.nodes("T")
+    Ta = T(X, Y, m.time) + np.zeros((1, 1, 2))
+    assert np.mean((m.tracers["T"].interior() - Ta) ** 2) / np.mean(Ta ** 2) < 1e-4
+
+
+def _halos(ocn):
+    N = (5, 7, 9)
+    rng = np.random.default_rng(0)
+    g = ocn.RectilinearGrid(size=N, extent=(100, 200, 300), halo=(1, 1, 1), topology=(P, P, B))
+    m = ocn.NonhydrostaticModel(g, tracers=("c",))
+    assert m.halo == (1, 1, 1)
+    f = m.tracers["c"]
+    f.set(rng.random(N))
+    d = f.parent()
+    assert (d[0] == 0).all() and (d[-1] == 0).all() and (d[:, :, 0] == 0).all()     # halos untouched by set!
+    ocn.update_state(m)
+    d = f.parent()
+    it = slice(1, -1)
+    Nx, Ny, Nz = N
+    assert (d[0, it, it] == d[Nx, it, it]).all() and (d[Nx + 1, it, it] == d[1, it, it]).all()
+    assert (d[it, 0, it] == d[it, Ny, it]).all() and (d[it, Ny + 1, it] == d[it, 1, it]).all()
+    assert (d[it, it, 0] == d[it, it, 1]).all() and (d[it, it, Nz + 1] == d[it, it, Nz]).all()
+    m2 = ocn.NonhydrostaticModel(ocn.RectilinearGrid(size=N, extent=(1, 1, 1), halo=(1, 1, 1), topology=(P, P, B)),
+                                 advection=ocn.WENO5())
+    assert m2.halo == (3, 3, 3)                                                  # halo inflation
+
+
+def _poisson(ocn):
+    import oracle as O
+    from oracle.fields import Field, fill_halo_regions
+    from oracle.operators import Ops
+    rng = np.random.default_rng(3)
+    faces = np.array([1, 2, 4, 7, 11, 16, 22, 29, 37.0])
+    cases = [((16, 11, 7), dict(extent=(1, 1, 1), topology=(P, P, P))),
+             ((11, 16, 7), dict(extent=(1, 1, 1), topology=(P, P, B))),
+             ((8, 7, 8), dict(x=(0, 1), y=(0, 1), z=faces, topology=(P, P, B)))]
+    for N, kw in cases:
+        m = ocn.NonhydrostaticModel(ocn.RectilinearGrid(size=N, **kw))
+        R = rng.random(N)
+        R -= R.mean()
+        if "z" in kw:    # volume-weighted compatibility on the stretched grid
+            dz = np.diff(faces).reshape(1, 1, -1)
+            R -= (R * dz).sum() / (dz.sum() * N[0] * N[1])
+        phi = m.poisson_solve(R)
+        og = O.RectilinearGrid(size=N, **kw)
+        f = Field(og, (O.Center,) * 3)
+        f.set(phi)
+        fill_halo_regions(f)
+        assert np.allclose(Ops(og).laplacian_ccc(f)((0, 0, 0)), R, rtol=1.5e-8, atol=1e-9)
+
+
+# ---- CPU (host emulation) at reduced sizes ----------------------------------------------------------------------
+@pytest.mark.parametrize("stepper", ["QuasiAdamsBashforth2", "RungeKutta3"])
+def test_incompressible_hostemu(ocn, backend, stepper):
+    _run(ocn, backend, False)
+    _incompressible(ocn, 16, stepper, 3)
+
+
+def test_taylor_green_hostemu(ocn, backend):
+    _run(ocn, backend, False)
+    _taylor_green(ocn, 64, "RungeKutta3")
+
+
+def test_halos_and_poisson_hostemu(ocn, backend):
+    _run(ocn, backend, False)
+    _halos(ocn)
+    _poisson(ocn)
+
+
+# ---- GPU at the reference's sizes -----------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("stepper", ["QuasiAdamsBashforth2", "RungeKutta3"])
+@pytest.mark.parametrize("Nt", [1, 10, 100])
+def test_incompressible_gpu(ocn, backend, stepper, Nt):
+    _run(ocn, backend, True)
+    _incompressible(ocn, 32, stepper, Nt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stepper", ["QuasiAdamsBashforth2", "RungeKutta3"])
+def test_taylor_green_gpu(ocn, backend, stepper):
+    _run(ocn, backend, True)
+    _taylor_green(ocn, 64, stepper)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stepper", ["QuasiAdamsBashforth2", "RungeKutta3"])
+def test_tracer_advection_gpu(ocn, backend, stepper):
+    _run(ocn, backend, True)
+    _tracer_advection(ocn, 128, stepper)
+
+
+@pytest.mark.gpu
+def test_halos_and_poisson_gpu(ocn, backend):
+    _run(ocn, backend, True)
+    _halos(ocn)
+    _poisson(ocn)
