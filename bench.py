@@ -177,8 +177,15 @@ def main():
     roofline = None
     if dom:
         ach = B_ALG_PHASE[dom] * cells_local / (cand[dom]["avg_ms"] * 1e-3)
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, calibrated; see profiles/)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if world == 1 and args.config == 2 and not args.size and dom in tj["kernels"]:
+                traffic = tj["kernels"][dom]["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK, "traffic": None,
+                    "frac": ach / HBM_PEAK, "traffic": traffic,
                     "alg_bytes_per_launch": B_ALG_PHASE[dom] * cells_local, "avg_launch_ms": cand[dom]["avg_ms"]}
     step_frac = value / world * B_ALG_STEP / HBM_PEAK
 
