@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--size", type=int, nargs=3, default=None, help="override per-GPU size (debug)")
     ap.add_argument("--stepper", default="AB2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tracers", type=int, default=0, help="passive tracers (config 2b: 1)")
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (headline, default) or 3 (ocean LES)")
     args = ap.parse_args()
 
@@ -124,10 +125,13 @@ def main():
         model, dt3, Nglobal, n = build_config3(ocn, ctx, args)
     else:
         grid = ocn.RectilinearGrid(ctx, size=Nglobal, extent=(1, 1, float(world)), topology=("Periodic",) * 3)
-        model = ocn.NonhydrostaticModel(grid, advection=ocn.WENO5(), timestepper=args.stepper)
+        tnames = tuple(f"c{i}" for i in range(args.tracers))
+        model = ocn.NonhydrostaticModel(grid, advection=ocn.WENO5(), timestepper=args.stepper, tracers=tnames)
         rng = np.random.default_rng(1 + rank)
         local = model.u.size
-        ocn.set_model(model, u=rng.random(local) - 0.5, v=rng.random(local) - 0.5, w=rng.random(local) - 0.5)
+        init = dict(u=rng.random(local) - 0.5, v=rng.random(local) - 0.5, w=rng.random(local) - 0.5)
+        init.update({t: rng.random(local) for t in tnames})
+        ocn.set_model(model, **init)
     umax = np.abs(model.u.interior()).max()
     if dist is not None:
         import torch
@@ -166,7 +170,7 @@ def main():
     value = cells * args.steps / el
 
     phases = {}
-    for ph in list(B_ALG_PHASE) + ["fill_halos", "store", "copy_pressure", "time_step", "halo_exchange", "transpose",
+    for ph in list(B_ALG_PHASE) + ["fused_tracer_step", "fill_halos", "store", "copy_pressure", "time_step", "halo_exchange", "transpose",
                                    "amd_diffusivities", "hydrostatic"]:
         avg, cnt = ctx.profile_read(ph)
         if cnt:
@@ -195,7 +199,7 @@ def main():
             "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} triply-periodic RectilinearGrid, "
-                                    f"NonhydrostaticModel WENO5(zweno) + FFT Poisson, {args.stepper}, halo 3, no tracers")
+                                    f"NonhydrostaticModel WENO5(zweno) + FFT Poisson, {args.stepper}, halo 3, {args.tracers} tracers")
                        if args.config == 2 else
                        (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} (Periodic,Periodic,Bounded) stretched z, WENO5, RK3, T+S, "
                         "FPlane, linear EOS, AMD, flux/gradient BCs, Fourier-tridiagonal Poisson (BASELINE config 3)"),

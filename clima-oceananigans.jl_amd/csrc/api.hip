@@ -412,6 +412,7 @@ static void zero_Gm(ocn_model* m) {
 // one fused (sub)step of the fast path: tendencies + update, rhs, solve, projection + halo images
 static int fused_substep(ocn_model* m, double dt_full, double cn, double cm, int use_m, double dt_stage, bool swap) {
   launch_fused_tend_step(m, dt_full, cn, cm, use_m);
+  launch_tracer_steps(m, dt_full, cn, cm, use_m);                  // passive tracers: old velocities, own update
   int rc = OCN_OK;
   if (m->g->dist && (rc = fused_exchange_ws(m))) return rc;        // w* of the level above the slab
   if (poisson_custom_xy(m)) {
@@ -424,11 +425,13 @@ static int fused_substep(ocn_model* m, double dt_full, double cn, double cm, int
   if (m->g->dist && (rc = fused_exchange_phi(m, poisson_rhs_buffer(m->solver)))) return rc;   // p below the slab
   launch_project(m, dt_stage, poisson_rhs_buffer(m->solver));
   if (m->g->dist) {
-    Field* fs[4] = {&m->u, &m->v, &m->w, &m->pNHS};
-    if ((rc = comm_halo_exchange_z(m, fs, 4))) return rc;
+    Field* fs[4 + OCN_MAX_TRACERS] = {&m->u, &m->v, &m->w, &m->pNHS};
+    int nf = 4;
+    for (int t = 0; t < m->nt; ++t) fs[nf++] = &m->tr[t];
+    if ((rc = comm_halo_exchange_z(m, fs, nf))) return rc;
   }
   if (swap)
-    for (int f = 0; f < 3; ++f) std::swap(m->Gn[f], m->Gm[f]);   // store_tendencies! as a pointer swap
+    for (int f = 0; f < 3 + m->nt; ++f) std::swap(m->Gn[f], m->Gm[f]);   // store_tendencies! as a pointer swap
   return OCN_OK;
 }
 
@@ -601,6 +604,7 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
   if (m->fast_path) {
     int r2 = field_alloc(m, m->us, OCN_FACE, OCN_CENTER, OCN_CENTER) | field_alloc(m, m->vs, OCN_CENTER, OCN_FACE, OCN_CENTER) |
              field_alloc(m, m->ws, OCN_CENTER, OCN_CENTER, OCN_FACE);
+    for (int t = 0; t < m->nt; ++t) r2 |= field_alloc(m, m->trs[t], OCN_CENTER, OCN_CENTER, OCN_CENTER);
     if (r2) {
       ocn_model_destroy(m);
       return OCN_ENOMEM;
@@ -622,6 +626,7 @@ void ocn_model_destroy(ocn_model* m) {
   Field* all[] = {&m->u, &m->v, &m->w, &m->pHY, &m->pNHS, &m->nu_e, &m->us, &m->vs, &m->ws};
   for (Field* f : all) hipFree(f->d);
   for (int t = 0; t < OCN_MAX_TRACERS; ++t) {
+    hipFree(m->trs[t].d);
     hipFree(m->tr[t].d);
     hipFree(m->kappa_e[t].d);
   }

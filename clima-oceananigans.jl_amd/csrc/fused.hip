@@ -467,6 +467,58 @@ __global__ void k_project(GridDev g, ProjArgs a) {
   store_images(g, a.p, i, j, k, p0, a.zwrap);
 }
 
+// ---- passive tracers on the fast path: calculate_Gc! + time-stepper update in one pass ---------------------------
+// (calculate_nonhydrostatic_tendencies.jl:177-180, tracer_advection_operators.jl:31-35, quasi_adams_bashforth_2.jl:158-166).
+// The updated tracer goes to a second buffer (neighbours still read the old one) together with its periodic
+// images; the two buffers are then swapped.  One thread per (i, j) column of a z-chunk: the bottom flux of the next
+// level is this level's top flux (register carry), z stencils live in a 6-deep register window; x / y face fluxes
+// are evaluated on both faces from cached loads (a tracer adds 5 reconstructions per cell).
+struct TracerArgs {
+  const double *u, *v, *w, *c, *gm;   // interior-origin pointers
+  double *gn, *cnew;
+  double dt, cn, cm;
+  int use_m, KZ, zwrap;
+};
+
+template <int ADV>
+__global__ void __launch_bounds__(256) k_tracer_step(GridDev g, TracerArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const int k0 = blockIdx.z * a.KZ;
+  const int k1 = (k0 + a.KZ < g.Nz) ? k0 + a.KZ : g.Nz;
+  const long sy = g.sy, sz = g.sz;
+  const double rdx = g.rdx, rdy = g.rdy, rdz = 1.0 / g.dz;
+  long c = i + j * sy + (long)k0 * sz;
+  double zc[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) zc[q] = a.c[c + (q - 3) * sz];
+  auto fz = [&](long p) {   // flux through the bottom face of the cell at p (window centred there)
+    const double wt = a.w[p];
+    const bool pos = wt > 0.0;
+    return wt * recon5<ADV>(pos ? zc[0] : zc[5], pos ? zc[1] : zc[4], pos ? zc[2] : zc[3], pos ? zc[3] : zc[2],
+                            pos ? zc[4] : zc[1], pos);
+  };
+  double fb = fz(c);
+  for (int k = k0; k < k1; ++k, c += sz) {
+    // west / east and south / north fluxes (advecting velocity un-interpolated: upwind_biased_advective_fluxes.jl:103-119)
+    const double uw = a.u[c], ue = a.u[c + 1], vs_ = a.v[c], vn = a.v[c + sy];
+    const double fxw = uw * recon_mem<ADV>(a.c + c, 1, uw), fxe = ue * recon_mem<ADV>(a.c + c + 1, 1, ue);
+    const double fys = vs_ * recon_mem<ADV>(a.c + c, sy, vs_), fyn = vn * recon_mem<ADV>(a.c + c + sy, sy, vn);
+    const double cc = zc[3];
+    // advance the window to level k+1 and take its bottom flux = this level's top flux
+#pragma unroll
+    for (int q = 0; q < 5; ++q) zc[q] = zc[q + 1];
+    zc[5] = a.c[c + 3 * sz];
+    const double ft = fz(c + sz);
+    const double G = -((fxe - fxw) * rdx + (fyn - fys) * rdy + (ft - fb) * rdz);
+    fb = ft;
+    a.gn[c] = G;
+    const double inc = a.use_m ? a.dt * (a.cn * G + a.cm * a.gm[c]) : a.dt * a.cn * G;
+    store_images(g, a.cnew, i, j, k, cc + inc, a.zwrap);
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------
 bool fused_available(const ocn_model* m) {
   const ocn_grid* g = m->g;
@@ -475,7 +527,6 @@ bool fused_available(const ocn_model* m) {
   int adv = m->d.advection;
   if (adv != ADV_WENO_Z && adv != ADV_WENO_JS && adv != ADV_U5) return false;
   if (m->d.closure != OCN_CLOSURE_NONE || m->d.coriolis_fplane || m->d.buoyancy != OCN_BUOYANCY_NONE) return false;
-  if (m->nt != 0) return false;
   for (int d = 0; d < 3; ++d)
     if (g->H[d] < 3 || g->N[d] < 2 * g->H[d]) return false;
   if (g->N[0] > FUSED_MAX_THREADS / 2) return false;   // a workgroup must own complete x rows (+ a ghost row)
@@ -612,4 +663,29 @@ int fused_exchange_phi(ocn_model* m, const double* phi) {
   std::vector<CommOp> s{{(char*)phi + plane * (size_t)(m->gd.Nz - 1), plane, up, 8}};
   std::vector<CommOp> q{{(void*)m->phi_below, plane, dn, 8}};
   return comm_exchange(c, s, q);
+}
+
+void launch_tracer_steps(ocn_model* m, double dt, double cn, double cm, int use_m) {
+  if (m->nt == 0) return;
+  ProfScope ps(m->ctx, "fused_tracer_step");
+  const GridDev& g = m->gd;
+  for (int t = 0; t < m->nt; ++t) {
+    TracerArgs a;
+    a.u = m->u.interior(); a.v = m->v.interior(); a.w = m->w.interior();
+    a.c = m->tr[t].interior();
+    a.gm = m->Gm[3 + t].interior();
+    a.gn = m->Gn[3 + t].interior();
+    a.cnew = m->trs[t].interior();
+    a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
+    a.KZ = 32;
+    a.zwrap = m->g->dist ? 0 : 1;
+    dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, (g.Nz + a.KZ - 1) / a.KZ);
+    switch (m->d.advection) {
+      case ADV_WENO_Z: ocn_launch(k_tracer_step<ADV_WENO_Z>, gr, b, m->ctx->stream, g, a); break;
+      case ADV_WENO_JS: ocn_launch(k_tracer_step<ADV_WENO_JS>, gr, b, m->ctx->stream, g, a); break;
+      default: ocn_launch(k_tracer_step<ADV_U5>, gr, b, m->ctx->stream, g, a); break;
+    }
+  }
+  // the freshly written buffers become the tracers (pointer swap; boundary conditions stay with the field)
+  for (int t = 0; t < m->nt; ++t) std::swap(m->tr[t].d, m->trs[t].d);
 }

@@ -82,6 +82,7 @@ struct ocn_model {
   Field nu_e, kappa_e[OCN_MAX_TRACERS];
   // projection scratch: predictor velocities are written here by the fused kernels
   Field us, vs, ws;
+  Field trs[OCN_MAX_TRACERS];   // second tracer buffers of the fused path
   PoissonSolver* solver = nullptr;
   std::vector<double*> owned;  // extra device allocations (bc arrays)
   // clock / stepper state
@@ -119,6 +120,7 @@ bool fused_available(const ocn_model* m);
 void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m);
 void launch_rhs_wrap(ocn_model* m, double dt, double* rhs);
 void launch_project(ocn_model* m, double dt, const double* phi);
+void launch_tracer_steps(ocn_model* m, double dt, double cn, double cm, int use_m);
 int fused_exchange_ws(ocn_model* m);
 int fused_exchange_phi(ocn_model* m, const double* phi);
 int poisson_run(ocn_model* m);   // transforms + spectral solve on the solver's rhs buffer, in place

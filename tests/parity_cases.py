@@ -22,6 +22,8 @@ CASES = {
     "ppp_weno_rk3": dict(size=(12, 16, 8), topo=(P, P, P), extent=(1, 1, 1), adv="WENO5", stepper="RK3", steps=2, dt=4e-3),
     "ppp_wenojs_tracer": dict(size=(8, 8, 8), topo=(P, P, P), extent=(1, 1, 1), adv="WENO5JS", stepper="AB2", steps=2,
                               dt=2e-3, tracers=("c",)),
+    "ppp_weno_rk3_2tracers": dict(size=(10, 8, 12), topo=(P, P, P), extent=(1, 1, 1), adv="WENO5", stepper="RK3", steps=2,
+                                  dt=3e-3, tracers=("a", "b2")),
     "ppp_u5_visc": dict(size=(10, 9, 8), topo=(P, P, P), extent=(1, 1, 1), adv="U5", stepper="AB2", steps=2, dt=2e-3,
                         tracers=("c",), closure=(1e-2, 2e-2)),
     "ppp_c4": dict(size=(8, 10, 12), topo=(P, P, P), extent=(1, 1, 1), adv="C4", stepper="RK3", steps=2, dt=2e-3),

@@ -38,8 +38,12 @@ def test_slab_trajectory_matches_single_domain_oracle(ocn, backend, R, stepper, 
     N = (8, 8, 8 * R)
     rng = np.random.default_rng(5)
     init = {n: rng.random(N) - 0.5 for n in "uvw"}
+    tracers = ("c",) if stepper == "RK3" else ()
+    for t in tracers:
+        init[t] = rng.random(N)
     og = O.RectilinearGrid(size=N, extent=(1, 1, float(R)), topology=(P,) * 3)
-    om = O.NonhydrostaticModel(og, advection=O.WENO5() if adv == "WENO5" else O.CenteredSecondOrder(), timestepper=stepper)
+    om = O.NonhydrostaticModel(og, advection=O.WENO5() if adv == "WENO5" else O.CenteredSecondOrder(), timestepper=stepper,
+                               tracers=tracers)
     O.set_model(om, **init)
     dt = 2e-3
     for _ in range(2):
@@ -48,17 +52,21 @@ def test_slab_trajectory_matches_single_domain_oracle(ocn, backend, R, stepper, 
     def rank_fn(ctx, r):
         g = ocn.RectilinearGrid(ctx, size=N, extent=(1, 1, float(R)), topology=(P,) * 3)
         m = ocn.NonhydrostaticModel(g, advection=ocn.WENO5() if adv == "WENO5" else ocn.CenteredSecondOrder(),
-                                    timestepper=stepper)
+                                    timestepper=stepper, tracers=tracers)
         nz = N[2] // R
         ocn.set_model(m, **{n: a[:, :, r * nz:(r + 1) * nz] for n, a in init.items()})
         for _ in range(2):
             ocn.time_step(m, dt)
-        return {n: f.parent() for n, f in (("u", m.u), ("v", m.v), ("w", m.w), ("p", m.pNHS))}, m.max_abs_divergence()
+        out = {n: f.parent() for n, f in (("u", m.u), ("v", m.v), ("w", m.w), ("p", m.pNHS))}
+        out.update({t: m.tracers[t].parent() for t in tracers})
+        return out, m.max_abs_divergence()
     res = run_ranks(ocn, R, rank_fn)
     H, nz = 3, N[2] // R
     for r, (flds, div) in enumerate(res):
         assert div < 1e-11
-        for n, ref in (("u", om.u.data), ("v", om.v.data), ("w", om.w.data), ("p", om.pNHS.data)):
+        refs = [("u", om.u.data), ("v", om.v.data), ("w", om.w.data), ("p", om.pNHS.data)]
+        refs += [(t, om.tracers[t].data) for t in tracers]
+        for n, ref in refs:
             # slab parent (incl. z halos) == the matching window of the periodic global parent array
             idx = (np.arange(-H, nz + H) + r * nz) % N[2] + H
             want = ref[:, :, idx]
