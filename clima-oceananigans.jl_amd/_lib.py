@@ -81,6 +81,7 @@ def load():
         "ocn_model_halo": (I, [P, C.POINTER(C.c_int32 * 3)]),
         "ocn_field_shape": (I, [P, I, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32 * 3)]),
         "ocn_field_device_ptr": (P, [P, I]),
+        "ocn_field_layout": (I, [P, I, C.POINTER(C.c_int64 * 3), C.POINTER(C.c_int64)]),
         "ocn_field_upload": (I, [P, I, PD]),
         "ocn_field_download": (I, [P, I, PD]),
         "ocn_field_set_interior": (I, [P, I, PD]),

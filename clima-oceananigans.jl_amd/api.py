@@ -175,7 +175,7 @@ class RectilinearGrid:
         self.topo = topo
         self.h = C.c_void_p()
         check(self.ctx.lib.ocn_grid_create(self.ctx.h, C.byref(d), C.byref(self.h)), self.ctx.h)
-        self.Nx, self.Ny, self.Nz = (d.N[0], d.N[1], 1 if topo[2] == Flat else d.N[2])
+        self.Nx, self.Ny, self.Nz = (1 if topo[a] == Flat else d.N[a] for a in range(3))
         self.Lx, self.Ly, self.Lz = d.L[0], d.L[1], d.L[2]
 
     @property
@@ -221,6 +221,13 @@ class FieldView:
     @property
     def device_ptr(self):
         return self.m.lib.ocn_field_device_ptr(self.m.h, self.id)
+
+    @property
+    def layout(self):
+        """(element strides, element offset of the parent's first entry) of the device array."""
+        st, org = (C.c_int64 * 3)(), C.c_int64()
+        check(self.m.lib.ocn_field_layout(self.m.h, self.id, C.byref(st), C.byref(org)), self.m.ctx.h)
+        return tuple(st), org.value
 
 
 class NonhydrostaticModel:
@@ -286,8 +293,10 @@ class NonhydrostaticModel:
                     b.value = float(bc.condition)
                 else:
                     arr = np.asfortranarray(bc.condition, dtype=np.float64)
-                    if arr.shape != (grid.Nx, grid.Ny):
-                        raise ValueError("array boundary conditions must have shape (Nx, Ny)")
+                    # arrays span the interior of the two directions tangential to the boundary
+                    tang = tuple(n for a, n in enumerate(grid.N) if a != _SIDES[side] // 2)
+                    if arr.shape != tang:
+                        raise ValueError(f"array boundary condition on side {side} must have shape {tang}")
                     self._keep.append(arr)
                     b.array = arr.ctypes.data_as(C.POINTER(C.c_double))
         self.desc = d
@@ -327,9 +336,14 @@ class NonhydrostaticModel:
         g = self.grid
         d = g.desc
         dx, dy = d.L[0] / g.Nx, d.L[1] / g.Ny
-        xF = d.x0[0] + dx * np.arange(g.Nx)
-        yF = d.x0[1] + dy * np.arange(g.Ny)
-        xC, yC = xF + dx / 2, yF + dy / 2
+        xC = d.x0[0] + dx * (np.arange(g.Nx) + 0.5)
+        yC = d.x0[1] + dy * (np.arange(g.Ny) + 0.5)
+        xF = d.x0[0] + dx * np.arange(g.Nx + 1 if g.topo[0] == Bounded else g.Nx)
+        yF = d.x0[1] + dy * np.arange(g.Ny + 1 if g.topo[1] == Bounded else g.Ny)
+        if g.topo[0] == Flat:
+            xF = xC = np.ones(1)
+        if g.topo[1] == Flat:
+            yF = yC = np.ones(1)
         if g.topo[2] == Flat:
             zF = zC = np.ones(1)
         elif g._zfaces is not None:

@@ -168,9 +168,15 @@ static int grid_build_dev(ocn_grid* g) {
   GridDev& d = g->dev;
   memset(&d, 0, sizeof(d));
   d.Nx = g->N[0]; d.Ny = g->N[1]; d.Nz = g->N[2];
-  d.Hx = g->H[0]; d.Hy = g->H[1]; d.Hz = g->H[2];
-  d.sy = d.Nx + 2 * d.Hx;
-  d.sz = d.sy * (d.Ny + 2 * d.Hy);
+  // Flat x / y: one cell stored with as many broadcast halo cells as the widest real halo
+  int hmax = 1;
+  for (int q = 0; q < 3; ++q) hmax = g->H[q] > hmax ? g->H[q] : hmax;
+  for (int q = 0; q < 3; ++q) g->PH[q] = (q < 2 && g->topo[q] == OCN_FLAT) ? hmax : g->H[q];
+  d.Hx = g->PH[0]; d.Hy = g->PH[1]; d.Hz = g->PH[2];
+  d.xb = g->topo[0] == OCN_BOUNDED;
+  d.yb = g->topo[1] == OCN_BOUNDED;
+  d.sy = d.Nx + 2 * d.Hx + d.xb;                 // one pitch for Face- and Center-located fields
+  d.sz = d.sy * (d.Ny + 2 * d.Hy + d.yb);
   // regular axes: L/N (grid_generation.jl:84; the reference rounds a BigFloat quotient once)
   d.dx = (double)((long double)g->L[0] / g->N[0]);
   d.dy = (double)((long double)g->L[1] / g->N[1]);
@@ -203,11 +209,6 @@ int ocn_grid_create(ocn_ctx* ctx, const ocn_grid_desc* desc, ocn_grid** out) {
     }
     if (desc->topology[d] < OCN_PERIODIC || desc->topology[d] > OCN_FLAT) return OCN_EINVAL;
   }
-  if (desc->topology[0] != OCN_PERIODIC || desc->topology[1] != OCN_PERIODIC) {
-    ocn_set_error(ctx, "only (Periodic, Periodic, *) topologies are supported: Bounded/Flat x or y needs the "
-                       "cosine-transform solver (SURVEY section 8f, rank 2)");
-    return OCN_EUNSUPPORTED;
-  }
   ocn_grid* g = new ocn_grid;
   g->ctx = ctx;
   g->d = *desc;
@@ -218,11 +219,12 @@ int ocn_grid_create(ocn_ctx* ctx, const ocn_grid_desc* desc, ocn_grid** out) {
     g->L[d] = desc->L[d];
     g->x0[d] = desc->x0[d];
   }
-  if (g->topo[2] == OCN_FLAT) {
-    g->N[2] = 1;
-    g->H[2] = 0;
-    g->L[2] = 1.0;
-  }
+  for (int d = 0; d < 3; ++d)
+    if (g->topo[d] == OCN_FLAT) {   // Grids/grid_utils.jl: Flat directions have one cell, no halo, unit spacing
+      g->N[d] = 1;
+      g->H[d] = 0;
+      g->L[d] = 1.0;
+    }
   g->z_regular = desc->z_faces == nullptr;
   if (!g->z_regular) {
     if (g->topo[2] == OCN_FLAT) return OCN_EINVAL;
@@ -245,12 +247,13 @@ int ocn_grid_create(ocn_ctx* ctx, const ocn_grid_desc* desc, ocn_grid** out) {
   g->Nzg = g->N[2];
   // OCNHIP_FORCE_DIST=1 exercises the slab code path (pack / z-plan / self exchange) on one rank, where eligible
   const bool forced = getenv("OCNHIP_FORCE_DIST") && atoi(getenv("OCNHIP_FORCE_DIST")) != 0 &&
-                      g->topo[2] == OCN_PERIODIC && g->z_regular && g->N[2] >= 6;
+                      g->topo[0] == OCN_PERIODIC && g->topo[1] == OCN_PERIODIC && g->topo[2] == OCN_PERIODIC &&
+                      g->z_regular && g->N[2] >= 6;
   g->dist = ctx->nranks > 1 || forced;
   if (g->dist) {
     // Distributed/multi_architectures.jl:20-47 -- here ranks = (1, 1, R): z-slabs of the global grid
-    if (g->topo[2] != OCN_PERIODIC || !g->z_regular) {
-      ocn_set_error(ctx, "slab decomposition needs a regular Periodic z direction (the reference's distributed "
+    if (g->topo[0] != OCN_PERIODIC || g->topo[1] != OCN_PERIODIC || g->topo[2] != OCN_PERIODIC || !g->z_regular) {
+      ocn_set_error(ctx, "slab decomposition needs a triply Periodic regular grid (the reference's distributed "
                          "solver is triply periodic too: distributed_fft_based_poisson_solver.jl)");
       delete g;
       return OCN_EUNSUPPORTED;
@@ -293,6 +296,7 @@ void ocn_grid_destroy(ocn_grid* g) {
 
 // ---- fields ---------------------------------------------------------------------------------------------------
 double* Field::interior() const { return d + Hx + Hy * sy + Hz * sz; }
+static bool field_dense(const Field& f) { return f.P[0] == f.T[0] && f.P[1] == f.T[1] && f.P[2] == f.T[2]; }
 
 static int field_alloc(ocn_model* m, Field& f, int lx, int ly, int lz) {
   ocn_grid* g = m->g;
@@ -302,11 +306,19 @@ static int field_alloc(ocn_model* m, Field& f, int lx, int ly, int lz) {
     if (g->topo[d] == OCN_FLAT) f.T[d] = g->N[d];
     else if (loc == OCN_FACE && g->topo[d] == OCN_BOUNDED) f.T[d] = g->N[d] + 1 + 2 * g->H[d];
     else f.T[d] = g->N[d] + 2 * g->H[d];
+    f.P[d] = f.T[d];
+    f.off[d] = 0;
+    if (d < 2 && g->topo[d] == OCN_FLAT) {
+      f.P[d] = 1 + 2 * g->PH[d];
+      f.off[d] = g->PH[d];
+    } else if (d < 2 && g->topo[d] == OCN_BOUNDED) {
+      f.P[d] = g->N[d] + 1 + 2 * g->H[d];
+    }
   }
-  f.n = (size_t)f.T[0] * f.T[1] * f.T[2];
-  f.sy = f.T[0];
-  f.sz = (long)f.T[0] * f.T[1];
-  f.Hx = g->H[0]; f.Hy = g->H[1]; f.Hz = g->H[2];
+  f.n = (size_t)f.P[0] * f.P[1] * f.P[2];
+  f.sy = f.P[0];
+  f.sz = (long)f.P[0] * f.P[1];
+  f.Hx = g->PH[0]; f.Hy = g->PH[1]; f.Hz = g->PH[2];
   OCN_HIP_CHECK(m->ctx, hipMalloc((void**)&f.d, f.n * sizeof(double)));
   OCN_HIP_CHECK(m->ctx, hipMemsetAsync(f.d, 0, f.n * sizeof(double), m->ctx->stream));
   f.present = true;
@@ -344,25 +356,52 @@ Field* model_field(ocn_model* m, int id) {
   return f;
 }
 
-// ---- halo fills (fill_halo_regions.jl:34-102): Bounded z first, then the periodic directions ------------
-static void fill_fields(ocn_model* m, Field** fs, int n) {
-  if (n == 0) return;
+// ---- halo fills (fill_halo_regions.jl:34-102) ---------------------------------------------------------------
+// Three passes in the order of permute_boundary_conditions (:55-83): sortperm of (west, south, bottom) with the
+// non-strict `fill_first` comparator (:91-99), i.e. Julia's insertion sort for three elements.  lt(a, b) is
+// false only when a is Periodic and b is not, so non-periodic directions come first and an all-equal triple
+// comes out reversed (z, y, x).
+static void fill_order(const ocn_grid* g, int order[3]) {
+  auto lt = [&](int a, int b) { return !(g->topo[a] == OCN_PERIODIC && g->topo[b] != OCN_PERIODIC); };
+  int v[3] = {0, 1, 2};
+  for (int i = 1; i < 3; ++i) {
+    int x = v[i], j = i;
+    while (j > 0 && lt(x, v[j - 1])) {
+      v[j] = v[j - 1];
+      --j;
+    }
+    v[j] = x;
+  }
+  for (int i = 0; i < 3; ++i) order[i] = v[i];
+}
+
+static int fill_fields(ocn_model* m, Field** fs, int n) {
+  if (n == 0) return OCN_OK;
   ProfScope ps(m->ctx, "fill_halos");
-  const GridDev& g = m->gd;
-  if (g.zb)
-    for (int i = 0; i < n; ++i) launch_fill_z_bounded(m, *fs[i]);
   FieldPtrs F;
   F.n = n;
   for (int i = 0; i < n; ++i) {
     F.p[i] = fs[i]->d;
+    F.Tx[i] = fs[i]->off[0] ? fs[i]->P[0] : fs[i]->T[0];
+    F.Ty[i] = fs[i]->off[1] ? fs[i]->P[1] : fs[i]->T[1];
     F.Tz[i] = fs[i]->T[2];
   }
-  // Julia's insertion sort with the non-strict `fill_first` comparator visits all-periodic directions in
-  // the order z, y, x; for periodic fills over full parent extents any order gives the same halos.
-  if (m->g->dist) comm_halo_exchange_z(m, fs, n);
-  else if (m->g->topo[2] == OCN_PERIODIC) launch_fill_periodic(m, F, 2);
-  launch_fill_periodic(m, F, 1);
-  launch_fill_periodic(m, F, 0);
+  int order[3], rc = OCN_OK;
+  fill_order(m->g, order);
+  for (int t = 0; t < 3; ++t) {
+    const int d = order[t];
+    if (m->g->topo[d] == OCN_BOUNDED) {
+      for (int i = 0; i < n; ++i) launch_fill_bounded(m, *fs[i], d);
+    } else if (m->g->topo[d] == OCN_PERIODIC) {
+      if (d == 2 && m->g->dist) rc = comm_halo_exchange_z(m, fs, n);
+      else launch_fill_periodic(m, F, d);
+      if (rc) return rc;
+    }
+  }
+  // Flat x / y: refresh the broadcast copies last, over the full extent of the other directions
+  for (int d = 0; d < 2; ++d)
+    if (m->g->topo[d] == OCN_FLAT) launch_fill_flat(m, F, d);
+  return OCN_OK;
 }
 
 static void fill_velocities_tracers(ocn_model* m, bool tracers) {
@@ -508,8 +547,8 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
   ocn_ctx* ctx = g->ctx;
   if (desc->n_tracers < 0 || desc->n_tracers > OCN_MAX_TRACERS) return OCN_EINVAL;
   if (desc->advection < OCN_ADV_NONE || desc->advection > OCN_ADV_WENO5_JS) return OCN_EINVAL;
-  if (desc->closure == OCN_CLOSURE_AMD && g->topo[2] == OCN_FLAT) {
-    ocn_set_error(ctx, "AnisotropicMinimumDissipation on a Flat z direction is outside the path");
+  if (desc->closure == OCN_CLOSURE_AMD && (g->topo[0] == OCN_FLAT || g->topo[1] == OCN_FLAT || g->topo[2] == OCN_FLAT)) {
+    ocn_set_error(ctx, "AnisotropicMinimumDissipation on a grid with a Flat direction is outside the path");
     return OCN_EUNSUPPORTED;
   }
   // halo inflation (nonhydrostatic_model.jl:140-148; Advection.jl:40)
@@ -563,7 +602,7 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
     default_bcs(m, m->nu_e, true);
     for (int t = 0; t < m->nt; ++t) default_bcs(m, m->kappa_e[t], true);
   }
-  // user boundary conditions (only z sides can be non-periodic here)
+  // user boundary conditions
   for (int f = 0; f < 3 + m->nt; ++f) {
     Field* fld = f == 0 ? &m->u : f == 1 ? &m->v : f == 2 ? &m->w : &m->tr[f - 3];
     for (int s = 0; s < 6; ++s) {
@@ -578,7 +617,8 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
       }
       BCdev bd{b.kind, b.value, nullptr};
       if (b.array) {
-        size_t nn = (size_t)g->N[0] * g->N[1];
+        // arrays span the two other directions' interior sizes (boundary_condition.jl getbc for arrays)
+        size_t nn = dim == 0 ? (size_t)g->N[1] * g->N[2] : dim == 1 ? (size_t)g->N[0] * g->N[2] : (size_t)g->N[0] * g->N[1];
         double* dptr = nullptr;
         if (hipMalloc((void**)&dptr, nn * sizeof(double)) != hipSuccess) {
           ocn_model_destroy(m);
@@ -664,12 +704,54 @@ void* ocn_field_device_ptr(ocn_model* m, int field_id) {
   return f ? f->d : nullptr;
 }
 
+// logical parent (column-major T[0] x T[1] x T[2]) <-> physical array.  A Flat x / y direction has one logical
+// index, stored in every physical slot of that direction.
+static void host_scatter(const Field& f, const double* logical, const int lo[3], const int ext[3], std::vector<double>& phys) {
+  // writes the logical box [lo, lo+ext) (box-local column-major input) into the physical buffer
+  for (int c = 0; c < ext[2]; ++c)
+    for (int b = 0; b < ext[1]; ++b)
+      for (int a = 0; a < ext[0]; ++a) {
+        const double val = logical[a + (size_t)ext[0] * (b + (size_t)ext[1] * c)];
+        const int x0 = f.off[0] ? 0 : lo[0] + a, x1 = f.off[0] ? f.P[0] : x0 + 1;
+        const int y0 = f.off[1] ? 0 : lo[1] + b, y1 = f.off[1] ? f.P[1] : y0 + 1;
+        for (int y = y0; y < y1; ++y)
+          for (int x = x0; x < x1; ++x) phys[x + (size_t)y * f.sy + (size_t)(lo[2] + c) * f.sz] = val;
+      }
+}
+static void host_gather(const Field& f, const std::vector<double>& phys, const int lo[3], const int ext[3], double* logical) {
+  for (int c = 0; c < ext[2]; ++c)
+    for (int b = 0; b < ext[1]; ++b)
+      for (int a = 0; a < ext[0]; ++a)
+        logical[a + (size_t)ext[0] * (b + (size_t)ext[1] * c)] =
+            phys[(f.off[0] + lo[0] + a) + (size_t)(f.off[1] + lo[1] + b) * f.sy + (size_t)(lo[2] + c) * f.sz];
+}
+
+int ocn_field_layout(const ocn_model* m, int field_id, int64_t strides[3], int64_t* origin) {
+  Field* f = model_field(const_cast<ocn_model*>(m), field_id);
+  if (!f) return OCN_EINVAL;
+  if (strides) {
+    strides[0] = 1;
+    strides[1] = f->sy;
+    strides[2] = f->sz;
+  }
+  if (origin) *origin = f->off[0] + (int64_t)f->off[1] * f->sy;
+  return OCN_OK;
+}
+
 int ocn_field_upload(ocn_model* m, int field_id, const double* host) {
   if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF) m->gn_alias_gm = false;
   Field* f = model_field(m, field_id);
   if (!f || !host) return OCN_EINVAL;
   OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));
-  OCN_HIP_CHECK(m->ctx, hipMemcpy(f->d, host, f->n * sizeof(double), hipMemcpyHostToDevice));
+  if (field_dense(*f)) {
+    OCN_HIP_CHECK(m->ctx, hipMemcpy(f->d, host, f->n * sizeof(double), hipMemcpyHostToDevice));
+    return OCN_OK;
+  }
+  std::vector<double> phys(f->n);
+  OCN_HIP_CHECK(m->ctx, hipMemcpy(phys.data(), f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
+  const int lo[3] = {0, 0, 0};
+  host_scatter(*f, host, lo, f->T, phys);
+  OCN_HIP_CHECK(m->ctx, hipMemcpy(f->d, phys.data(), f->n * sizeof(double), hipMemcpyHostToDevice));
   return OCN_OK;
 }
 
@@ -677,23 +759,30 @@ int ocn_field_download(const ocn_model* m, int field_id, double* host) {
   Field* f = model_field(const_cast<ocn_model*>(m), field_id);
   if (!f || !host) return OCN_EINVAL;
   OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));
-  OCN_HIP_CHECK(m->ctx, hipMemcpy(host, f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
+  if (field_dense(*f)) {
+    OCN_HIP_CHECK(m->ctx, hipMemcpy(host, f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
+    return OCN_OK;
+  }
+  std::vector<double> phys(f->n);
+  OCN_HIP_CHECK(m->ctx, hipMemcpy(phys.data(), f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
+  const int lo[3] = {0, 0, 0};
+  host_gather(*f, phys, lo, f->T, host);
   return OCN_OK;
 }
 
 int ocn_field_set_interior(ocn_model* m, int field_id, const double* host) {
+  if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF) m->gn_alias_gm = false;
   Field* f = model_field(m, field_id);
   if (!f || !host) return OCN_EINVAL;
   int32_t it[3];
   ocn_field_shape(m, field_id, nullptr, it, nullptr);
-  std::vector<double> buf(f->n);
-  int rc = ocn_field_download(m, field_id, buf.data());
-  if (rc) return rc;
-  for (int k = 0; k < it[2]; ++k)
-    for (int j = 0; j < it[1]; ++j)
-      memcpy(&buf[f->Hx + (size_t)(j + f->Hy) * f->sy + (size_t)(k + f->Hz) * f->sz],
-             &host[(size_t)it[0] * (j + (size_t)it[1] * k)], it[0] * sizeof(double));
-  return ocn_field_upload(m, field_id, buf.data());
+  OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));
+  std::vector<double> phys(f->n);
+  OCN_HIP_CHECK(m->ctx, hipMemcpy(phys.data(), f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
+  const int lo[3] = {m->g->H[0], m->g->H[1], m->g->H[2]}, ext[3] = {it[0], it[1], it[2]};
+  host_scatter(*f, host, lo, ext, phys);
+  OCN_HIP_CHECK(m->ctx, hipMemcpy(f->d, phys.data(), f->n * sizeof(double), hipMemcpyHostToDevice));
+  return OCN_OK;
 }
 
 int ocn_field_get_interior(const ocn_model* m, int field_id, double* host) {
@@ -701,13 +790,11 @@ int ocn_field_get_interior(const ocn_model* m, int field_id, double* host) {
   if (!f || !host) return OCN_EINVAL;
   int32_t it[3];
   ocn_field_shape(m, field_id, nullptr, it, nullptr);
-  std::vector<double> buf(f->n);
-  int rc = ocn_field_download(m, field_id, buf.data());
-  if (rc) return rc;
-  for (int k = 0; k < it[2]; ++k)
-    for (int j = 0; j < it[1]; ++j)
-      memcpy(&host[(size_t)it[0] * (j + (size_t)it[1] * k)],
-             &buf[f->Hx + (size_t)(j + f->Hy) * f->sy + (size_t)(k + f->Hz) * f->sz], it[0] * sizeof(double));
+  OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));
+  std::vector<double> phys(f->n);
+  OCN_HIP_CHECK(m->ctx, hipMemcpy(phys.data(), f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
+  const int lo[3] = {m->g->H[0], m->g->H[1], m->g->H[2]}, ext[3] = {it[0], it[1], it[2]};
+  host_gather(*f, phys, lo, ext, host);
   return OCN_OK;
 }
 

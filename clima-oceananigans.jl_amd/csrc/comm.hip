@@ -110,17 +110,32 @@ int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vecto
     g_world.sends[c->rank] = sends;
   }
   g_world.barrier();
+  // RCCL has no tags: the k-th send of rank a to rank b pairs with the k-th receive b posts from a.  The
+  // mailbox pairs messages the same way and then insists that tag and size agree, so an ordering mistake
+  // that RCCL would turn into silently swapped buffers fails here.
+  std::vector<int> taken(c->nranks, 0);
   for (const CommOp& r : recvs) {
     if (r.peer == c->rank) continue;
-    bool found = false;
-    for (const CommOp& s : g_world.sends[r.peer])
-      if (s.peer == c->rank && s.tag == r.tag) {
-        memcpy(r.buf, s.buf, r.bytes);
-        found = true;
-        break;
-      }
-    if (!found) {
-      ocn_set_error(c, "emu comm: unmatched receive (peer %d tag %d)", r.peer, r.tag);
+    const std::vector<CommOp>& from = g_world.sends[r.peer];
+    int seen = 0;
+    const CommOp* match = nullptr;
+    for (const CommOp& s : from)
+      if (s.peer == c->rank && seen++ == taken[r.peer]) { match = &s; break; }
+    ++taken[r.peer];
+    if (!match || match->tag != r.tag || match->bytes != r.bytes) {
+      ocn_set_error(c, "emu comm: receive #%d from rank %d (tag %d, %zu B) pairs with %s (tag %d, %zu B)",
+                    taken[r.peer] - 1, r.peer, r.tag, r.bytes, match ? "send" : "nothing",
+                    match ? match->tag : -1, match ? match->bytes : (size_t)0);
+      return OCN_ESTATE;
+    }
+    memcpy(r.buf, match->buf, r.bytes);
+  }
+  for (int p = 0; p < c->nranks; ++p) {
+    if (p == c->rank) continue;
+    int posted = 0;
+    for (const CommOp& s : g_world.sends[p]) posted += (s.peer == c->rank);
+    if (posted != taken[p]) {
+      ocn_set_error(c, "emu comm: rank %d posted %d sends to rank %d, which receives %d", p, posted, c->rank, taken[p]);
       return OCN_ESTATE;
     }
   }

@@ -42,6 +42,7 @@ struct ocn_grid {
   bool dist = false;    // z-slab decomposition active (also forced with one rank by OCNHIP_FORCE_DIST=1)
   ocn_grid_desc d;
   int N[3], H[3], topo[3];
+  int PH[3];            // physical halo: H, except Flat x / y, which are stored with broadcast halos
   double L[3], x0[3];
   bool z_regular;
   std::vector<double> zF_int;            // interior faces (stretched)
@@ -57,11 +58,19 @@ struct BCdev {
   const double* arr;  // device (Nx*Ny) or null
 };
 
+// Device layout of a field.  T is the reference's parent size (Grids/new_data.jl:16-61); P the size actually
+// allocated.  They coincide unless x or y is Bounded or Flat: then every field of the model shares ONE pitch
+// (as hipMallocPitch would give) -- Nx+2H+1 columns when x is Bounded, so Face- and Center-located fields have
+// equal strides and one linear index addresses all of them -- and a Flat x / y direction is stored with
+// broadcast halos (every difference across it is exactly 0, every interpolation the identity, as the
+// reference's Flat operators).  ocn_field_layout() reports strides and origin; upload / download convert.
 struct Field {
   double* d = nullptr;  // parent array on the device
   int T[3] = {0, 0, 0};
+  int P[3] = {0, 0, 0};
+  int off[3] = {0, 0, 0};   // physical index of the logical parent's first element
   int loc[3] = {0, 0, 0};
-  size_t n = 0;
+  size_t n = 0;             // physical element count
   BCdev bc[6];
   bool present = false;
   double* interior() const;  // pointer to the first interior cell
@@ -100,11 +109,12 @@ Field* model_field(ocn_model* m, int id);
 // ---- kernels.hip ------------------------------------------------------------------------------------
 struct FieldPtrs {
   double* p[OCN_NF];
-  int Tz[OCN_NF];
+  int Tx[OCN_NF], Ty[OCN_NF], Tz[OCN_NF];   // extents the fill sweeps (the field's own parent extents)
   int n;
 };
 void launch_fill_periodic(ocn_model* m, const FieldPtrs& f, int dim);
-void launch_fill_z_bounded(ocn_model* m, Field& f);
+void launch_fill_flat(ocn_model* m, const FieldPtrs& f, int dim);
+void launch_fill_bounded(ocn_model* m, Field& f, int dim);
 void launch_tendencies(ocn_model* m);
 void launch_step(ocn_model* m, double dt, double cn, double cm, int use_m);
 void launch_store(ocn_model* m);

@@ -51,30 +51,40 @@ __global__ void k_tend_uvw(GridDev g, Phys ph, const double* __restrict__ u, con
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long sy = g.sy, sz = g.sz;
   const long c = i + j * sy + k * sz;
-  const int kk = k + 1;  // 1-based, as in the reference's boundary-buffer tests
-  const bool zb = g.zb != 0, zf = g.zflat != 0;
-  const int Nz = g.Nz, nb = g.nb;
+  const int ii = i + 1, jj = j + 1, kk = k + 1;  // 1-based, as in the reference's boundary-buffer tests
+  const bool xb = g.xb != 0, yb = g.yb != 0, zb = g.zb != 0, zf = g.zflat != 0;
+  const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz, nb = g.nb;
   const double rdx = g.rdx, rdy = g.rdy;
   const double rdzc = zf ? 0.0 : 1.0 / g_dzc(g, k);
   const double rdzf = zf ? 0.0 : 1.0 / g_dzf(g, k);
   double gu = 0, gv = 0, gw = 0;
 
   if (ADV != ADV_NONE) {
+    // Indices passed to the *_b helpers are the reference's 1-based index of the evaluation point along the
+    // stencil direction (topologically_conditional_interpolation.jl:46-79); ii/jj/kk are those of this cell.
     // ---- div_vu at fcc (momentum_advection_operators.jl:52-56) ----
-    auto Fuu = [&](long p) { return adv_flux<ADV>(u + p + 1, 1, sym_b<ADV>(u + p, 1, false, 0, 0, 0)); };
-    auto Fvu = [&](long p) { return adv_flux<ADV>(u + p, sy, sym_b<ADV>(v + p - 1, 1, false, 0, 0, 0)); };
-    auto Fwu = [&](long p, int k1) {
-      return adv_flux_b<ADV>(u + p, sz, sym_b<ADV>(w + p - 1, 1, false, 0, 0, 0), zb, k1, Nz, nb);
+    auto Fuu = [&](long p, int i1) {   // ccc
+      return adv_flux_b<ADV>(u + p + 1, 1, sym_b<ADV>(u + p, 1, xb, i1, Nx, nb), xb, i1, Nx, nb);
     };
-    gu -= (Fuu(c) - Fuu(c - 1)) * rdx + (Fvu(c + sy) - Fvu(c)) * rdy;
+    auto Fvu = [&](long p, int j1) {   // ffc
+      return adv_flux_b<ADV>(u + p, sy, sym_b<ADV>(v + p - 1, 1, xb, ii, Nx, nb), yb, j1, Ny, nb);
+    };
+    auto Fwu = [&](long p, int k1) {   // fcf
+      return adv_flux_b<ADV>(u + p, sz, sym_b<ADV>(w + p - 1, 1, xb, ii, Nx, nb), zb, k1, Nz, nb);
+    };
+    gu -= (Fuu(c, ii) - Fuu(c - 1, ii - 1)) * rdx + (Fvu(c + sy, jj + 1) - Fvu(c, jj)) * rdy;
     if (!zf) gu -= (Fwu(c + sz, kk + 1) - Fwu(c, kk)) * rdzc;
     // ---- div_vv at cfc (:68-72) ----
-    auto Fuv = [&](long p) { return adv_flux<ADV>(v + p, 1, sym_b<ADV>(u + p - sy, sy, false, 0, 0, 0)); };
-    auto Fvv = [&](long p) { return adv_flux<ADV>(v + p + sy, sy, sym_b<ADV>(v + p, sy, false, 0, 0, 0)); };
-    auto Fwv = [&](long p, int k1) {
-      return adv_flux_b<ADV>(v + p, sz, sym_b<ADV>(w + p - sy, sy, false, 0, 0, 0), zb, k1, Nz, nb);
+    auto Fuv = [&](long p, int i1) {   // ffc
+      return adv_flux_b<ADV>(v + p, 1, sym_b<ADV>(u + p - sy, sy, yb, jj, Ny, nb), xb, i1, Nx, nb);
     };
-    gv -= (Fuv(c + 1) - Fuv(c)) * rdx + (Fvv(c) - Fvv(c - sy)) * rdy;
+    auto Fvv = [&](long p, int j1) {   // ccc
+      return adv_flux_b<ADV>(v + p + sy, sy, sym_b<ADV>(v + p, sy, yb, j1, Ny, nb), yb, j1, Ny, nb);
+    };
+    auto Fwv = [&](long p, int k1) {   // cff
+      return adv_flux_b<ADV>(v + p, sz, sym_b<ADV>(w + p - sy, sy, yb, jj, Ny, nb), zb, k1, Nz, nb);
+    };
+    gv -= (Fuv(c + 1, ii + 1) - Fuv(c, ii)) * rdx + (Fvv(c, jj) - Fvv(c - sy, jj - 1)) * rdy;
     if (!zf) gv -= (Fwv(c + sz, kk + 1) - Fwv(c, kk)) * rdzc;
     // ---- div_vw at ccf (:82-86) ----
     // advecting u, v interpolated in z to the w level.  CenteredSecondOrder interpolates the
@@ -84,9 +94,9 @@ __global__ void k_tend_uvw(GridDev g, Phys ph, const double* __restrict__ u, con
       if (ADV == ADV_C2 && g.dzc) return 0.5 * (g_dzc(g, k - 1) * q[p - sz] + g_dzc(g, k) * q[p]) * rdzf;
       return sym_b<ADV>(q + p - sz, sz, zb, kk, Nz, nb);
     };
-    auto Fuw = [&](long p) { return adv_flux<ADV>(w + p, 1, uz(u, p)); };
-    auto Fvw = [&](long p) { return adv_flux<ADV>(w + p, sy, uz(v, p)); };
-    gw -= (Fuw(c + 1) - Fuw(c)) * rdx + (Fvw(c + sy) - Fvw(c)) * rdy;
+    auto Fuw = [&](long p, int i1) { return adv_flux_b<ADV>(w + p, 1, uz(u, p), xb, i1, Nx, nb); };    // fcf
+    auto Fvw = [&](long p, int j1) { return adv_flux_b<ADV>(w + p, sy, uz(v, p), yb, j1, Ny, nb); };   // cff
+    gw -= (Fuw(c + 1, ii + 1) - Fuw(c, ii)) * rdx + (Fvw(c + sy, jj + 1) - Fvw(c, jj)) * rdy;
     if (!zf) {
       auto Fww = [&](long p, int k1) {
         return adv_flux_b<ADV>(w + p + sz, sz, sym_b<ADV>(w + p, sz, zb, k1, Nz, nb), zb, k1, Nz, nb);
@@ -150,9 +160,9 @@ __global__ void k_tend_c(GridDev g, const double* __restrict__ u, const double* 
   double gc = 0;
   if (ADV != ADV_NONE) {
     // tracer_advection_operators.jl:31-35; advecting velocity un-interpolated
-    auto Fx = [&](long p) { return adv_flux<ADV>(q + p, 1, u[p]); };
-    auto Fy = [&](long p) { return adv_flux<ADV>(q + p, sy, v[p]); };
-    gc -= (Fx(c + 1) - Fx(c)) * rdx + (Fy(c + sy) - Fy(c)) * rdy;
+    auto Fx = [&](long p, int i1) { return adv_flux_b<ADV>(q + p, 1, u[p], g.xb != 0, i1, g.Nx, g.nb); };
+    auto Fy = [&](long p, int j1) { return adv_flux_b<ADV>(q + p, sy, v[p], g.yb != 0, j1, g.Ny, g.nb); };
+    gc -= (Fx(c + 1, i + 2) - Fx(c, i + 1)) * rdx + (Fy(c + sy, j + 2) - Fy(c, j + 1)) * rdy;
     if (!zf) {
       auto Fz = [&](long p, int k1) { return adv_flux_b<ADV>(q + p, sz, w[p], zb, k1, g.Nz, g.nb); };
       gc -= (Fz(c + sz, kk + 1) - Fz(c, kk)) * rdzc;
@@ -172,22 +182,30 @@ __global__ void k_tend_c(GridDev g, const double* __restrict__ u, const double* 
   Gc[c] = gc;
 }
 
-// ---- flux boundary conditions at bottom / top (apply_flux_bcs.jl:125-160) ---------------------------
-__global__ void k_apply_z_flux(GridDev g, double* __restrict__ G, int zloc_face, BCdev bot, BCdev top) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny) return;
-  const long c = i + j * g.sy;
-  if (bot.kind == OCN_BC_FLUX) {
-    double val = bot.arr ? bot.arr[i + (long)j * g.Nx] : bot.value;
-    double dzv = zloc_face ? g_dzf(g, 0) : g_dzc(g, 0);
-    G[c] += val / dzv;
+// ---- flux boundary conditions (apply_flux_bcs.jl:111-160): G[1] += flux * A / V, G[N] -= flux * A / V ------------
+// dim: direction normal to the boundary; threads span the two other directions' interior (:xy / :xz / :yz).
+__global__ void k_apply_flux(GridDev g, double* __restrict__ G, int dim, int zloc_face, BCdev lo, BCdev hi) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y * blockDim.y + threadIdx.y;
+  const int Na = dim == 0 ? g.Ny : g.Nx, Nb = dim == 2 ? g.Ny : g.Nz;
+  if (a >= Na || b >= Nb) return;
+  long c, st;
+  int N;
+  if (dim == 0) { c = a * g.sy + b * g.sz; st = 1; N = g.Nx; }
+  else if (dim == 1) { c = a + b * g.sz; st = g.sy; N = g.Ny; }
+  else { c = a + b * g.sy; st = g.sz; N = g.Nz; }
+  auto rspacing = [&](int idx) -> double {   // A / V at the first / last interior point
+    if (dim == 0) return g.rdx;
+    if (dim == 1) return g.rdy;
+    return 1.0 / (zloc_face ? g_dzf(g, idx) : g_dzc(g, idx));
+  };
+  if (lo.kind == OCN_BC_FLUX) {
+    double val = lo.arr ? lo.arr[a + (long)b * Na] : lo.value;
+    G[c] += val * rspacing(0);
   }
-  if (top.kind == OCN_BC_FLUX) {
-    double val = top.arr ? top.arr[i + (long)j * g.Nx] : top.value;
-    int kt = g.Nz - 1;
-    double dzv = zloc_face ? g_dzf(g, kt) : g_dzc(g, kt);
-    G[c + kt * g.sz] -= val / dzv;
+  if (hi.kind == OCN_BC_FLUX) {
+    double val = hi.arr ? hi.arr[a + (long)b * Na] : hi.value;
+    G[c + (N - 1) * st] -= val * rspacing(N - 1);
   }
 }
 
@@ -223,19 +241,21 @@ void launch_tendencies(ocn_model* m) {
     TEND_CASE(ADV_WENO_JS)
   }
 #undef TEND_CASE
-  // boundary contributions: only z can be Bounded here
-  if (g.zb) {
-    dim3 b2(64, 4, 1), g2((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
+  // boundary contributions in every Bounded direction
+  for (int dim = 0; dim < 3; ++dim) {
+    if (m->g->topo[dim] != OCN_BOUNDED) continue;
+    const int Na = dim == 0 ? g.Ny : g.Nx, Nb = dim == 2 ? g.Ny : g.Nz;
+    dim3 b2(64, 4, 1), g2((Na + 63) / 64, (Nb + 3) / 4, 1);
     for (int f = 0; f < 3 + m->nt; ++f) {
       Field* fld = f == 0 ? &m->u : f == 1 ? &m->v : f == 2 ? &m->w : &m->tr[f - 3];
-      const BCdev &bot = fld->bc[OCN_BOTTOM], &top = fld->bc[OCN_TOP];
-      bool nb = bot.kind == OCN_BC_FLUX && (bot.arr || bot.value != 0.0);
-      bool nt = top.kind == OCN_BC_FLUX && (top.arr || top.value != 0.0);
-      if (!nb && !nt) continue;
-      BCdev b_ = bot, t_ = top;
-      if (!nb) b_.kind = OCN_BC_NOFLUX;
-      if (!nt) t_.kind = OCN_BC_NOFLUX;
-      ocn_launch(k_apply_z_flux, g2, b2, s, g, m->Gn[f].interior(), fld->loc[2], b_, t_);
+      const BCdev &lo = fld->bc[2 * dim], &hi = fld->bc[2 * dim + 1];
+      bool nl = lo.kind == OCN_BC_FLUX && (lo.arr || lo.value != 0.0);
+      bool nh = hi.kind == OCN_BC_FLUX && (hi.arr || hi.value != 0.0);
+      if (!nl && !nh) continue;
+      BCdev l_ = lo, h_ = hi;
+      if (!nl) l_.kind = OCN_BC_NOFLUX;
+      if (!nh) h_.kind = OCN_BC_NOFLUX;
+      ocn_launch(k_apply_flux, g2, b2, s, g, m->Gn[f].interior(), dim, fld->loc[2], l_, h_);
     }
   }
 }
@@ -306,13 +326,12 @@ void launch_store(ocn_model* m) {
 // ---- halo fills ------------------------------------------------------------------------------------------
 // Periodic: exact restatement of fill_halo_regions_periodic.jl:37-65 on the *parent* array, sequential in
 // the halo index (matters when N < H), launched over the full parent extent of the other two dims.
-__global__ void k_fill_periodic(FieldPtrs F, int dim, int N, int H, int Tx, int Ty) {
+__global__ void k_fill_periodic(FieldPtrs F, int dim, int N, int H, long sy, long sz) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y * blockDim.y + threadIdx.y;
   const int f = blockIdx.z;
-  const int Tz = F.Tz[f];
+  const int Tx = F.Tx[f], Ty = F.Ty[f], Tz = F.Tz[f];
   double* p = F.p[f];
-  const long sy = Tx, sz = (long)Tx * Ty;
   long base, st;
   if (dim == 0) {  // a: y, b: z
     if (a >= Ty || b >= Tz) return;
@@ -333,58 +352,107 @@ __global__ void k_fill_periodic(FieldPtrs F, int dim, int N, int H, int Tx, int 
   }
 }
 
+static void fill_launch_shape(const FieldPtrs& F, int dim, dim3& b, dim3& gr) {
+  int Tx = 0, Ty = 0, Tz = 0;
+  for (int f = 0; f < F.n; ++f) {
+    Tx = F.Tx[f] > Tx ? F.Tx[f] : Tx;
+    Ty = F.Ty[f] > Ty ? F.Ty[f] : Ty;
+    Tz = F.Tz[f] > Tz ? F.Tz[f] : Tz;
+  }
+  int na = dim == 0 ? Ty : Tx;
+  int nbb = dim == 2 ? Ty : Tz;
+  b = dim3(dim == 0 ? 8 : 64, dim == 0 ? 32 : 4, 1);
+  gr = dim3((na + b.x - 1) / b.x, (nbb + b.y - 1) / b.y, F.n);
+}
+
 void launch_fill_periodic(ocn_model* m, const FieldPtrs& F, int dim) {
   const GridDev& g = m->gd;
-  int Tx = g.Nx + 2 * g.Hx, Ty = g.Ny + 2 * g.Hy;
   int N = dim == 0 ? g.Nx : dim == 1 ? g.Ny : g.Nz;
   int H = dim == 0 ? g.Hx : dim == 1 ? g.Hy : g.Hz;
   if (H == 0) return;
-  int Tzmax = 0;
-  for (int f = 0; f < F.n; ++f) Tzmax = F.Tz[f] > Tzmax ? F.Tz[f] : Tzmax;
-  int na = dim == 0 ? Ty : Tx;
-  int nbb = dim == 2 ? Ty : Tzmax;
-  dim3 b(dim == 0 ? 8 : 64, dim == 0 ? 32 : 4, 1);
-  dim3 gr((na + b.x - 1) / b.x, (nbb + b.y - 1) / b.y, F.n);
-  ocn_launch(k_fill_periodic, gr, b, m->ctx->stream, F, dim, N, H, Tx, Ty);
+  dim3 b, gr;
+  fill_launch_shape(F, dim, b, gr);
+  ocn_launch(k_fill_periodic, gr, b, m->ctx->stream, F, dim, N, H, g.sy, g.sz);
 }
 
-// Bounded z: one halo cell per side (fill_halo_regions_flux.jl:16-35, ..value_gradient.jl:81-99, ..open.jl:34-39)
-__global__ void k_fill_z_bounded(GridDev g, double* __restrict__ p, int face, BCdev bot, BCdev top) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= g.Nx || j >= g.Ny) return;
-  const long c = i + j * g.sy, sz = g.sz;
-  const int Nz = g.Nz;
-  // bottom
-  {
-    double val = bot.arr ? bot.arr[i + (long)j * g.Nx] : bot.value;
-    if (bot.kind == OCN_BC_NOFLUX || bot.kind == OCN_BC_FLUX) p[c - sz] = p[c];
-    else if (bot.kind == OCN_BC_IMPENETRABLE) p[c] = val;
-    else if (bot.kind == OCN_BC_VALUE || bot.kind == OCN_BC_GRADIENT) {
-      double D = face ? g_dzc(g, 0) : g_dzf(g, 0);   // spacing at flip(loc), index 1 (1-based)
-      double cI = p[c];
-      double grad = bot.kind == OCN_BC_GRADIENT ? val : (cI - val) / (D / 2);
-      p[c - sz] = cI + grad * (-D);
-    }
+// Flat x / y: every physical slot along the direction holds the single logical value
+__global__ void k_fill_flat(FieldPtrs F, int dim, int H, long sy, long sz) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y * blockDim.y + threadIdx.y;
+  const int f = blockIdx.z;
+  const int Tx = F.Tx[f], Ty = F.Ty[f], Tz = F.Tz[f];
+  double* p = F.p[f];
+  long base, st;
+  if (dim == 0) {
+    if (a >= Ty || b >= Tz) return;
+    base = a * sy + b * sz;
+    st = 1;
+  } else {
+    if (a >= Tx || b >= Tz) return;
+    base = a + b * sz;
+    st = sy;
   }
-  // top
-  {
-    double val = top.arr ? top.arr[i + (long)j * g.Nx] : top.value;
-    if (top.kind == OCN_BC_NOFLUX || top.kind == OCN_BC_FLUX) p[c + Nz * sz] = p[c + (Nz - 1) * sz];
-    else if (top.kind == OCN_BC_IMPENETRABLE) p[c + Nz * sz] = val;
-    else if (top.kind == OCN_BC_VALUE || top.kind == OCN_BC_GRADIENT) {
-      double D = face ? g_dzc(g, Nz) : g_dzf(g, Nz);  // index Nz+1 (1-based)
-      double cI = p[c + (Nz - 1) * sz];
-      double grad = top.kind == OCN_BC_GRADIENT ? val : (val - cI) / (D / 2);
-      p[c + Nz * sz] = cI + grad * D;
-    }
-  }
+  const double val = p[base + H * st];
+  for (int i = 0; i < 2 * H + 1; ++i)
+    if (i != H) p[base + i * st] = val;
 }
 
-void launch_fill_z_bounded(ocn_model* m, Field& f) {
+void launch_fill_flat(ocn_model* m, const FieldPtrs& F, int dim) {
   const GridDev& g = m->gd;
-  dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
-  ocn_launch(k_fill_z_bounded, gr, b, m->ctx->stream, g, f.interior(), f.loc[2], f.bc[OCN_BOTTOM], f.bc[OCN_TOP]);
+  int H = dim == 0 ? g.Hx : g.Hy;
+  if (H == 0) return;
+  dim3 b, gr;
+  fill_launch_shape(F, dim, b, gr);
+  ocn_launch(k_fill_flat, gr, b, m->ctx->stream, F, dim, H, g.sy, g.sz);
+}
+
+// Bounded directions: one halo cell per side (fill_halo_regions_flux.jl:16-35, ..value_gradient.jl:7-99,
+// ..open.jl:34-39), launched over the two other directions' *centre* sizes (:yz / :xz / :xy).
+__global__ void k_fill_bounded(GridDev g, double* __restrict__ p, int dim, int face, BCdev lo, BCdev hi) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y * blockDim.y + threadIdx.y;
+  const int Na = dim == 0 ? g.Ny : g.Nx, Nb = dim == 2 ? g.Ny : g.Nz;
+  if (a >= Na || b >= Nb) return;
+  long c, st;
+  int N;
+  if (dim == 0) { c = a * g.sy + b * g.sz; st = 1; N = g.Nx; }
+  else if (dim == 1) { c = a + b * g.sz; st = g.sy; N = g.Ny; }
+  else { c = a + b * g.sy; st = g.sz; N = g.Nz; }
+  // spacing between the first interior and the first halo point: at flip(loc), index 1 / N+1 (1-based)
+  auto spacing = [&](int idx) -> double {
+    if (dim == 0) return g.dx;
+    if (dim == 1) return g.dy;
+    return face ? g_dzc(g, idx) : g_dzf(g, idx);
+  };
+  {
+    double val = lo.arr ? lo.arr[a + (long)b * Na] : lo.value;
+    if (lo.kind == OCN_BC_NOFLUX || lo.kind == OCN_BC_FLUX) p[c - st] = p[c];
+    else if (lo.kind == OCN_BC_IMPENETRABLE) p[c] = val;
+    else if (lo.kind == OCN_BC_VALUE || lo.kind == OCN_BC_GRADIENT) {
+      double D = spacing(0);
+      double cI = p[c];
+      double grad = lo.kind == OCN_BC_GRADIENT ? val : (cI - val) / (D / 2);
+      p[c - st] = cI + grad * (-D);
+    }
+  }
+  {
+    double val = hi.arr ? hi.arr[a + (long)b * Na] : hi.value;
+    if (hi.kind == OCN_BC_NOFLUX || hi.kind == OCN_BC_FLUX) p[c + N * st] = p[c + (N - 1) * st];
+    else if (hi.kind == OCN_BC_IMPENETRABLE) p[c + N * st] = val;
+    else if (hi.kind == OCN_BC_VALUE || hi.kind == OCN_BC_GRADIENT) {
+      double D = spacing(N);
+      double cI = p[c + (N - 1) * st];
+      double grad = hi.kind == OCN_BC_GRADIENT ? val : (val - cI) / (D / 2);
+      p[c + N * st] = cI + grad * D;
+    }
+  }
+}
+
+void launch_fill_bounded(ocn_model* m, Field& f, int dim) {
+  const GridDev& g = m->gd;
+  const int Na = dim == 0 ? g.Ny : g.Nx, Nb = dim == 2 ? g.Ny : g.Nz;
+  dim3 b(64, 4, 1), gr((Na + 63) / 64, (Nb + 3) / 4, 1);
+  ocn_launch(k_fill_bounded, gr, b, m->ctx->stream, g, f.interior(), dim, f.loc[dim], f.bc[2 * dim], f.bc[2 * dim + 1]);
 }
 
 // ---- Poisson right-hand side (solve_for_pressure.jl:15-18,30-33) ------------------------------------------

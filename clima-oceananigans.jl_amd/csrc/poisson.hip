@@ -21,7 +21,8 @@ struct double2_ {
 };
 
 struct PoissonSolver {
-  int kind;        // 0: 3-D FFT (z Periodic)   1: 2-D FFT (+ tridiagonal if z Bounded, plain divide if z Flat)
+  int kind;        // 4: Bounded / Flat x or y (dense cosine / Fourier transforms, see run_general)
+                   // 0: 3-D FFT (z Periodic)   1: 2-D FFT (+ tridiagonal if z Bounded, plain divide if z Flat)
                    // 2: z-slabs: 2-D FFT per plane, all-to-all to ky-slabs, 1-D FFT along z, and back
   int Nx, Ny, Nz, Nxh;
   int R = 1, rank = 0, Nzg = 0, Nyl = 0;   // slab decomposition
@@ -35,6 +36,9 @@ struct PoissonSolver {
   double2_* spec = nullptr;   // complex (Nxh,Ny,Nz)
   double* tscr = nullptr;     // Thomas scratch (Nxh*Ny, Nz)
   double *lx = nullptr, *ly = nullptr, *lz = nullptr;  // eigenvalues on the device
+  // kind 4 (any topology): dense transforms along x / y / z on the full complex array, ping-pong ga <-> gb
+  double2_ *ga = nullptr, *gb = nullptr;
+  double2_* gm[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // [axis][fwd / inv], null: identity
 #ifndef OCN_HOST_EMU
   hipfftHandle fwd = 0, inv = 0, zplan = 0, xinv = 0;
 #endif
@@ -52,6 +56,40 @@ static std::vector<double> eigenvalues_periodic(int N, double L) {
   return l;
 }
 
+static std::vector<double> eigenvalues(int topo, int N, double L) {
+  // poisson_eigenvalues.jl:8-31: Periodic (2 sin(pi i / N) / d)^2, Bounded (2 sin(pi i / 2N) / d)^2, Flat 0
+  if (topo == OCN_PERIODIC) return eigenvalues_periodic(N, L);
+  std::vector<double> l(N, 0.0);
+  if (topo == OCN_BOUNDED)
+    for (int i = 0; i < N; ++i) {
+      double s = 2.0 * sin(i * M_PI / (2.0 * N)) / (L / N);
+      l[i] = s * s;
+    }
+  return l;
+}
+
+// Transform matrices of one direction, stored input-major: M[n * N + k] maps input n to output k.
+//   Periodic: forward exp(-2 pi i k n / N), inverse exp(+2 pi i k n / N) / N            (discrete_transforms.jl:107-121)
+//   Bounded : forward cos(pi (n + 1/2) k / N)  (DCT-II), inverse (k == 0 ? 1 : 2) cos(pi (n + 1/2) k / N) / N
+//             (DCT-III); FFTW's REDFT10 / REDFT01 pair is 2x / 1x these and normalised by 1 / 2N (:140-161) --
+//             the composition with the eigenvalue division is identical.
+static void transform_matrices(int topo, int N, std::vector<double2_>& fwd, std::vector<double2_>& inv) {
+  fwd.assign((size_t)N * N, {0, 0});
+  inv.assign((size_t)N * N, {0, 0});
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < N; ++k) {
+      if (topo == OCN_PERIODIC) {
+        double ang = 2.0 * M_PI * (double)(((long)n * k) % N) / N;
+        fwd[(size_t)n * N + k] = {cos(ang), -sin(ang)};
+        inv[(size_t)k * N + n] = {cos(ang) / N, sin(ang) / N};   // input k (spectral) -> output n (physical)
+      } else {
+        double c = cos(M_PI * (n + 0.5) * k / N);
+        fwd[(size_t)n * N + k] = {c, 0.0};
+        inv[(size_t)k * N + n] = {(k == 0 ? 1.0 : 2.0) * c / N, 0.0};
+      }
+    }
+}
+
 static double* upload(const std::vector<double>& v) {
   double* d = nullptr;
   if (hipMalloc((void**)&d, v.size() * sizeof(double)) != hipSuccess) return nullptr;
@@ -67,6 +105,33 @@ PoissonSolver* poisson_create(ocn_model* m) {
   s->Nz = g->N[2];
   s->Nxh = s->Nx / 2 + 1;
   s->kind = (g->topo[2] == OCN_PERIODIC) ? 0 : 1;
+  if (g->topo[0] != OCN_PERIODIC || g->topo[1] != OCN_PERIODIC) {
+    s->kind = 4;
+    s->Nxh = s->Nx;
+    size_t n = (size_t)s->Nx * s->Ny * s->Nz;
+    bool ok = hipMalloc((void**)&s->rhs, n * sizeof(double)) == hipSuccess &&
+              hipMalloc((void**)&s->ga, n * sizeof(double2_)) == hipSuccess &&
+              hipMalloc((void**)&s->gb, n * sizeof(double2_)) == hipSuccess;
+    if (ok && g->topo[2] == OCN_BOUNDED) ok = hipMalloc((void**)&s->tscr, n * sizeof(double)) == hipSuccess;
+    for (int d = 0; d < 3 && ok; ++d) {
+      if (g->N[d] == 1 || g->topo[d] == OCN_FLAT) continue;           // identity
+      if (d == 2 && g->topo[2] == OCN_BOUNDED) continue;              // tridiagonal solve instead of a transform
+      std::vector<double2_> f, b;
+      transform_matrices(g->topo[d], g->N[d], f, b);
+      for (int q = 0; q < 2 && ok; ++q) {
+        ok = hipMalloc((void**)&s->gm[d][q], f.size() * sizeof(double2_)) == hipSuccess;
+        if (ok) hipMemcpy(s->gm[d][q], (q ? b : f).data(), f.size() * sizeof(double2_), hipMemcpyHostToDevice);
+      }
+    }
+    if (!ok) {
+      poisson_destroy(s);
+      return nullptr;
+    }
+    s->lx = upload(eigenvalues(g->topo[0], s->Nx, g->L[0]));
+    s->ly = upload(eigenvalues(g->topo[1], s->Ny, g->L[1]));
+    if (g->topo[2] == OCN_PERIODIC) s->lz = upload(eigenvalues(g->topo[2], s->Nz, g->L[2]));
+    return s;
+  }
   if (g->dist) {
     s->kind = 2;
     s->R = m->ctx->nranks;
@@ -192,6 +257,10 @@ void poisson_destroy(PoissonSolver* s) {
   zsolve_destroy(s->tw);
   hipFree(s->ta);
   hipFree(s->tb);
+  hipFree(s->ga);
+  hipFree(s->gb);
+  for (int d = 0; d < 3; ++d)
+    for (int q = 0; q < 2; ++q) hipFree(s->gm[d][q]);
   zsolve_destroy(s->zs);
   zslab_destroy(s->zsl);
   hipFree(s->rhs);
@@ -395,9 +464,87 @@ __global__ void k_tridiag(GridDev g, int Nxh, int Ny, int Nz, const double* __re
   }
 }
 
+// ---- any topology: dense transforms (kind 4) ------------------------------------------------------------------------
+// out[.., k, ..] = sum_n M[n][k] in[.., n, ..] along `axis` of a column-major (n0, n1, n2) complex array.
+// One thread per output element; along x consecutive threads read consecutive matrix entries (input-major
+// storage), along y / z consecutive threads read consecutive data and the matrix entry is wave-uniform.
+__global__ void k_dense_axis(int n0, int n1, int n2, int axis, const double2_* __restrict__ M,
+                             const double2_* __restrict__ in, double2_* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= n0 || j >= n1 || k >= n2) return;
+  const size_t s1 = n0, s2 = (size_t)n0 * n1;
+  const size_t c = i + s1 * j + s2 * k;
+  const int N = axis == 0 ? n0 : axis == 1 ? n1 : n2;
+  const int o = axis == 0 ? i : axis == 1 ? j : k;
+  const size_t st = axis == 0 ? 1 : axis == 1 ? s1 : s2;
+  const size_t base = c - (size_t)o * st;
+  double ax = 0, ay = 0;
+  for (int n = 0; n < N; ++n) {
+    const double2_ w = M[(size_t)n * N + o], v = in[base + (size_t)n * st];
+    ax = fma(w.x, v.x, fma(-w.y, v.y, ax));
+    ay = fma(w.x, v.y, fma(w.y, v.x, ay));
+  }
+  out[c] = {ax, ay};
+}
+__global__ void k_real_to_complex(size_t n, const double* __restrict__ r, double2_* __restrict__ c) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) c[i] = {r[i], 0.0};
+}
+__global__ void k_complex_to_real(size_t n, const double2_* __restrict__ c, double* __restrict__ r) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) r[i] = c[i].x;
+}
+
+// fft_based_poisson_solver.jl:93-120 / fourier_tridiagonal_poisson_solver.jl:67-101 for any (x, y, z) topology:
+// forward transforms direction by direction, eigenvalue division (or the tridiagonal solve down a Bounded z),
+// inverse transforms, real part.
+static int run_general(ocn_model* m) {
+  PoissonSolver* s = m->solver;
+  hipStream_t st = m->ctx->stream;
+  const size_t n = (size_t)s->Nx * s->Ny * s->Nz;
+  const dim3 b(64, 4, 1), gr((s->Nx + 63) / 64, (s->Ny + 3) / 4, s->Nz);
+  const dim3 b1(256, 1, 1), g1((unsigned)((n + 255) / 256), 1, 1);
+  double2_ *cur = s->ga, *oth = s->gb;
+  auto pass = [&](int axis, int inverse) {
+    if (!s->gm[axis][inverse]) return;
+    ocn_launch(k_dense_axis, gr, b, st, s->Nx, s->Ny, s->Nz, axis, (const double2_*)s->gm[axis][inverse],
+               (const double2_*)cur, oth);
+    std::swap(cur, oth);
+  };
+  {
+    ProfScope ps(m->ctx, "fft_forward");
+    ocn_launch(k_real_to_complex, g1, b1, st, n, (const double*)s->rhs, cur);
+    pass(0, 0);
+    pass(1, 0);
+    pass(2, 0);
+  }
+  {
+    ProfScope ps(m->ctx, "spectral_solve");
+    if (m->g->topo[2] == OCN_BOUNDED) {
+      dim3 g2((s->Nx + 63) / 64, (s->Ny + 3) / 4, 1);
+      ocn_launch(k_tridiag, g2, b, st, m->gd, s->Nx, s->Ny, s->Nz, (const double*)s->lx, (const double*)s->ly, 1.0, cur,
+                 s->tscr);
+    } else {
+      ocn_launch(k_scale_spectrum, gr, b, st, s->Nx, s->Ny, s->Nz, (const double*)s->lx, (const double*)s->ly,
+                 (const double*)s->lz, 1.0, cur);
+    }
+  }
+  {
+    ProfScope ps(m->ctx, "fft_backward");
+    pass(2, 1);
+    pass(1, 1);
+    pass(0, 1);
+    ocn_launch(k_complex_to_real, g1, b1, st, n, (const double2_*)cur, s->rhs);
+  }
+  return OCN_OK;
+}
+
 static int run_solver(ocn_model* m) {
   PoissonSolver* s = m->solver;
   hipStream_t st = m->ctx->stream;
+  if (s->kind == 4) return run_general(m);
   {
     ProfScope ps(m->ctx, "fft_forward");
 #ifndef OCN_HOST_EMU

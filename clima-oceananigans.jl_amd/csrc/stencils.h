@@ -21,8 +21,8 @@ struct GridDev {
   double rdx, rdy;
   const double* dzc;        // stretched z: spacing at centres, entry [k + Hz]   (k = 0-based centre index)
   const double* dzf;        //              spacing at faces,   entry [k + Hz + 1] (k = 0-based face index)
-  int zb;                   // z Bounded
-  int zflat;                // z Flat
+  int xb, yb, zb;           // Bounded directions
+  int zflat;                // z Flat (Flat x / y are stored with broadcast halos and need no flag)
   int nb;                   // boundary buffer of the advection scheme
 };
 

@@ -15,7 +15,11 @@
  *     need to stay alive for the duration of the (synchronous) upload / download call.
  *   - field memory is the reference's *parent* array: column-major (x fastest), halos included,
  *     size total_size(loc, grid) (Grids/new_data.jl:16-61, Grids/grid_utils.jl:105-128), so a Julia
- *     `OffsetArray` can alias ocn_field_device_ptr() with the usual offsets.
+ *     `OffsetArray` can alias ocn_field_device_ptr() with the usual offsets.  Exception: when x or y is
+ *     Bounded or Flat the rows / planes are pitched (like hipMallocPitch: one pitch of N+2H+1 for Face- and
+ *     Center-located fields; a Flat x / y direction is stored with broadcast copies).  ocn_field_layout()
+ *     returns the element strides and the origin of the logical parent inside the allocation, so the
+ *     alias becomes a strided view; ocn_field_upload / download always speak the dense parent layout.
  *   - one context = one device + one in-order HIP stream.  Compute calls are asynchronous with
  *     respect to the host and ordered on that stream; only ocn_sync, uploads and downloads block.
  *   - handles are not thread-safe: one host thread per context.
@@ -144,6 +148,9 @@ int ocn_model_halo(const ocn_model* m, int32_t H[3]);
 /* ---- fields: parent arrays incl. halos (Fields/field.jl:16-30; OutputWriters/fetch_output.jl:26) - */
 int ocn_field_shape(const ocn_model* m, int field_id, int32_t total[3], int32_t interior[3], int32_t halo[3]);
 void* ocn_field_device_ptr(ocn_model* m, int field_id);           /* Julia unsafe_wrap / torch from_blob */
+/* element strides (x, y, z) of the device array and the element offset of the logical parent's first entry;
+ * strides == (1, T0, T0*T1) and origin == 0 on (Periodic, Periodic, *) grids */
+int ocn_field_layout(const ocn_model* m, int field_id, int64_t strides[3], int64_t* origin);
 int ocn_field_upload(ocn_model* m, int field_id, const double* host_parent);   /* arch_array(GPU(), a) */
 int ocn_field_download(const ocn_model* m, int field_id, double* host_parent); /* arch_array(CPU(), a) */
 int ocn_field_set_interior(ocn_model* m, int field_id, const double* host_interior); /* Fields/set!.jl:21-39 */

@@ -53,10 +53,38 @@ CASES = {
                                  "S": {"top": ("flux", -1e-3)}}),
     "ppb_amd_regular_c2": dict(size=(8, 6, 7), topo=(P, P, B), extent=(1, 1, 1), adv="C2", stepper="AB2", steps=2,
                                dt=2e-3, tracers=("b",), closure="amd", buoyancy="b"),
+    # Bounded / Flat x and y: walls, cosine-transform topologies, 2-D slices
+    "bbb_weno_walls": dict(size=(8, 7, 6), topo=(B, B, B), extent=(1, 1.5, 0.8), adv="WENO5", stepper="RK3", steps=2, dt=2e-3,
+                           tracers=("c",), closure=(1e-2, 2e-2),
+                           bcs={"u": {"south": ("value", 0.0), "north": ("value", 0.1), "bottom": ("value", 0.0), "top": ("value", 0.0)},
+                                "v": {"west": ("value", 0.0), "east": ("value", 0.0), "bottom": ("value", 0.0), "top": ("gradient", 0.2)},
+                                "w": {"west": ("value", 0.0), "east": ("value", 0.0), "south": ("flux", 1e-3), "north": ("value", 0.0)},
+                                "c": {"west": ("value", 1.0), "east": ("gradient", -0.5), "south": ("flux", "rand:7:1e-2"),
+                                      "top": ("flux", "rand:8:1e-2"), "bottom": ("value", "rand:9:1.0")}}),
+    "pbb_u5_channel": dict(size=(8, 8, 8), topo=(P, B, B), extent=(2, 1, 1), adv="U5", stepper="AB2", steps=3, dt=2e-3,
+                           tracers=("b",), buoyancy="b", coriolis=5e-2, closure=(1e-3, 1e-3),
+                           bcs={"u": {"south": ("value", 0.0), "north": ("value", 0.0)}}),
+    "bpp_c4": dict(size=(9, 8, 6), topo=(B, P, P), extent=(1, 1, 1), adv="C4", stepper="RK3", steps=2, dt=2e-3),
+    "bpb_c2_stretched": dict(size=(6, 5, 8), topo=(B, P, B), xy=((0, 1), (-1, 1)), zfaces=[0, 1, 2, 4, 7, 11, 16, 22, 29],
+                             adv="C2", stepper="AB2", steps=2, dt=1e-2, tracers=("b",), buoyancy="b", closure=(1e-2, 1e-2)),
+    "pbb_amd": dict(size=(8, 6, 7), topo=(P, B, B), extent=(1, 1, 1), adv="WENO5", stepper="RK3", steps=2, dt=2e-3,
+                    tracers=("b",), closure="amd", buoyancy="b"),
+    "bfb_weno_slice": dict(size=(12, 10), topo=(B, F, B), extent=(2, 1), adv="WENO5", stepper="RK3", steps=2, dt=2e-3,
+                           tracers=("b",), buoyancy="b", closure=(1e-3, 1e-3)),
+    "fpb_u5_slice": dict(size=(10, 9), topo=(F, P, B), extent=(1, 1), adv="U5", stepper="AB2", steps=2, dt=2e-3,
+                         tracers=("c",)),
+    "pfp_weno_slice": dict(size=(12, 8), topo=(P, F, P), extent=(1, 1), adv="WENO5", stepper="AB2", steps=2, dt=2e-3),
+    "bbf_weno_box": dict(size=(10, 12), topo=(B, B, F), extent=(1, 1), adv="WENO5", stepper="RK3", steps=2, dt=5e-3,
+                         closure=(1e-4, 0.0)),
     # two-dimensional turbulence (BASELINE config 1): Flat z
     "ppf_weno_rk3": dict(size=(16, 16), topo=(P, P, F), extent=(2 * np.pi, 2 * np.pi), adv="WENO5", stepper="RK3",
                          steps=2, dt=0.05, closure=(1e-5, 0.0)),
 }
+
+
+def _full_size(cfg):
+    it = iter(cfg["size"])
+    return [1 if t == F else next(it) for t in cfg["topo"]]
 
 
 def build(mod, cfg, rng_seed=1234):
@@ -83,22 +111,34 @@ def build(mod, cfg, rng_seed=1234):
         mk["buoyancy"] = mod.BuoyancyTracer()
     if cfg.get("bcs"):
         ctor = {"flux": mod.FluxBC, "value": mod.ValueBC, "gradient": mod.GradientBC}
-        mk["boundary_conditions"] = {f: {s: ctor[k](v) for s, (k, v) in sides.items()} for f, sides in cfg["bcs"].items()}
+        dim_of = {"west": 0, "east": 0, "south": 1, "north": 1, "bottom": 2, "top": 2}
+        gN = [1 if t == F else n for t, n in zip(cfg["topo"], _full_size(cfg))]
+
+        def cond(side, v):
+            if isinstance(v, str):     # "rand:<seed>:<amplitude>": array over the two tangential directions
+                _, seed, amp = v.split(":")
+                shp = tuple(n for a, n in enumerate(gN) if a != dim_of[side])
+                return float(amp) * (np.random.default_rng(int(seed)).random(shp) - 0.5)
+            return v
+        mk["boundary_conditions"] = {f: {s: ctor[k](cond(s, v)) for s, (k, v) in sides.items()}
+                                     for f, sides in cfg["bcs"].items()}
     m = mod.NonhydrostaticModel(g, advection=_adv(mod, cfg["adv"]), timestepper=cfg["stepper"],
                                 tracers=cfg.get("tracers", ()), **mk)
     rng = np.random.default_rng(rng_seed)
-    N = tuple(cfg["size"]) + ((1,) if len(cfg["size"]) == 2 else ())
-    bounded_z = cfg["topo"][2] == B
-    init = {"u": rng.random(N) - 0.5, "v": rng.random(N) - 0.5}
-    wN = (N[0], N[1], N[2] + 1) if bounded_z else N
-    w = rng.random(wN) - 0.5
-    if bounded_z:
-        w[:, :, 0] = 0
-        w[:, :, -1] = 0
-    if cfg["topo"][2] != F:
-        init["w"] = w
+    init = {}
+    for n in ("u", "v", "w"):
+        if n == "w" and cfg["topo"][2] == F:
+            continue
+        a = rng.random(getattr(m, n).interior().shape) - 0.5
+        d = "uvw".index(n)
+        if cfg["topo"][d] == B:        # impenetrable walls
+            idx = [slice(None)] * 3
+            for side in (0, -1):
+                idx[d] = side
+                a[tuple(idx)] = 0
+        init[n] = a
     for t in cfg.get("tracers", ()):
-        init[t] = rng.random(N)
+        init[t] = rng.random(m.tracers[t].interior().shape)
     mod.set_model(m, **init)
     return m
 

@@ -120,6 +120,31 @@ def test_incompressible_weno5_periodic_100_steps():
     assert max_div(m) < 5e-8 and np.isfinite(m.u.data).all()
 
 
+# The same invariants on grids with walls in x / y and on 2-D slices (the topologies of test_poisson_solvers.jl:8-9
+# and test_flat_dimensions): projection leaves max|div U| at round-off, impenetrable walls stay closed, no-flux
+# walls conserve tracers.  These pin the oracle's Bounded / Flat x, y code paths used by the parity cases.
+@pytest.mark.parametrize("topo", [(B, B, B), (P, B, B), (B, P, P), (B, "Flat", B), (B, B, "Flat"), ("Flat", P, B)])
+@pytest.mark.parametrize("stepper", ["QuasiAdamsBashforth2", "RungeKutta3"])
+def test_incompressible_with_walls_and_slices(topo, stepper):
+    N = 10
+    size = tuple(N for t in topo if t != "Flat")
+    g = O.RectilinearGrid(size=size, extent=tuple(1.0 for _ in size), topology=topo)
+    m = O.NonhydrostaticModel(g, timestepper=stepper, advection=O.WENO5(), tracers=("c",),
+                              closure=O.ScalarDiffusivity(nu=1e-3, kappa=1e-3))
+    rng = np.random.default_rng(5)
+    O.set_model(m, u=0.2 * (rng.random(m.u.interior().shape) - 0.5), v=0.2 * (rng.random(m.v.interior().shape) - 0.5),
+                c=rng.random(m.tracers["c"].interior().shape))
+    c0 = m.tracers["c"].interior().sum()
+    for _ in range(3):
+        O.time_step(m, 2e-3)
+    assert max_div(m) < 5e-8
+    if topo[0] == B:
+        assert (m.u.interior()[0] == 0).all() and (m.u.interior()[-1] == 0).all()
+    if topo[1] == B:
+        assert (m.v.interior()[:, 0] == 0).all() and (m.v.interior()[:, -1] == 0).all()
+    assert abs(m.tracers["c"].interior().sum() - c0) < 1e-10 * abs(c0)
+
+
 # ---- tracer conservation (test_time_stepping.jl:154-188; isotropic diffusivity variant) -------
 def test_tracer_conserved():
     Nx, Ny, Nz = 16, 32, 16

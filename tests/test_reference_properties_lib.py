@@ -115,6 +115,75 @@ def _poisson(ocn):
         assert np.allclose(Ops(og).laplacian_ccc(f)((0, 0, 0)), R, rtol=1.5e-8, atol=1e-9)
 
 
+def _poisson_all_topologies(ocn, sizes):
+    """test_poisson_solvers.jl:8-9,45-85: every (x, y, z) in {Periodic, Bounded}^3 (+ Flat slices, + stretched z
+    under Bounded x / y): lap(phi) == R, and phi equals the oracle's solution (same zero-mean gauge)."""
+    import itertools
+    import oracle as O
+    from oracle.fields import Field, fill_halo_regions
+    from oracle.operators import Ops
+    from oracle.poisson import FFTBasedPoissonSolver, FourierTridiagonalPoissonSolver
+    F = "Flat"
+    rng = np.random.default_rng(11)
+    topos = list(itertools.product((P, B), repeat=3)) + [(B, F, B), (F, P, B), (P, F, P), (B, B, F), (F, B, F)]
+    worst = 0.0
+    for topo in topos:
+        for N3 in sizes:
+            N = tuple(n for n, t in zip(N3, topo) if t != F)
+            kw = dict(extent=tuple(1.0 + 0.5 * a for a, t in enumerate(topo) if t != F), topology=topo)
+            m = ocn.NonhydrostaticModel(ocn.RectilinearGrid(size=N, **kw))
+            og = O.RectilinearGrid(size=N, **kw)
+            full = tuple(1 if t == F else n for n, t in zip(N3, topo))
+            R = rng.random(full)
+            R -= R.mean()
+            phi = m.poisson_solve(R)
+            ref = FFTBasedPoissonSolver(og).solve(R)
+            worst = max(worst, np.abs(phi - ref).max() / np.abs(ref).max())
+            f = Field(og, (O.Center,) * 3)
+            f.set(phi)
+            fill_halo_regions(f)
+            assert np.allclose(Ops(og).laplacian_ccc(f)((0, 0, 0)), R, rtol=1.5e-8, atol=1e-9), (topo, N)
+    assert worst < 1e-11, worst
+    # Fourier-tridiagonal with walls in x / y (fourier_tridiagonal_poisson_solver.jl with Bounded x, y)
+    faces = np.array([1, 2, 4, 7, 11, 16, 22, 29, 37.0])
+    for topo in [(B, B, B), (P, B, B), (B, P, B)]:
+        N = (7, 6, 8)
+        kw = dict(x=(0, 1), y=(0, 2), z=faces, topology=topo)
+        m = ocn.NonhydrostaticModel(ocn.RectilinearGrid(size=N, **kw))
+        og = O.RectilinearGrid(size=N, **kw)
+        R = rng.random(N)
+        dz = np.diff(faces).reshape(1, 1, -1)
+        R -= (R * dz).sum() / (dz.sum() * N[0] * N[1])
+        phi = m.poisson_solve(R)
+        ref = FourierTridiagonalPoissonSolver(og).solve_source(R)
+        assert np.abs(phi - ref).max() / np.abs(ref).max() < 1e-11
+        f = Field(og, (O.Center,) * 3)
+        f.set(phi)
+        fill_halo_regions(f)
+        assert np.allclose(Ops(og).laplacian_ccc(f)((0, 0, 0)), R, rtol=1.5e-8, atol=1e-9), topo
+
+
+def _incompressible_walls(ocn, N, stepper, Nt):
+    """test_time_stepping.jl:112-146 transplanted to grids with walls in x / y and to 2-D slices."""
+    F = "Flat"
+    for topo in [(B, B, B), (P, B, B), (B, P, P), (B, F, B), (B, B, F)]:
+        size = tuple(N for t in topo if t != F)
+        g = ocn.RectilinearGrid(size=size, extent=tuple(1.0 for _ in size), topology=topo)
+        m = ocn.NonhydrostaticModel(g, timestepper=stepper, advection=ocn.WENO5(), tracers=("c",),
+                                    closure=ocn.ScalarDiffusivity(nu=1e-3, kappa=1e-3))
+        rng = np.random.default_rng(5)
+        ocn.set_model(m, u=0.2 * (rng.random(m.u.size) - 0.5), v=0.2 * (rng.random(m.v.size) - 0.5),
+                      c=rng.random(m.tracers["c"].size))
+        c0 = m.tracers["c"].interior().sum()
+        for _ in range(Nt):
+            ocn.time_step(m, 0.02 / N)
+        assert m.max_abs_divergence() < 5e-8
+        u = m.u.interior()
+        if topo[0] == B:
+            assert (u[0] == 0).all() and (u[-1] == 0).all()              # impenetrable walls
+        assert abs(m.tracers["c"].interior().sum() - c0) < 1e-10 * abs(c0)   # no-flux walls conserve the tracer
+
+
 # ---- CPU (host emulation) at reduced sizes ----------------------------------------------------------------------
 @pytest.mark.parametrize("stepper", ["QuasiAdamsBashforth2", "RungeKutta3"])
 def test_incompressible_hostemu(ocn, backend, stepper):
@@ -131,6 +200,16 @@ def test_halos_and_poisson_hostemu(ocn, backend):
     _run(ocn, backend, False)
     _halos(ocn)
     _poisson(ocn)
+
+
+def test_poisson_all_topologies_hostemu(ocn, backend):
+    _run(ocn, backend, False)
+    _poisson_all_topologies(ocn, [(7, 11, 16), (16, 7, 11)])
+
+
+def test_incompressible_walls_hostemu(ocn, backend):
+    _run(ocn, backend, False)
+    _incompressible_walls(ocn, 10, "RungeKutta3", 3)
 
 
 # ---- GPU at the reference's sizes -----------------------------------------------------------------------------------
@@ -154,6 +233,19 @@ def test_taylor_green_gpu(ocn, backend, stepper):
 def test_tracer_advection_gpu(ocn, backend, stepper):
     _run(ocn, backend, True)
     _tracer_advection(ocn, 128, stepper)
+
+
+@pytest.mark.gpu
+def test_poisson_all_topologies_gpu(ocn, backend):
+    _run(ocn, backend, True)
+    _poisson_all_topologies(ocn, [(7, 11, 16), (16, 7, 11), (32, 24, 20)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stepper", ["QuasiAdamsBashforth2", "RungeKutta3"])
+def test_incompressible_walls_gpu(ocn, backend, stepper):
+    _run(ocn, backend, True)
+    _incompressible_walls(ocn, 24, stepper, 10)
 
 
 @pytest.mark.gpu
