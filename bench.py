@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--stepper", default="AB2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tracers", type=int, default=0, help="passive tracers (config 2b: 1)")
+    ap.add_argument("--topology", default="PPP", help="config 2 with other x/y/z topologies, e.g. PBB (debug / widening rows)")
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (headline, default) or 3 (ocean LES)")
     args = ap.parse_args()
 
@@ -124,13 +125,13 @@ def main():
     if args.config == 3:
         model, dt3, Nglobal, n = build_config3(ocn, ctx, args)
     else:
-        grid = ocn.RectilinearGrid(ctx, size=Nglobal, extent=(1, 1, float(world)), topology=("Periodic",) * 3)
+        topo = tuple({"P": "Periodic", "B": "Bounded"}[c] for c in args.topology.upper())
+        grid = ocn.RectilinearGrid(ctx, size=Nglobal, extent=(1, 1, float(world)), topology=topo)
         tnames = tuple(f"c{i}" for i in range(args.tracers))
         model = ocn.NonhydrostaticModel(grid, advection=ocn.WENO5(), timestepper=args.stepper, tracers=tnames)
         rng = np.random.default_rng(1 + rank)
-        local = model.u.size
-        init = dict(u=rng.random(local) - 0.5, v=rng.random(local) - 0.5, w=rng.random(local) - 0.5)
-        init.update({t: rng.random(local) for t in tnames})
+        init = dict(u=rng.random(model.u.size) - 0.5, v=rng.random(model.v.size) - 0.5, w=rng.random(model.w.size) - 0.5)
+        init.update({t: rng.random(model.tracers[t].size) for t in tnames})
         ocn.set_model(model, **init)
     umax = np.abs(model.u.interior()).max()
     if dist is not None:
@@ -198,7 +199,9 @@ def main():
             "metric": "cell-updates/sec per time_step!, 256^3 Nonhydrostatic WENO5", "value": value,
             "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} triply-periodic RectilinearGrid, "
+            "config": {"workload": (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} "
+                                    + ("triply-periodic" if args.topology.upper() == "PPP" else f"topology {args.topology.upper()}")
+                                    + " RectilinearGrid, "
                                     f"NonhydrostaticModel WENO5(zweno) + FFT Poisson, {args.stepper}, halo 3, {args.tracers} tracers")
                        if args.config == 2 else
                        (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} (Periodic,Periodic,Bounded) stretched z, WENO5, RK3, T+S, "

@@ -444,6 +444,20 @@ static int pressure_correction(ocn_model* m, double dt) {
   return OCN_OK;
 }
 
+// store_tendencies! (store_tendencies.jl:14-36) without the copy: G^- takes over G^n's buffers, and G^n gets
+// the old G^- buffers, which the next tendency evaluation overwrites completely.
+static void store_by_swap(ocn_model* m) {
+  for (int f = 0; f < 3 + m->nt; ++f) std::swap(m->Gn[f], m->Gm[f]);
+}
+
+// Phase-level callers expect two distinct arrays: make G^n a real copy of G^- again when they are aliased.
+static void materialize_gn(ocn_model* m) {
+  if (!m->gn_alias_gm) return;
+  for (int f = 0; f < 3 + m->nt; ++f)
+    hipMemcpyAsync(m->Gn[f].d, m->Gm[f].d, m->Gm[f].n * sizeof(double), hipMemcpyDeviceToDevice, m->ctx->stream);
+  m->gn_alias_gm = false;
+}
+
 static void zero_Gm(ocn_model* m) {
   for (int f = 0; f < 3 + m->nt; ++f) hipMemsetAsync(m->Gm[f].d, 0, m->Gm[f].n * sizeof(double), m->ctx->stream);
 }
@@ -491,12 +505,14 @@ static int time_step_ab2(ocn_model* m, double dt, int force_euler) {
     m->stage = 1;
     return OCN_OK;           // update_state!: halos were written by the projection; no pHY', no closure
   }
+  if (m->gn_alias_gm) m->gn_alias_gm = false;   // G^n gets its own (recycled) buffer again
   launch_tendencies(m);
   launch_step(m, dt, 1.5 + chi, -(0.5 + chi), 1);
   int rc = pressure_correction(m, dt);
   if (rc) return rc;
   launch_pcorrect(m, dt);
-  launch_store(m);
+  store_by_swap(m);
+  m->gn_alias_gm = true;
   m->time += dt;
   m->iteration += 1;
   m->stage = 1;
@@ -521,6 +537,7 @@ static int time_step_rk3(ocn_model* m, double dt) {
     m->stage = 1;
     return OCN_OK;
   }
+  m->gn_alias_gm = false;
   for (int s = 0; s < 3; ++s) {
     launch_tendencies(m);
     launch_step(m, dt, gam[s], zet[s], s > 0);
@@ -530,7 +547,7 @@ static int time_step_rk3(ocn_model* m, double dt) {
     m->time += sdt[s];
     if (s < 2) {
       m->stage += 1;
-      launch_store(m);
+      store_by_swap(m);
     } else {
       m->iteration += 1;
       m->stage = 1;
@@ -739,7 +756,7 @@ int ocn_field_layout(const ocn_model* m, int field_id, int64_t strides[3], int64
 }
 
 int ocn_field_upload(ocn_model* m, int field_id, const double* host) {
-  if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF) m->gn_alias_gm = false;
+  if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF) materialize_gn(m);
   Field* f = model_field(m, field_id);
   if (!f || !host) return OCN_EINVAL;
   OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));
@@ -771,7 +788,7 @@ int ocn_field_download(const ocn_model* m, int field_id, double* host) {
 }
 
 int ocn_field_set_interior(ocn_model* m, int field_id, const double* host) {
-  if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF) m->gn_alias_gm = false;
+  if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF) materialize_gn(m);
   Field* f = model_field(m, field_id);
   if (!f || !host) return OCN_EINVAL;
   int32_t it[3];
@@ -826,18 +843,21 @@ int ocn_compute_tendencies(ocn_model* m) {
 
 int ocn_ab2_step(ocn_model* m, double dt, double chi) {
   if (!m) return OCN_EINVAL;
+  materialize_gn(m);
   launch_step(m, dt, 1.5 + chi, -(0.5 + chi), 1);
   return OCN_OK;
 }
 
 int ocn_rk3_substep(ocn_model* m, double dt, double gamma, double zeta, int has_zeta) {
   if (!m) return OCN_EINVAL;
+  materialize_gn(m);
   launch_step(m, dt, gamma, zeta, has_zeta);
   return OCN_OK;
 }
 
 int ocn_store_tendencies(ocn_model* m) {
   if (!m) return OCN_EINVAL;
+  materialize_gn(m);
   launch_store(m);
   return OCN_OK;
 }

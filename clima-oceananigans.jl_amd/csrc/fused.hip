@@ -37,6 +37,7 @@ struct FusedArgs {
   int KZ;                         // levels per z-chunk
   int BYo;                        // output rows per workgroup (= blockDim.y - 1)
   int ntiles;                     // y-tiles (v3: segment decomposition)
+  int dbg_nobar;                  // timing experiments only (OCNHIP_DBG_NOBAR): results are wrong
 };
 
 OCN_DEVFN void sto(double* base, unsigned boff, double v) { *(double*)((char*)base + boff) = v; }
@@ -278,7 +279,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
     const unsigned c = cxy + (unsigned)k * szb;
     const bool last = (k == k1);
     commit();
-    __syncthreads();
+    if (!(a.dbg_nobar & 2)) __syncthreads();
     if (EARLY && !last) prefetch(k + 1);   // next level's slab in flight during the whole flux stage
     double gm0 = 0, gm1 = 0, gm2 = 0;      // G^- of the level finalized below, also fetched early
     if (EARLY && a.use_m && full && k > k0) {
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
 #undef YSYM
 #undef XREC
 #undef YREC
-    __syncthreads();
+    if (!(a.dbg_nobar & 1)) __syncthreads();
     if (!EARLY && !last) prefetch(k + 1);  // in flight during the (cheap) finalize stage; committed at the loop top
     if (full) {
       if (k > k0) {
@@ -562,6 +563,7 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
   a.us = m->us.d; a.vs = m->vs.d; a.ws = m->ws.d;
   a.org = (unsigned)((m->u.Hx + m->u.Hy * m->u.sy + m->u.Hz * m->u.sz) * sizeof(double));
   a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
+  a.dbg_nobar = 0;
   dim3 block, grid;
   fused_geometry(m, block, grid, a.KZ, a.BYo);
   hipStream_t s = m->ctx->stream;
@@ -577,6 +579,8 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
     static const bool early = !(getenv("OCNHIP_FUSED_EARLY") && atoi(getenv("OCNHIP_FUSED_EARLY")) == 0);
     a.BYo = by - 1;
     a.ntiles = (gd.Ny + by - 2) / (by - 1);
+    static const int nobar = getenv("OCNHIP_DBG_NOBAR") ? atoi(getenv("OCNHIP_DBG_NOBAR")) : 0;
+    a.dbg_nobar = nobar;
     static const int segs_env = getenv("OCNHIP_FUSED_SEGS") ? atoi(getenv("OCNHIP_FUSED_SEGS")) : 0;
     static int ncu = 0;
     if (!ncu) {

@@ -41,7 +41,7 @@ OCN_DEVFN double nu_cff(const Phys& ph, long p, long sy, long sz) {
   return ph.nu_e ? 0.25 * ((ph.nu_e[p - sy - sz] + ph.nu_e[p - sz]) + (ph.nu_e[p - sy] + ph.nu_e[p])) : ph.nu;
 }
 
-template <int ADV>
+template <int ADV, bool WALLS>
 __global__ void k_tend_uvw(GridDev g, Phys ph, const double* __restrict__ u, const double* __restrict__ v,
                            const double* __restrict__ w, double* __restrict__ Gu, double* __restrict__ Gv,
                            double* __restrict__ Gw) {
@@ -52,7 +52,7 @@ __global__ void k_tend_uvw(GridDev g, Phys ph, const double* __restrict__ u, con
   const long sy = g.sy, sz = g.sz;
   const long c = i + j * sy + k * sz;
   const int ii = i + 1, jj = j + 1, kk = k + 1;  // 1-based, as in the reference's boundary-buffer tests
-  const bool xb = g.xb != 0, yb = g.yb != 0, zb = g.zb != 0, zf = g.zflat != 0;
+  const bool xb = WALLS && g.xb != 0, yb = WALLS && g.yb != 0, zb = g.zb != 0, zf = g.zflat != 0;   // WALLS: Bounded x or y
   const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz, nb = g.nb;
   const double rdx = g.rdx, rdy = g.rdy;
   const double rdzc = zf ? 0.0 : 1.0 / g_dzc(g, k);
@@ -143,7 +143,7 @@ __global__ void k_tend_uvw(GridDev g, Phys ph, const double* __restrict__ u, con
   Gw[c] = gw;
 }
 
-template <int ADV>
+template <int ADV, bool WALLS>
 __global__ void k_tend_c(GridDev g, const double* __restrict__ u, const double* __restrict__ v,
                          const double* __restrict__ w, const double* __restrict__ q, double kap,
                          const double* __restrict__ kap_e, int closure, double* __restrict__ Gc) {
@@ -160,8 +160,8 @@ __global__ void k_tend_c(GridDev g, const double* __restrict__ u, const double* 
   double gc = 0;
   if (ADV != ADV_NONE) {
     // tracer_advection_operators.jl:31-35; advecting velocity un-interpolated
-    auto Fx = [&](long p, int i1) { return adv_flux_b<ADV>(q + p, 1, u[p], g.xb != 0, i1, g.Nx, g.nb); };
-    auto Fy = [&](long p, int j1) { return adv_flux_b<ADV>(q + p, sy, v[p], g.yb != 0, j1, g.Ny, g.nb); };
+    auto Fx = [&](long p, int i1) { return adv_flux_b<ADV>(q + p, 1, u[p], WALLS && g.xb != 0, i1, g.Nx, g.nb); };
+    auto Fy = [&](long p, int j1) { return adv_flux_b<ADV>(q + p, sy, v[p], WALLS && g.yb != 0, j1, g.Ny, g.nb); };
     gc -= (Fx(c + 1, i + 2) - Fx(c, i + 1)) * rdx + (Fy(c + sy, j + 2) - Fy(c, j + 1)) * rdy;
     if (!zf) {
       auto Fz = [&](long p, int k1) { return adv_flux_b<ADV>(q + p, sz, w[p], zb, k1, g.Nz, g.nb); };
@@ -224,13 +224,19 @@ void launch_tendencies(ocn_model* m) {
   dim3 b(64, 4, 1), gr = grid3(g, b);
   const double *u = m->u.interior(), *v = m->v.interior(), *w = m->w.interior();
   double *Gu = m->Gn[0].interior(), *Gv = m->Gn[1].interior(), *Gw = m->Gn[2].interior();
-#define TEND_CASE(A)                                                            \
-  case A:                                                                       \
-    ocn_launch(k_tend_uvw<A>, gr, b, s, g, ph, u, v, w, Gu, Gv, Gw);           \
-    for (int t = 0; t < m->nt; ++t)                                            \
-      ocn_launch(k_tend_c<A>, gr, b, s, g, u, v, w, (const double*)m->tr[t].interior(), m->d.kappa[t], \
-                 (const double*)(m->kappa_e[t].present ? m->kappa_e[t].interior() : nullptr), m->d.closure, \
-                 m->Gn[3 + t].interior());                                      \
+#define TEND_LAUNCH(A, W)                                                       \
+  ocn_launch(k_tend_uvw<A, W>, gr, b, s, g, ph, u, v, w, Gu, Gv, Gw);           \
+  for (int t = 0; t < m->nt; ++t)                                               \
+    ocn_launch(k_tend_c<A, W>, gr, b, s, g, u, v, w, (const double*)m->tr[t].interior(), m->d.kappa[t], \
+               (const double*)(m->kappa_e[t].present ? m->kappa_e[t].interior() : nullptr), m->d.closure, \
+               m->Gn[3 + t].interior());
+#define TEND_CASE(A)                \
+  case A:                           \
+    if (g.xb || g.yb) {             \
+      TEND_LAUNCH(A, true)          \
+    } else {                        \
+      TEND_LAUNCH(A, false)         \
+    }                               \
     break;
   switch (m->d.advection) {
     TEND_CASE(ADV_NONE)
@@ -241,6 +247,7 @@ void launch_tendencies(ocn_model* m) {
     TEND_CASE(ADV_WENO_JS)
   }
 #undef TEND_CASE
+#undef TEND_LAUNCH
   // boundary contributions in every Bounded direction
   for (int dim = 0; dim < 3; ++dim) {
     if (m->g->topo[dim] != OCN_BOUNDED) continue;
@@ -614,13 +621,23 @@ template <class F> OCN_DEVFN double amd_Iyz(const AmdCtx& a, long p, int k, F f)
   return 0.5 * (0.5 * (f(p, k) + f(p + a.sy, k)) + 0.5 * (f(p + a.sz, k + 1) + f(p + a.sy + a.sz, k + 1)));
 }
 
-__global__ void k_amd_nu(AmdCtx a, double Cnu, double* __restrict__ nu) {
+struct AmdTracers {
+  const double* q[OCN_MAX_TRACERS];
+  double* kap[OCN_MAX_TRACERS];
+  double Ck[OCN_MAX_TRACERS];
+  int n;
+};
+
+// nu_e and every kappa_e in one pass: the interpolated velocity gradients are shared by all predictors
+// (calc_nu / calc_kappa, anisotropic_minimum_dissipation.jl:138-178).
+__global__ void k_amd_all(AmdCtx a, double Cnu, double* __restrict__ nu, AmdTracers T) {
   const GridDev& g = a.g;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
-  const long c = i + j * a.sy + k * a.sz;
+  const long sy = a.sy, sz = a.sz;
+  const long c = i + j * sy + k * sz;
   auto sq = [](double x) { return x * x; };
   auto ndxv = [&](long p, int) { return amd_ndxv(a, p); };
   auto ndyu = [&](long p, int) { return amd_ndyu(a, p); };
@@ -633,7 +650,11 @@ __global__ void k_amd_nu(AmdCtx a, double Cnu, double* __restrict__ nu) {
   auto S23 = [&](long p, int kk) { return amd_S23(a, p, kk); };
   const double dxu = amd_dxu(a, c), dyv = amd_dyv(a, c), dzw = amd_dzw(a, c, k);
   const double S11 = dxu, S22 = dyv, S33 = dzw;
-  // squares and products interpolated to ccc
+  // gradients interpolated to ccc (shared by nu_e and kappa_e)
+  const double xy_dxv = amd_Ixy(a, c, k, ndxv), xy_dyu = amd_Ixy(a, c, k, ndyu);
+  const double xz_dxw = amd_Ixz(a, c, k, ndxw), xz_dzu = amd_Ixz(a, c, k, ndzu);
+  const double yz_dyw = amd_Iyz(a, c, k, ndyw), yz_dzv = amd_Iyz(a, c, k, ndzv);
+  // squares interpolated to ccc
   const double xy_dxv2 = amd_Ixy(a, c, k, [&](long p, int kk) { return sq(ndxv(p, kk)); });
   const double xy_dyu2 = amd_Ixy(a, c, k, [&](long p, int kk) { return sq(ndyu(p, kk)); });
   const double xz_dxw2 = amd_Ixz(a, c, k, [&](long p, int kk) { return sq(ndxw(p, kk)); });
@@ -641,59 +662,46 @@ __global__ void k_amd_nu(AmdCtx a, double Cnu, double* __restrict__ nu) {
   const double yz_dyw2 = amd_Iyz(a, c, k, [&](long p, int kk) { return sq(ndyw(p, kk)); });
   const double yz_dzv2 = amd_Iyz(a, c, k, [&](long p, int kk) { return sq(ndzv(p, kk)); });
   const double q = sq(dxu) + sq(dyv) + sq(dzw) + xy_dxv2 + xy_dyu2 + xz_dxw2 + xz_dzu2 + yz_dyw2 + yz_dzv2;
+  const double Dz = amd_Dz(a, k);
+  const double d2 = 3.0 / (1.0 / (a.Dx * a.Dx) + 1.0 / (a.Dy * a.Dy) + 1.0 / (Dz * Dz));
   double nus = 0.0;
   if (q != 0.0) {
     const double r1 = S11 * sq(dxu) + S22 * xy_dxv2 + S33 * xz_dxw2 +
                       2 * dxu * amd_Ixy(a, c, k, [&](long p, int kk) { return ndxv(p, kk) * S12(p, kk); }) +
                       2 * dxu * amd_Ixz(a, c, k, [&](long p, int kk) { return ndxw(p, kk) * S13(p, kk); }) +
-                      2 * amd_Ixy(a, c, k, ndxv) * amd_Ixz(a, c, k, ndxw) * amd_Iyz(a, c, k, S23);
+                      2 * xy_dxv * xz_dxw * amd_Iyz(a, c, k, S23);
     const double r2 = S11 * xy_dyu2 + S22 * sq(dyv) + S33 * yz_dyw2 +
                       2 * dyv * amd_Ixy(a, c, k, [&](long p, int kk) { return ndyu(p, kk) * S12(p, kk); }) +
-                      2 * amd_Ixy(a, c, k, ndyu) * amd_Iyz(a, c, k, ndyw) * amd_Ixz(a, c, k, S13) +
+                      2 * xy_dyu * yz_dyw * amd_Ixz(a, c, k, S13) +
                       2 * dyv * amd_Iyz(a, c, k, [&](long p, int kk) { return ndyw(p, kk) * S23(p, kk); });
     const double r3 = S11 * xz_dzu2 + S22 * yz_dzv2 + S33 * sq(dzw) +
-                      2 * amd_Ixz(a, c, k, ndzu) * amd_Iyz(a, c, k, ndzv) * amd_Ixy(a, c, k, S12) +
+                      2 * xz_dzu * yz_dzv * amd_Ixy(a, c, k, S12) +
                       2 * dzw * amd_Ixz(a, c, k, [&](long p, int kk) { return ndzu(p, kk) * S13(p, kk); }) +
                       2 * dzw * amd_Iyz(a, c, k, [&](long p, int kk) { return ndzv(p, kk) * S23(p, kk); });
-    const double Dz = amd_Dz(a, k);
-    const double d2 = 3.0 / (1.0 / (a.Dx * a.Dx) + 1.0 / (a.Dy * a.Dy) + 1.0 / (Dz * Dz));
     nus = -Cnu * d2 * (r1 + r2 + r3) / q;
   }
   nu[c] = fmax(0.0, nus);
-}
-
-__global__ void k_amd_kappa(AmdCtx a, const double* __restrict__ q_, double Ck, double* __restrict__ kap) {
-  const GridDev& g = a.g;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
-  const long c = i + j * a.sy + k * a.sz, sy = a.sy, sz = a.sz;
-  auto sq = [](double x) { return x * x; };
-  // normalised tracer gradients at fcc / cfc / ccf
-  auto nx = [&](long p) { return a.Dx * ((q_[p] - q_[p - 1]) * a.rdx); };
-  auto ny = [&](long p) { return a.Dy * ((q_[p] - q_[p - sy]) * a.rdy); };
-  auto nz = [&](long p, int kk) { return amd_Dz(a, kk) * ((q_[p] - q_[p - sz]) / g_dzf(g, kk)); };
-  const double x0 = nx(c), x1 = nx(c + 1), y0 = ny(c), y1 = ny(c + sy), z0 = nz(c, k), z1 = nz(c + sz, k + 1);
-  const double Ix_c = 0.5 * (x0 + x1), Iy_c = 0.5 * (y0 + y1), Iz_c = 0.5 * (z0 + z1);
-  const double Ix_c2 = 0.5 * (sq(x0) + sq(x1)), Iy_c2 = 0.5 * (sq(y0) + sq(y1)), Iz_c2 = 0.5 * (sq(z0) + sq(z1));
-  const double sigma = Ix_c2 + Iy_c2 + Iz_c2;
-  double ks = 0.0;
-  if (sigma != 0.0) {
-    auto ndxv = [&](long p, int) { return amd_ndxv(a, p); };
-    auto ndyu = [&](long p, int) { return amd_ndyu(a, p); };
-    auto ndxw = [&](long p, int kk) { return amd_ndxw(a, p, kk); };
-    auto ndzu = [&](long p, int kk) { return amd_ndzu(a, p, kk); };
-    auto ndyw = [&](long p, int kk) { return amd_ndyw(a, p, kk); };
-    auto ndzv = [&](long p, int kk) { return amd_ndzv(a, p, kk); };
-    const double cx = amd_dxu(a, c) * Ix_c2 + amd_Ixy(a, c, k, ndxv) * Ix_c * Iy_c + amd_Ixz(a, c, k, ndxw) * Ix_c * Iz_c;
-    const double cy = amd_Ixy(a, c, k, ndyu) * Iy_c * Ix_c + amd_dyv(a, c) * Iy_c2 + amd_Ixz(a, c, k, ndyw) * Iy_c * Iz_c;
-    const double cz = amd_Ixz(a, c, k, ndzu) * Iz_c * Ix_c + amd_Iyz(a, c, k, ndzv) * Iz_c * Iy_c + amd_dzw(a, c, k) * Iz_c2;
-    const double Dz = amd_Dz(a, k);
-    const double d2 = 3.0 / (1.0 / (a.Dx * a.Dx) + 1.0 / (a.Dy * a.Dy) + 1.0 / (Dz * Dz));
-    ks = -Ck * d2 * (cx + cy + cz) / sigma;
+  if (T.n == 0) return;
+  const double xz_dyw = amd_Ixz(a, c, k, ndyw);   // cy_uy interpolates norm_dy_w with I_xz, as written (:326)
+  for (int t = 0; t < T.n; ++t) {
+    const double* __restrict__ q_ = T.q[t];
+    // normalised tracer gradients at fcc / cfc / ccf
+    auto nx = [&](long p) { return a.Dx * ((q_[p] - q_[p - 1]) * a.rdx); };
+    auto ny = [&](long p) { return a.Dy * ((q_[p] - q_[p - sy]) * a.rdy); };
+    auto nz = [&](long p, int kk) { return amd_Dz(a, kk) * ((q_[p] - q_[p - sz]) / g_dzf(g, kk)); };
+    const double x0 = nx(c), x1 = nx(c + 1), y0 = ny(c), y1 = ny(c + sy), z0 = nz(c, k), z1 = nz(c + sz, k + 1);
+    const double Ix_c = 0.5 * (x0 + x1), Iy_c = 0.5 * (y0 + y1), Iz_c = 0.5 * (z0 + z1);
+    const double Ix_c2 = 0.5 * (sq(x0) + sq(x1)), Iy_c2 = 0.5 * (sq(y0) + sq(y1)), Iz_c2 = 0.5 * (sq(z0) + sq(z1));
+    const double sigma = Ix_c2 + Iy_c2 + Iz_c2;
+    double ks = 0.0;
+    if (sigma != 0.0) {
+      const double cx = dxu * Ix_c2 + xy_dxv * Ix_c * Iy_c + xz_dxw * Ix_c * Iz_c;
+      const double cy = xy_dyu * Iy_c * Ix_c + dyv * Iy_c2 + xz_dyw * Iy_c * Iz_c;
+      const double cz = xz_dzu * Iz_c * Ix_c + yz_dzv * Iz_c * Iy_c + dzw * Iz_c2;
+      ks = -T.Ck[t] * d2 * (cx + cy + cz) / sigma;
+    }
+    T.kap[t][c] = fmax(0.0, ks);
   }
-  kap[c] = fmax(0.0, ks);
 }
 
 // calculate_diffusivities!(diffusivity_fields, closure::AMD, model)  (anisotropic_minimum_dissipation.jl:180-205)
@@ -706,8 +714,12 @@ void launch_amd(ocn_model* m) {
   a.sy = g.sy; a.sz = g.sz; a.rdx = g.rdx; a.rdy = g.rdy;
   a.Dx = 2.0 * g.dx; a.Dy = 2.0 * g.dy;
   dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
-  ocn_launch(k_amd_nu, gr, b, m->ctx->stream, a, m->d.amd_Cnu, m->nu_e.interior());
-  for (int t = 0; t < m->nt; ++t)
-    ocn_launch(k_amd_kappa, gr, b, m->ctx->stream, a, (const double*)m->tr[t].interior(), m->d.amd_Ckappa[t],
-               m->kappa_e[t].interior());
+  AmdTracers T;
+  T.n = m->nt;
+  for (int t = 0; t < m->nt; ++t) {
+    T.q[t] = m->tr[t].interior();
+    T.kap[t] = m->kappa_e[t].interior();
+    T.Ck[t] = m->d.amd_Ckappa[t];
+  }
+  ocn_launch(k_amd_all, gr, b, m->ctx->stream, a, m->d.amd_Cnu, m->nu_e.interior(), T);
 }

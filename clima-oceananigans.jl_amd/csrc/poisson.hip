@@ -13,6 +13,9 @@
 // as the reference's cosine-transform path (same operator, same zero-mean gauge), without a DCT.
 #include "internal.h"
 
+#ifndef OCN_HOST_EMU
+#include <rocblas/rocblas.h>
+#endif
 #include <complex>
 typedef std::complex<double> cplx;
 
@@ -36,11 +39,17 @@ struct PoissonSolver {
   double2_* spec = nullptr;   // complex (Nxh,Ny,Nz)
   double* tscr = nullptr;     // Thomas scratch (Nxh*Ny, Nz)
   double *lx = nullptr, *ly = nullptr, *lz = nullptr;  // eigenvalues on the device
-  // kind 4 (any topology): dense transforms along x / y / z on the full complex array, ping-pong ga <-> gb
-  double2_ *ga = nullptr, *gb = nullptr;
-  double2_* gm[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // [axis][fwd / inv], null: identity
+  // kind 4 (a Bounded or Flat x / y direction), see run_walls
+  bool tr = false;                 // solved on the x <-> y transposed array (x Bounded / Flat with y Periodic)
+  int gNx = 0, gNy = 0, gR = 0;    // sizes after the swap; gR: x extent of the complex array (Nx/2+1 if x is Periodic)
+  int gtopo[2] = {0, 0};
+  double *ra = nullptr, *rb = nullptr;      // real (gNx, gNy, Nz) ping-pong
+  double2_ *ga = nullptr, *gb = nullptr;    // complex (gR, gNy, Nz) ping-pong
+  double* gm[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // cosine-transform matrices [x / y][forward / inverse]
+  void* blas = nullptr;                     // rocblas_handle
 #ifndef OCN_HOST_EMU
   hipfftHandle fwd = 0, inv = 0, zplan = 0, xinv = 0;
+  hipfftHandle wxf = 0, wxi = 0, wz = 0;    // kind 4: batched 1-D x (R2C / C2R) and z (C2C) plans
 #endif
 };
 
@@ -68,25 +77,18 @@ static std::vector<double> eigenvalues(int topo, int N, double L) {
   return l;
 }
 
-// Transform matrices of one direction, stored input-major: M[n * N + k] maps input n to output k.
-//   Periodic: forward exp(-2 pi i k n / N), inverse exp(+2 pi i k n / N) / N            (discrete_transforms.jl:107-121)
-//   Bounded : forward cos(pi (n + 1/2) k / N)  (DCT-II), inverse (k == 0 ? 1 : 2) cos(pi (n + 1/2) k / N) / N
-//             (DCT-III); FFTW's REDFT10 / REDFT01 pair is 2x / 1x these and normalised by 1 / 2N (:140-161) --
-//             the composition with the eigenvalue division is identical.
-static void transform_matrices(int topo, int N, std::vector<double2_>& fwd, std::vector<double2_>& inv) {
-  fwd.assign((size_t)N * N, {0, 0});
-  inv.assign((size_t)N * N, {0, 0});
+// Cosine-transform matrices of a Bounded direction, column-major N x N (discrete_transforms.jl:140-161 uses
+// FFTW's REDFT10 / REDFT01, which are 2x / 1x these and normalised by 1 / 2N; the composition is the same):
+//   forward  F(k, n) = cos(pi (n + 1/2) k / N)                       (DCT-II)
+//   inverse  I(n, k) = (k == 0 ? 1 : 2) cos(pi (n + 1/2) k / N) / N  (DCT-III), I F = identity
+static void cosine_matrices(int N, std::vector<double>& F, std::vector<double>& I) {
+  F.assign((size_t)N * N, 0.0);
+  I.assign((size_t)N * N, 0.0);
   for (int n = 0; n < N; ++n)
     for (int k = 0; k < N; ++k) {
-      if (topo == OCN_PERIODIC) {
-        double ang = 2.0 * M_PI * (double)(((long)n * k) % N) / N;
-        fwd[(size_t)n * N + k] = {cos(ang), -sin(ang)};
-        inv[(size_t)k * N + n] = {cos(ang) / N, sin(ang) / N};   // input k (spectral) -> output n (physical)
-      } else {
-        double c = cos(M_PI * (n + 0.5) * k / N);
-        fwd[(size_t)n * N + k] = {c, 0.0};
-        inv[(size_t)k * N + n] = {(k == 0 ? 1.0 : 2.0) * c / N, 0.0};
-      }
+      double c = cos(M_PI * (n + 0.5) * k / N);
+      F[k + (size_t)n * N] = c;
+      I[n + (size_t)k * N] = (k == 0 ? 1.0 : 2.0) * c / N;
     }
 }
 
@@ -96,6 +98,8 @@ static double* upload(const std::vector<double>& v) {
   hipMemcpy(d, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
   return d;
 }
+
+static int walls_create(ocn_model* m, PoissonSolver* s);
 
 PoissonSolver* poisson_create(ocn_model* m) {
   ocn_grid* g = m->g;
@@ -107,29 +111,11 @@ PoissonSolver* poisson_create(ocn_model* m) {
   s->kind = (g->topo[2] == OCN_PERIODIC) ? 0 : 1;
   if (g->topo[0] != OCN_PERIODIC || g->topo[1] != OCN_PERIODIC) {
     s->kind = 4;
-    s->Nxh = s->Nx;
-    size_t n = (size_t)s->Nx * s->Ny * s->Nz;
-    bool ok = hipMalloc((void**)&s->rhs, n * sizeof(double)) == hipSuccess &&
-              hipMalloc((void**)&s->ga, n * sizeof(double2_)) == hipSuccess &&
-              hipMalloc((void**)&s->gb, n * sizeof(double2_)) == hipSuccess;
-    if (ok && g->topo[2] == OCN_BOUNDED) ok = hipMalloc((void**)&s->tscr, n * sizeof(double)) == hipSuccess;
-    for (int d = 0; d < 3 && ok; ++d) {
-      if (g->N[d] == 1 || g->topo[d] == OCN_FLAT) continue;           // identity
-      if (d == 2 && g->topo[2] == OCN_BOUNDED) continue;              // tridiagonal solve instead of a transform
-      std::vector<double2_> f, b;
-      transform_matrices(g->topo[d], g->N[d], f, b);
-      for (int q = 0; q < 2 && ok; ++q) {
-        ok = hipMalloc((void**)&s->gm[d][q], f.size() * sizeof(double2_)) == hipSuccess;
-        if (ok) hipMemcpy(s->gm[d][q], (q ? b : f).data(), f.size() * sizeof(double2_), hipMemcpyHostToDevice);
-      }
-    }
-    if (!ok) {
+    int rc4 = walls_create(m, s);
+    if (rc4) {
       poisson_destroy(s);
       return nullptr;
     }
-    s->lx = upload(eigenvalues(g->topo[0], s->Nx, g->L[0]));
-    s->ly = upload(eigenvalues(g->topo[1], s->Ny, g->L[1]));
-    if (g->topo[2] == OCN_PERIODIC) s->lz = upload(eigenvalues(g->topo[2], s->Nz, g->L[2]));
     return s;
   }
   if (g->dist) {
@@ -259,8 +245,16 @@ void poisson_destroy(PoissonSolver* s) {
   hipFree(s->tb);
   hipFree(s->ga);
   hipFree(s->gb);
-  for (int d = 0; d < 3; ++d)
+  hipFree(s->ra);
+  hipFree(s->rb);
+  for (int d = 0; d < 2; ++d)
     for (int q = 0; q < 2; ++q) hipFree(s->gm[d][q]);
+#ifndef OCN_HOST_EMU
+  if (s->wxf) hipfftDestroy(s->wxf);
+  if (s->wxi) hipfftDestroy(s->wxi);
+  if (s->wz) hipfftDestroy(s->wz);
+  if (s->blas) rocblas_destroy_handle((rocblas_handle)s->blas);
+#endif
   zsolve_destroy(s->zs);
   zslab_destroy(s->zsl);
   hipFree(s->rhs);
@@ -464,29 +458,27 @@ __global__ void k_tridiag(GridDev g, int Nxh, int Ny, int Nz, const double* __re
   }
 }
 
-// ---- any topology: dense transforms (kind 4) ------------------------------------------------------------------------
-// out[.., k, ..] = sum_n M[n][k] in[.., n, ..] along `axis` of a column-major (n0, n1, n2) complex array.
-// One thread per output element; along x consecutive threads read consecutive matrix entries (input-major
-// storage), along y / z consecutive threads read consecutive data and the matrix entry is wave-uniform.
-__global__ void k_dense_axis(int n0, int n1, int n2, int axis, const double2_* __restrict__ M,
-                             const double2_* __restrict__ in, double2_* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+// ---- a Bounded or Flat x / y direction (kind 4) ----------------------------------------------------------------
+// fft_based_poisson_solver.jl:93-120 / fourier_tridiagonal_poisson_solver.jl:67-101 for the topologies beyond
+// (Periodic, Periodic, *).  The reference builds cosine transforms from permuted FFTs + twiddles
+// (discrete_transforms.jl:125-175); here a cosine transform is what it is -- a small dense real matrix applied
+// along one direction of a large array -- and runs as ONE FP64 GEMM on the matrix cores (rocBLAS): N x N
+// times N x (everything else), 2 N flops per element, ~0.15 ms per direction at 256^3, no permutation passes,
+// any N.  Periodic directions keep their FFTs: x as a batched real-to-complex transform (contiguous), z as a
+// strided complex one; a cosine transform in y then acts on the interleaved half spectrum as on a real array
+// with twice as many rows.  x Bounded / Flat with y Periodic is solved on the x <-> y transposed array.
+__global__ void k_transpose_xy(int n0, int n1, int n2, const double* __restrict__ in, double* __restrict__ out) {
+  // out(j, i, k) = in(i, j, k); in is (n0, n1, n2)
+  OCN_SHARED double tile[32][33];
   const int k = blockIdx.z;
-  if (i >= n0 || j >= n1 || k >= n2) return;
-  const size_t s1 = n0, s2 = (size_t)n0 * n1;
-  const size_t c = i + s1 * j + s2 * k;
-  const int N = axis == 0 ? n0 : axis == 1 ? n1 : n2;
-  const int o = axis == 0 ? i : axis == 1 ? j : k;
-  const size_t st = axis == 0 ? 1 : axis == 1 ? s1 : s2;
-  const size_t base = c - (size_t)o * st;
-  double ax = 0, ay = 0;
-  for (int n = 0; n < N; ++n) {
-    const double2_ w = M[(size_t)n * N + o], v = in[base + (size_t)n * st];
-    ax = fma(w.x, v.x, fma(-w.y, v.y, ax));
-    ay = fma(w.x, v.y, fma(w.y, v.x, ay));
-  }
-  out[c] = {ax, ay};
+  int i = blockIdx.x * 32 + threadIdx.x, j = blockIdx.y * 32 + threadIdx.y;
+  for (int r = 0; r < 32; r += 8)
+    if (i < n0 && j + r < n1) tile[threadIdx.y + r][threadIdx.x] = in[i + (size_t)n0 * (j + r + (size_t)n1 * k)];
+  __syncthreads();
+  i = blockIdx.x * 32 + threadIdx.y;
+  j = blockIdx.y * 32 + threadIdx.x;
+  for (int r = 0; r < 32; r += 8)
+    if (i + r < n0 && j < n1) out[j + (size_t)n1 * (i + r + (size_t)n0 * k)] = tile[threadIdx.x][threadIdx.y + r];
 }
 __global__ void k_real_to_complex(size_t n, const double* __restrict__ r, double2_* __restrict__ c) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -497,46 +489,239 @@ __global__ void k_complex_to_real(size_t n, const double2_* __restrict__ c, doub
   if (i < n) r[i] = c[i].x;
 }
 
-// fft_based_poisson_solver.jl:93-120 / fourier_tridiagonal_poisson_solver.jl:67-101 for any (x, y, z) topology:
-// forward transforms direction by direction, eigenvalue division (or the tridiagonal solve down a Bounded z),
-// inverse transforms, real part.
-static int run_general(ocn_model* m) {
+#ifdef OCN_HOST_EMU
+static void emu_x_r2c(const double* in, double2_* out, int Nx, int Nxh, size_t lines) {
+  for (size_t L = 0; L < lines; ++L)
+    for (int k = 0; k < Nxh; ++k) {
+      cplx acc = 0;
+      for (int n = 0; n < Nx; ++n) {
+        double ang = -2.0 * M_PI * ((long)n * k % Nx) / Nx;
+        acc += in[n + Nx * L] * cplx(cos(ang), sin(ang));
+      }
+      out[k + Nxh * L] = {acc.real(), acc.imag()};
+    }
+}
+static void emu_x_c2r(const double2_* in, double* out, int Nx, int Nxh, size_t lines) {
+  std::vector<cplx> full(Nx);
+  for (size_t L = 0; L < lines; ++L) {
+    for (int i = 0; i < Nx; ++i) {
+      double2_ q = in[(i < Nxh ? i : Nx - i) + Nxh * L];
+      full[i] = cplx(q.x, i < Nxh ? q.y : -q.y);
+    }
+    for (int n = 0; n < Nx; ++n) {
+      cplx acc = 0;
+      for (int i = 0; i < Nx; ++i) {
+        double ang = 2.0 * M_PI * ((long)i * n % Nx) / Nx;
+        acc += full[i] * cplx(cos(ang), sin(ang));
+      }
+      out[n + Nx * L] = acc.real();
+    }
+  }
+}
+#endif
+
+// C(m x n) = A(m x k) * op(B), column-major, batched over `batch` with strides (0 = shared operand)
+static int walls_gemm(ocn_model* m, bool transB, int M, int N, int K, const double* A, int lda, long sA, const double* B,
+                      int ldb, double* C, int ldc, long sC, int batch) {
+#ifndef OCN_HOST_EMU
+  const double one = 1.0, zero = 0.0;
+  rocblas_status st = rocblas_dgemm_strided_batched(
+      (rocblas_handle)m->solver->blas, rocblas_operation_none, transB ? rocblas_operation_transpose : rocblas_operation_none,
+      M, N, K, &one, A, lda, sA, B, ldb, 0, &zero, C, ldc, sC, batch);
+  if (st != rocblas_status_success) {
+    ocn_set_error(m->ctx, "rocblas_dgemm_strided_batched failed (%d)", (int)st);
+    return OCN_EHIP;
+  }
+#else
+  for (int b = 0; b < batch; ++b)
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i < M; ++i) {
+        double acc = 0;
+        for (int q = 0; q < K; ++q)
+          acc += A[i + (size_t)lda * q + (size_t)sA * b] * (transB ? B[j + (size_t)ldb * q] : B[q + (size_t)ldb * j]);
+        C[i + (size_t)ldc * j + (size_t)sC * b] = acc;
+      }
+#endif
+  return OCN_OK;
+}
+
+static int walls_create(ocn_model* m, PoissonSolver* s) {
+  ocn_grid* g = m->g;
+  // x Bounded / Flat with y Periodic: swap the horizontal directions so that the Periodic one is contiguous
+  s->tr = g->topo[0] != OCN_PERIODIC && g->topo[1] == OCN_PERIODIC;
+  const int a = s->tr ? 1 : 0, b = s->tr ? 0 : 1;
+  s->gNx = g->N[a];
+  s->gNy = g->N[b];
+  s->gtopo[0] = g->topo[a];
+  s->gtopo[1] = g->topo[b];
+  const bool xper = s->gtopo[0] == OCN_PERIODIC && s->gNx > 1;
+  s->gR = xper ? s->gNx / 2 + 1 : s->gNx;
+  s->Nxh = s->gR;
+  const size_t nr = (size_t)s->gNx * s->gNy * s->Nz, nc = (size_t)s->gR * s->gNy * s->Nz;
+  if (hipMalloc((void**)&s->rhs, nr * sizeof(double)) != hipSuccess || hipMalloc((void**)&s->ra, nr * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&s->rb, nr * sizeof(double)) != hipSuccess || hipMalloc((void**)&s->ga, nc * sizeof(double2_)) != hipSuccess ||
+      hipMalloc((void**)&s->gb, nc * sizeof(double2_)) != hipSuccess)
+    return OCN_ENOMEM;
+  if (g->topo[2] == OCN_BOUNDED && hipMalloc((void**)&s->tscr, nc * sizeof(double)) != hipSuccess) return OCN_ENOMEM;
+  for (int d = 0; d < 2; ++d) {
+    const int N = d == 0 ? s->gNx : s->gNy;
+    if (s->gtopo[d] != OCN_BOUNDED || N == 1) continue;
+    std::vector<double> F, I;
+    cosine_matrices(N, F, I);
+    s->gm[d][0] = upload(F);
+    s->gm[d][1] = upload(I);
+    if (!s->gm[d][0] || !s->gm[d][1]) return OCN_ENOMEM;
+  }
+  std::vector<double> lx = eigenvalues(s->gtopo[0], s->gNx, g->L[a]);
+  lx.resize(s->gR);
+  s->lx = upload(lx);
+  s->ly = upload(eigenvalues(s->gtopo[1], s->gNy, g->L[b]));
+  if (g->topo[2] == OCN_PERIODIC) s->lz = upload(eigenvalues(OCN_PERIODIC, s->Nz, g->L[2]));
+#ifndef OCN_HOST_EMU
+  rocblas_handle h = nullptr;
+  if (rocblas_create_handle(&h) != rocblas_status_success) {
+    ocn_set_error(m->ctx, "rocblas_create_handle failed");
+    return OCN_EHIP;
+  }
+  s->blas = h;
+  rocblas_set_stream(h, m->ctx->stream);
+  const int lines = s->gNy * s->Nz;
+  if (xper) {
+    int nx[1] = {s->gNx};
+    if (hipfftPlanMany(&s->wxf, 1, nx, nullptr, 1, s->gNx, nullptr, 1, s->gR, HIPFFT_D2Z, lines) != HIPFFT_SUCCESS ||
+        hipfftPlanMany(&s->wxi, 1, nx, nullptr, 1, s->gR, nullptr, 1, s->gNx, HIPFFT_Z2D, lines) != HIPFFT_SUCCESS) {
+      ocn_set_error(m->ctx, "hipfft x-plan creation failed");
+      return OCN_EHIP;
+    }
+    hipfftSetStream(s->wxf, m->ctx->stream);
+    hipfftSetStream(s->wxi, m->ctx->stream);
+  }
+  if (g->topo[2] == OCN_PERIODIC && s->Nz > 1) {
+    int nz[1] = {s->Nz};
+    int st = s->gR * s->gNy;
+    if (hipfftPlanMany(&s->wz, 1, nz, nz, st, 1, nz, st, 1, HIPFFT_Z2Z, st) != HIPFFT_SUCCESS) {
+      ocn_set_error(m->ctx, "hipfft z-plan creation failed");
+      return OCN_EHIP;
+    }
+    hipfftSetStream(s->wz, m->ctx->stream);
+  }
+#endif
+  return OCN_OK;
+}
+
+static int run_walls(ocn_model* m) {
   PoissonSolver* s = m->solver;
   hipStream_t st = m->ctx->stream;
-  const size_t n = (size_t)s->Nx * s->Ny * s->Nz;
-  const dim3 b(64, 4, 1), gr((s->Nx + 63) / 64, (s->Ny + 3) / 4, s->Nz);
-  const dim3 b1(256, 1, 1), g1((unsigned)((n + 255) / 256), 1, 1);
+  const int Nx = s->gNx, Ny = s->gNy, Nz = s->Nz, R = s->gR;
+  const size_t nr = (size_t)Nx * Ny * Nz, nc = (size_t)R * Ny * Nz;
+  const bool xper = s->gtopo[0] == OCN_PERIODIC && Nx > 1, zper = m->g->topo[2] == OCN_PERIODIC && Nz > 1;
+  const dim3 b1(256, 1, 1);
+  auto g1 = [&](size_t n) { return dim3((unsigned)((n + 255) / 256), 1, 1); };
+  const dim3 tb(32, 8, 1);
+  int rc = OCN_OK;
+  double* real = s->rhs;          // where the real array currently lives
   double2_ *cur = s->ga, *oth = s->gb;
-  auto pass = [&](int axis, int inverse) {
-    if (!s->gm[axis][inverse]) return;
-    ocn_launch(k_dense_axis, gr, b, st, s->Nx, s->Ny, s->Nz, axis, (const double2_*)s->gm[axis][inverse],
-               (const double2_*)cur, oth);
-    std::swap(cur, oth);
-  };
   {
     ProfScope ps(m->ctx, "fft_forward");
-    ocn_launch(k_real_to_complex, g1, b1, st, n, (const double*)s->rhs, cur);
-    pass(0, 0);
-    pass(1, 0);
-    pass(2, 0);
+    if (s->tr) {   // (Ny_orig = gNx ...): rhs is (gNy, gNx, Nz) in memory -> (gNx, gNy, Nz)
+      ocn_launch_sync(k_transpose_xy, dim3((Ny + 31) / 32, (Nx + 31) / 32, Nz), tb, st, Ny, Nx, Nz, (const double*)real, s->ra);
+      real = s->ra;
+    }
+    if (s->gm[0][0]) {   // cosine transform along x: F (Nx x Nx) * A (Nx x Ny Nz)
+      double* out = real == s->ra ? s->rb : s->ra;
+      if ((rc = walls_gemm(m, false, Nx, Ny * Nz, Nx, s->gm[0][0], Nx, 0, real, Nx, out, Nx, 0, 1))) return rc;
+      real = out;
+    }
+    if (xper) {
+#ifndef OCN_HOST_EMU
+      if (hipfftExecD2Z(s->wxf, real, (hipfftDoubleComplex*)cur) != HIPFFT_SUCCESS) {
+        ocn_set_error(m->ctx, "hipfftExecD2Z failed");
+        return OCN_EHIP;
+      }
+#else
+      emu_x_r2c(real, cur, Nx, R, (size_t)Ny * Nz);
+#endif
+    } else {
+      ocn_launch(k_real_to_complex, g1(nr), b1, st, nr, (const double*)real, cur);
+    }
+    if (s->gm[1][0]) {   // cosine transform along y on (2R x Ny) planes: A * F^T
+      if ((rc = walls_gemm(m, true, 2 * R, Ny, Ny, (const double*)cur, 2 * R, (long)2 * R * Ny, s->gm[1][0], Ny, (double*)oth,
+                           2 * R, (long)2 * R * Ny, Nz)))
+        return rc;
+      std::swap(cur, oth);
+    }
   }
   {
     ProfScope ps(m->ctx, "spectral_solve");
+    const dim3 b(64, 4, 1);
+    const double norm = 1.0 / ((xper ? (double)Nx : 1.0) * (zper ? (double)Nz : 1.0));
     if (m->g->topo[2] == OCN_BOUNDED) {
-      dim3 g2((s->Nx + 63) / 64, (s->Ny + 3) / 4, 1);
-      ocn_launch(k_tridiag, g2, b, st, m->gd, s->Nx, s->Ny, s->Nz, (const double*)s->lx, (const double*)s->ly, 1.0, cur,
-                 s->tscr);
+      ocn_launch(k_tridiag, dim3((R + 63) / 64, (Ny + 3) / 4, 1), b, st, m->gd, R, Ny, Nz, (const double*)s->lx,
+                 (const double*)s->ly, norm, cur, s->tscr);
     } else {
-      ocn_launch(k_scale_spectrum, gr, b, st, s->Nx, s->Ny, s->Nz, (const double*)s->lx, (const double*)s->ly,
-                 (const double*)s->lz, 1.0, cur);
+      if (zper) {
+#ifndef OCN_HOST_EMU
+        if (hipfftExecZ2Z(s->wz, (hipfftDoubleComplex*)cur, (hipfftDoubleComplex*)cur, HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
+          ocn_set_error(m->ctx, "hipfftExecZ2Z failed");
+          return OCN_EHIP;
+        }
+#else
+        {
+          std::vector<cplx> a(nc);
+          for (size_t i = 0; i < nc; ++i) a[i] = cplx(cur[i].x, cur[i].y);
+          emu_dft_axis(a, R, Ny, Nz, 2, -1);
+          for (size_t i = 0; i < nc; ++i) cur[i] = {a[i].real(), a[i].imag()};
+        }
+#endif
+      }
+      ocn_launch(k_scale_spectrum, dim3((R + 63) / 64, (Ny + 3) / 4, Nz), b, st, R, Ny, Nz, (const double*)s->lx,
+                 (const double*)s->ly, (const double*)(zper ? s->lz : nullptr), norm, cur);
+      if (zper) {
+#ifndef OCN_HOST_EMU
+        if (hipfftExecZ2Z(s->wz, (hipfftDoubleComplex*)cur, (hipfftDoubleComplex*)cur, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) {
+          ocn_set_error(m->ctx, "hipfftExecZ2Z failed");
+          return OCN_EHIP;
+        }
+#else
+        {
+          std::vector<cplx> a(nc);
+          for (size_t i = 0; i < nc; ++i) a[i] = cplx(cur[i].x, cur[i].y);
+          emu_dft_axis(a, R, Ny, Nz, 2, +1);
+          for (size_t i = 0; i < nc; ++i) cur[i] = {a[i].real(), a[i].imag()};
+        }
+#endif
+      }
     }
   }
   {
     ProfScope ps(m->ctx, "fft_backward");
-    pass(2, 1);
-    pass(1, 1);
-    pass(0, 1);
-    ocn_launch(k_complex_to_real, g1, b1, st, n, (const double2_*)cur, s->rhs);
+    if (s->gm[1][1]) {
+      if ((rc = walls_gemm(m, true, 2 * R, Ny, Ny, (const double*)cur, 2 * R, (long)2 * R * Ny, s->gm[1][1], Ny, (double*)oth,
+                           2 * R, (long)2 * R * Ny, Nz)))
+        return rc;
+      std::swap(cur, oth);
+    }
+    // back to a real array; the last stage writes s->rhs directly when no further pass follows
+    const bool more = s->gm[0][1] != nullptr || s->tr;
+    real = more ? s->ra : s->rhs;
+    if (xper) {
+#ifndef OCN_HOST_EMU
+      if (hipfftExecZ2D(s->wxi, (hipfftDoubleComplex*)cur, real) != HIPFFT_SUCCESS) {
+        ocn_set_error(m->ctx, "hipfftExecZ2D failed");
+        return OCN_EHIP;
+      }
+#else
+      emu_x_c2r(cur, real, Nx, R, (size_t)Ny * Nz);
+#endif
+    } else {
+      ocn_launch(k_complex_to_real, g1(nr), b1, st, nr, (const double2_*)cur, real);
+    }
+    if (s->gm[0][1]) {
+      double* out = s->tr ? s->rb : s->rhs;
+      if ((rc = walls_gemm(m, false, Nx, Ny * Nz, Nx, s->gm[0][1], Nx, 0, real, Nx, out, Nx, 0, 1))) return rc;
+      real = out;
+    }
+    if (s->tr) ocn_launch_sync(k_transpose_xy, dim3((Nx + 31) / 32, (Ny + 31) / 32, Nz), tb, st, Nx, Ny, Nz, (const double*)real, s->rhs);
   }
   return OCN_OK;
 }
@@ -544,7 +729,7 @@ static int run_general(ocn_model* m) {
 static int run_solver(ocn_model* m) {
   PoissonSolver* s = m->solver;
   hipStream_t st = m->ctx->stream;
-  if (s->kind == 4) return run_general(m);
+  if (s->kind == 4) return run_walls(m);
   {
     ProfScope ps(m->ctx, "fft_forward");
 #ifndef OCN_HOST_EMU
