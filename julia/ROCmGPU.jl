@@ -67,11 +67,19 @@ end
 # forcings, Stokes drift, background fields and function-valued BCs are rejected here (not representable).
 # ... (field-by-field, as clima-oceananigans.jl_amd/api.py does for the Python mirror)
 
-# Field data alias the library's parent arrays (same layout as Grids/new_data.jl:33-61):
+# Field data alias the library's parent arrays (same layout as Grids/new_data.jl:33-61).  With walls or slices in
+# x / y the allocation is pitched: ocn_field_layout gives element strides and the origin of the logical parent.
+# G^n / G^- / fast-path tracers rotate buffers: call this again after every time_step! for those fields.
 function alias_field_data(model_handle, field_id, grid, loc)
     p = ccall((:ocn_field_device_ptr, libocnhip), Ptr{Float64}, (Ptr{Cvoid}, Cint), model_handle, field_id)
+    st = zeros(Int64, 3); org = Ref(Int64(0))
+    ccall((:ocn_field_layout, libocnhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}, Ref{Int64}), model_handle, field_id, st, org)
     T = Oceananigans.Grids.total_size(loc, grid)
-    return Oceananigans.Grids.offset_data(ROCArray{Float64, 3}(p, T), grid, loc)
+    Px, Py = st[2], st[3] ÷ st[2]
+    whole = unsafe_wrap(ROCArray, p, (Px, Py, T[3]))
+    ox, oy = org[] % Px, org[] ÷ Px
+    parent = (Px, Py) == T[1:2] ? whole : view(whole, ox .+ (1:T[1]), oy .+ (1:T[2]), :)
+    return Oceananigans.Grids.offset_data(parent, grid, loc)
 end
 
 # ---- phase-level overloads (each is ONE ccall) ---------------------------------------------------------------

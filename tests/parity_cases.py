@@ -76,10 +76,39 @@ CASES = {
     "pfp_weno_slice": dict(size=(12, 8), topo=(P, F, P), extent=(1, 1), adv="WENO5", stepper="AB2", steps=2, dt=2e-3),
     "bbf_weno_box": dict(size=(10, 12), topo=(B, B, F), extent=(1, 1), adv="WENO5", stepper="RK3", steps=2, dt=5e-3,
                          closure=(1e-4, 0.0)),
+    # The reference's regression-test configurations (test/regression_tests/*.jl).  Their stored fields are remote
+    # DataDeps (test/data_dependencies.jl) and cannot be fetched here; the same set-ups pin HIP against the oracle.
+    "regr_thermal_bubble_regular": dict(size=(16, 16, 16), topo=(P, P, B), extent=(100, 100, 100), halo=(1, 1, 1), adv="C2",
+                                        stepper="AB2", steps=10, dt=6.0, tracers=("T", "S"), closure=(4e-2, 4e-2),
+                                        coriolis=1e-4, buoyancy="TS", eos=(1.67e-4, 7.8e-4), init="thermal_bubble",
+                                        # pHY' carries the O(25) hydrostatic load of T = 9.85, S = 35 while the dynamics
+                                        # come from a 0.01 K anomaly: tendencies are differences of nearly equal numbers
+                                        tol=5e-10),
+    "regr_thermal_bubble_unstretched": dict(size=(16, 16, 16), topo=(P, P, B), xy=((0, 100), (0, 100)),
+                                            zfaces=list(np.linspace(-100, 0, 17)), halo=(1, 1, 1), adv="C2", stepper="AB2",
+                                            steps=10, dt=6.0, tracers=("T", "S"), closure=(4e-2, 4e-2), coriolis=1e-4,
+                                            buoyancy="TS", eos=(1.67e-4, 7.8e-4), init="thermal_bubble", tol=5e-10),
+    "regr_ocean_les_amd": dict(size=(16, 16, 16), topo=(P, P, B), extent=(16, 16, 16), halo=(1, 1, 1), adv="C2", stepper="AB2",
+                               steps=10, dt=2.0, tracers=("T", "S"), closure="amd", coriolis=1e-4, buoyancy="TS",
+                               eos=(2e-4, 8e-4), init="ocean_les",
+                               # S starts uniform: kappa_e(S) = -C d2 theta/sigma is then a ratio of round-off sized
+                               # gradients wherever the surface flux has not reached, i.e. ill-conditioned in any
+                               # implementation (the reference compares this run with isapprox as well)
+                               tol=2e-9,
+                               bcs={"u": {"top": ("flux", -2e-5)}, "T": {"top": ("flux", 5e-5), "bottom": ("gradient", 0.005)},
+                                    "S": {"top": ("flux", 5e-8)}}),
     # two-dimensional turbulence (BASELINE config 1): Flat z
     "ppf_weno_rk3": dict(size=(16, 16), topo=(P, P, F), extent=(2 * np.pi, 2 * np.pi), adv="WENO5", stepper="RK3",
                          steps=2, dt=0.05, closure=(1e-5, 0.0)),
 }
+
+
+def _nodes(m, name, mod):
+    if mod is O:
+        f = m.w if name == "w" else m.tracers[name]
+        g = m.grid
+        return g.xnodes(f.loc[0]).reshape(-1, 1, 1), g.ynodes(f.loc[1]).reshape(1, -1, 1), g.znodes(f.loc[2]).reshape(1, 1, -1)
+    return m.nodes(name)
 
 
 def _full_size(cfg):
@@ -106,7 +135,8 @@ def build(mod, cfg, rng_seed=1234):
     if cfg.get("coriolis"):
         mk["coriolis"] = mod.FPlane(cfg["coriolis"])
     if cfg.get("buoyancy") == "TS":
-        mk["buoyancy"] = mod.SeawaterBuoyancy(thermal_expansion=2e-1, haline_contraction=8e-1)
+        a_, b_ = cfg.get("eos", (2e-1, 8e-1))
+        mk["buoyancy"] = mod.SeawaterBuoyancy(thermal_expansion=a_, haline_contraction=b_)
     elif cfg.get("buoyancy") == "b":
         mk["buoyancy"] = mod.BuoyancyTracer()
     if cfg.get("bcs"):
@@ -126,6 +156,22 @@ def build(mod, cfg, rng_seed=1234):
                                 tracers=cfg.get("tracers", ()), **mk)
     rng = np.random.default_rng(rng_seed)
     init = {}
+    if cfg.get("init") == "thermal_bubble":      # thermal_bubble_regression_test.jl:17-27
+        Nx, Ny, Nz = cfg["size"]
+        T = np.full((Nx, Ny, Nz), 9.85)
+        T[round(Nx / 4) - 1:round(3 * Nx / 4), round(Ny / 4) - 1:round(3 * Ny / 4), round(Nz / 4) - 1:round(3 * Nz / 4)] += 0.01
+        mod.set_model(m, T=T, S=35.0)
+        return m
+    if cfg.get("init") == "ocean_les":           # ocean_large_eddy_simulation_regression_test.jl:52-56
+        Lz, dTdz, Qu = 16.0, 0.005, -2e-5
+        xi = lambda z: rng.standard_normal(z.shape) * z / Lz * (1 + z / Lz)    # noqa: E731
+        _, _, zc = _nodes(m, "T", mod)
+        _, _, zw = _nodes(m, "w", mod)
+        shp = m.u.interior().shape
+        zc3, zw3 = zc + np.zeros(shp), zw + np.zeros(m.w.interior().shape)
+        mod.set_model(m, u=np.sqrt(abs(Qu)) * 1e-3 * xi(zc3), w=np.sqrt(abs(Qu)) * 1e-3 * xi(zw3),
+                      T=20 + dTdz * zc3 + dTdz * Lz * 1e-2 * xi(zc3), S=35.0)
+        return m
     for n in ("u", "v", "w"):
         if n == "w" and cfg["topo"][2] == F:
             continue

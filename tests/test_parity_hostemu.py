@@ -11,5 +11,5 @@ def test_case_matches_oracle(ocn, backend, name):
     if backend != "hostemu":
         pytest.skip("host-emulation run only")
     worst = run_case(ocn, name)
-    bad = {k: v for k, v in worst.items() if v > 2e-11}
+    bad = {k: v for k, v in worst.items() if v > CASES[name].get("tol", 2e-11)}
     assert not bad, bad
