@@ -25,8 +25,16 @@ struct Phys {
   double g, alpha, beta;
 };
 
-static inline dim3 grid3(const GridDev& g, dim3 b) {
-  return dim3((g.Nx + b.x - 1) / b.x, (g.Ny + b.y - 1) / b.y, (g.Nz + b.z - 1) / b.z);
+// workgroup shape of the one-thread-per-cell kernels; OCNHIP_<NAME>_BLOCK=bx,by,bz overrides (tuning)
+static dim3 tuned_block(const char* env, dim3 def) {
+  const char* e = getenv(env);
+  int x, y, z;
+  if (e && sscanf(e, "%d,%d,%d", &x, &y, &z) == 3 && x > 0 && y > 0 && z == 1 && x * y <= 1024) return dim3(x, y, 1);
+  return def;
+}
+
+static inline dim3 grid3(const GridDev& g, dim3 b) {   // workgroups are one level thick (b.z == 1)
+  return dim3((g.Nx + b.x - 1) / b.x, (g.Ny + b.y - 1) / b.y, g.Nz);
 }
 
 // viscosity at the four stress locations (closure_kernel_operators.jl:72-90)
@@ -47,7 +55,7 @@ __global__ void k_tend_uvw(GridDev g, Phys ph, const double* __restrict__ u, con
                            double* __restrict__ Gw) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long sy = g.sy, sz = g.sz;
   const long c = i + j * sy + k * sz;
@@ -149,7 +157,7 @@ __global__ void k_tend_c(GridDev g, const double* __restrict__ u, const double* 
                          const double* __restrict__ kap_e, int closure, double* __restrict__ Gc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long sy = g.sy, sz = g.sz;
   const long c = i + j * sy + k * sz;
@@ -221,7 +229,8 @@ void launch_tendencies(ocn_model* m) {
   ph.f = m->d.f;
   ph.pH = m->pHY.present ? m->pHY.interior() : nullptr;
   ph.nu_e = m->nu_e.present ? m->nu_e.interior() : nullptr;
-  dim3 b(64, 4, 1), gr = grid3(g, b);
+  static const dim3 b = tuned_block("OCNHIP_TEND_BLOCK", dim3(64, 4, 1));
+  const dim3 gr = grid3(g, b);
   const double *u = m->u.interior(), *v = m->v.interior(), *w = m->w.interior();
   double *Gu = m->Gn[0].interior(), *Gv = m->Gn[1].interior(), *Gw = m->Gn[2].interior();
 #define TEND_LAUNCH(A, W)                                                       \
@@ -278,7 +287,7 @@ struct StepPtrs {
 __global__ void k_step(GridDev g, StepPtrs P, double dt, double cn, double cm, int use_m) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long c = i + j * g.sy + k * g.sz;
   for (int f = 0; f < P.n; ++f) {
@@ -312,7 +321,7 @@ struct CopyPtrs {
 __global__ void k_copy_interior(GridDev g, CopyPtrs P) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long c = i + j * g.sy + k * g.sz;
   for (int f = 0; f < P.n; ++f) P.dst[f][c] = P.src[f][c];
@@ -467,7 +476,7 @@ __global__ void k_rhs(GridDev g, const double* __restrict__ u, const double* __r
                       const double* __restrict__ w, double rdt, int mult_dz, double* __restrict__ rhs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long c = i + j * g.sy + k * g.sz;
   double dzc = g.zflat ? 1.0 : g_dzc(g, k);
@@ -490,7 +499,7 @@ __global__ void k_pcorrect(GridDev g, const double* __restrict__ p, double dt, d
                            double* __restrict__ v, double* __restrict__ w) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long c = i + j * g.sy + k * g.sz;
   double pc = p[c];
@@ -551,7 +560,7 @@ void launch_hydrostatic(ocn_model* m) {
 __global__ void k_copy_to_field(GridDev g, const double* __restrict__ src, double* __restrict__ dst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z * blockDim.z + threadIdx.z;
+  const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   dst[i + j * g.sy + k * g.sz] = src[i + (long)g.Nx * (j + (long)g.Ny * k)];
 }
@@ -634,7 +643,7 @@ __global__ void k_amd_all(AmdCtx a, double Cnu, double* __restrict__ nu, AmdTrac
   const GridDev& g = a.g;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
+  const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long sy = a.sy, sz = a.sz;
   const long c = i + j * sy + k * sz;
@@ -713,7 +722,8 @@ void launch_amd(ocn_model* m) {
   a.u = m->u.interior(); a.v = m->v.interior(); a.w = m->w.interior();
   a.sy = g.sy; a.sz = g.sz; a.rdx = g.rdx; a.rdy = g.rdy;
   a.Dx = 2.0 * g.dx; a.Dy = 2.0 * g.dy;
-  dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+  static const dim3 b = tuned_block("OCNHIP_AMD_BLOCK", dim3(64, 4, 1));
+  const dim3 gr = grid3(g, b);
   AmdTracers T;
   T.n = m->nt;
   for (int t = 0; t < m->nt; ++t) {

@@ -62,6 +62,24 @@ template <int S> OCN_DEVFN void dft16(cd* v) {
     }
 }
 
+// 16 x 16 x 16 transpose through LDS in two halves (real parts, then imaginary parts): 32 KB per workgroup
+// instead of 64, so four workgroups fit a CU and twice as many loads are in flight (these passes are
+// HBM-latency bound).  wi(q) / ri(q): element index written / read for register q.
+template <class WI, class RI>
+OCN_DEVFN void transpose_halves(double* sm, cd* v, WI wi, RI ri) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) sm[wi(q)] = v[q].x;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q].x = sm[ri(q)];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) sm[wi(q)] = v[q].y;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q].y = sm[ri(q)];
+}
+
 // `a`: (ncol, 256) complex, element (col, z) at a[col + ncol * z].  lxy[col]: lx + ly of the column.
 // lz[kz]; tw256[m] = exp(-2 pi i m / 256).  zero_col: flattened column whose kz = 0 mode is set to 0 (or -1).
 __global__ void __launch_bounds__(256) k_zsolve256(cd* __restrict__ a, long ncol, const double* __restrict__ lxy,
@@ -122,7 +140,7 @@ __global__ void __launch_bounds__(256) k_zsolve256(cd* __restrict__ a, long ncol
 // Nxh % 16 left-over kx columns are tiled over the flattened (kx_left, z) index.
 template <int S>
 __global__ void __launch_bounds__(256) k_yfft256(cd* __restrict__ a, int Nxh, int Nz, const cd* __restrict__ tw256) {
-  OCN_SHARED cd sm[16 * 16 * 16];
+  OCN_SHARED double sm[16 * 16 * 16];
   const int t = threadIdx.x;
   const int col = t & 15, r = t >> 4;
   const int nfull = Nxh / 16, left = Nxh - 16 * nfull;
@@ -149,12 +167,8 @@ __global__ void __launch_bounds__(256) k_yfft256(cd* __restrict__ a, int Nxh, in
     if (S < 0) w.y = -w.y;
     v[k1] = cmul(v[k1], w);
   }
-#pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) sm[(k1 * 16 + r) * 16 + col] = v[k1];
-  __syncthreads();
-#pragma unroll
-  for (int n2 = 0; n2 < 16; ++n2) v[n2] = sm[(r * 16 + n2) * 16 + col];   // r = k1 now
-  dft16<S>(v);                                                            // v[k2] = X[k1 + 16 k2]
+  transpose_halves(sm, v, [&](int k1) { return (k1 * 16 + r) * 16 + col; }, [&](int n2) { return (r * 16 + n2) * 16 + col; });
+  dft16<S>(v);                                                            // r = k1 now; v[k2] = X[k1 + 16 k2]
   if (ok) {
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) a[base + (long)Nxh * (r + 16 * k2)] = v[k2];
@@ -168,7 +182,7 @@ __global__ void __launch_bounds__(256) k_yfft256(cd* __restrict__ a, int Nxh, in
 __global__ void __launch_bounds__(256) k_xfft_rhs256(GridDev g, const double* __restrict__ us, const double* __restrict__ vs,
                                                      const double* __restrict__ ws, double rdt, int zwrap,
                                                      cd* __restrict__ spec, const cd* __restrict__ tw256) {
-  OCN_SHARED cd sm[16 * 16 * 16];
+  OCN_SHARED double sm[16 * 16 * 16];
   const int t = threadIdx.x;
   const int r = t & 15, ln = t >> 4;              // r = x mod 16 (loads) / k1 (stores); ln = line inside the tile
   const long L = (long)blockIdx.x * 16 + ln;      // line index j + Ny k
@@ -192,11 +206,7 @@ __global__ void __launch_bounds__(256) k_xfft_rhs256(GridDev g, const double* __
   dft16<1>(v);
 #pragma unroll
   for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], tw256[(r * k1) & 255]);
-#pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) sm[(k1 * 16 + r) * 16 + ln] = v[k1];
-  __syncthreads();
-#pragma unroll
-  for (int n2 = 0; n2 < 16; ++n2) v[n2] = sm[(r * 16 + n2) * 16 + ln];
+  transpose_halves(sm, v, [&](int k1) { return (k1 * 16 + r) * 16 + ln; }, [&](int n2) { return (r * 16 + n2) * 16 + ln; });
   dft16<1>(v);                                    // v[k2] = X[k1 + 16 k2], k1 = r
   if (ok) {
     cd* out = spec + L * 129;

@@ -37,6 +37,31 @@ def test_medium_weno_trajectory(ocn):
         assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max()
 
 
+@pytest.mark.parametrize("N,stepper,tracers", [((256, 256, 8), "AB2", ()), ((256, 256, 12), "RK3", ("c",)),
+                                               ((16, 12, 256), "AB2", ()), ((64, 256, 256), "RK3", ())])
+def test_headline_kernels_vs_oracle(ocn, N, stepper, tracers):
+    """Triply periodic WENO5 on the shapes that select the headline kernels -- 256-point x / y passes with the fused
+    right-hand side (Nx = Ny = 256), the fused z stage (Nz = 256), the tiled tendency kernel at full row width --
+    compared with the oracle field by field (the full 256^3 takes the oracle minutes per step: properties only)."""
+    import oracle as O
+    Nz = N[2]
+    rng = np.random.default_rng(5)
+    init = {n: rng.random(N) - 0.5 for n in "uvw"}
+    init.update({t: rng.random(N) for t in tracers})
+    kw = dict(size=N, extent=(1, 1, Nz / 256), topology=("Periodic",) * 3)
+    m = ocn.NonhydrostaticModel(ocn.RectilinearGrid(**kw), advection=ocn.WENO5(), timestepper=stepper, tracers=tracers)
+    om = O.NonhydrostaticModel(O.RectilinearGrid(**kw), advection=O.WENO5(), timestepper=stepper, tracers=tracers)
+    ocn.set_model(m, **init)
+    O.set_model(om, **init)
+    dt = 0.2 / 256 / np.abs(om.u.data).max()
+    for _ in range(2):
+        ocn.time_step(m, dt)
+        O.time_step(om, dt)
+    pairs = [(m.u, om.u), (m.v, om.v), (m.w, om.w), (m.pNHS, om.pNHS)] + [(m.tracers[t], om.tracers[t]) for t in tracers]
+    for a, b in pairs:
+        assert np.abs(a.parent() - b.data).max() <= 2e-11 * np.abs(b.data).max()
+
+
 def test_full_size_properties(ocn):
     """BASELINE config 2 (256^3, WENO5, AB2): projection leaves max|div U| ~ roundoff, halos are periodic
     images, and the Poisson solve satisfies lap(phi) = R to roundoff."""
