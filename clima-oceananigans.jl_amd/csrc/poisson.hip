@@ -413,38 +413,63 @@ __global__ void k_tridiag(GridDev g, int Nxh, int Ny, int Nz, const double* __re
     double lo = (k > 0) ? 1.0 / g_dzf(g, k) : 0.0;
     return -(up + lo) - g_dzc(g, k) * lam;
   };
+  // Only Nxh*Ny threads exist (a few waves per CU) and every level depends on the one before, so the sweep is
+  // load-latency bound: right-hand sides are fetched PF levels ahead of the recurrence that consumes them.
+  // (Splitting real and imaginary parts over two threads was measured slower: the second copy of the
+  // elimination factors costs more traffic than the extra parallelism returns.)
+  constexpr int PF = 8;
   double beta = diag(0);
   double2_ f = a[col];
   double2_ prev = {f.x * norm / beta, f.y * norm / beta};
   a[col] = prev;
   int kbreak = Nz;
-  for (int k = 1; k < Nz; ++k) {
-    double off = 1.0 / g_dzf(g, k);  // a^{k-1} = c^{k-1} = 1/dzf(k) (1-based face k+1 -> 0-based face k)
-    double tk = off / beta;
-    t[col + ncol * k] = tk;
-    beta = diag(k) - off * tk;
-    if (!(fabs(beta) > 10.0 * 2.220446049250313e-16)) {  // reference `break` (:113-114)
-      kbreak = k;
-      break;
+  for (int k0 = 1; k0 < Nz && kbreak == Nz; k0 += PF) {
+    double2_ fb[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+      if (k0 + q < Nz) fb[q] = a[col + ncol * (k0 + q)];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int k = k0 + q;
+      if (k >= Nz || kbreak != Nz) break;
+      double off = 1.0 / g_dzf(g, k);  // a^{k-1} = c^{k-1} = 1/dzf(k) (1-based face k+1 -> 0-based face k)
+      double tk = off / beta;
+      t[col + ncol * k] = tk;
+      beta = diag(k) - off * tk;
+      if (!(fabs(beta) > 10.0 * 2.220446049250313e-16)) {  // reference `break` (:113-114)
+        kbreak = k;
+        break;
+      }
+      double2_ cur = {(fb[q].x * norm - off * prev.x) / beta, (fb[q].y * norm - off * prev.y) / beta};
+      a[col + ncol * k] = cur;
+      prev = cur;
     }
-    f = a[col + ncol * k];
-    double2_ cur = {(f.x * norm - off * prev.x) / beta, (f.y * norm - off * prev.y) / beta};
-    a[col + ncol * k] = cur;
-    prev = cur;
   }
   for (int k = kbreak; k < Nz; ++k) a[col + ncol * k] = {0.0, 0.0};  // deterministic stand-in for the stale storage
   for (int k = kbreak + 1; k < Nz; ++k) t[col + ncol * k] = 0.0;
   double2_ nxt = a[col + ncol * (Nz - 1)];
   double sx = nxt.x, sy_ = nxt.y;
-  for (int k = Nz - 2; k >= 0; --k) {
-    double tk = t[col + ncol * (k + 1)];
-    double2_ cur = a[col + ncol * k];
-    cur.x -= tk * nxt.x;
-    cur.y -= tk * nxt.y;
-    a[col + ncol * k] = cur;
-    nxt = cur;
-    sx += cur.x;
-    sy_ += cur.y;
+  for (int k0 = Nz - 2; k0 >= 0; k0 -= PF) {
+    double tb[PF];
+    double2_ ab[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+      if (k0 - q >= 0) {
+        tb[q] = t[col + ncol * (k0 - q + 1)];
+        ab[q] = a[col + ncol * (k0 - q)];
+      }
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int k = k0 - q;
+      if (k < 0) break;
+      double2_ cur = ab[q];
+      cur.x -= tb[q] * nxt.x;
+      cur.y -= tb[q] * nxt.y;
+      a[col + ncol * k] = cur;
+      nxt = cur;
+      sx += cur.x;
+      sy_ += cur.y;
+    }
   }
   if (i == 0 && j == 0) {
     // phi .-= mean(phi) (fourier_tridiagonal_poisson_solver.jl:95), done on the horizontal-mean mode
