@@ -56,11 +56,12 @@ def build_config3(ocn, ctx, args):
     examples/ocean_wind_mixing_and_convection.jl:38-60 with Nz = 128, T and S, FPlane, linear EOS, AMD, wind stress /
     heat flux / (constant) evaporation / bottom gradient BCs, RK3, WENO5 in place of the script's U5."""
     Nx, Ny, Nz = tuple(args.size) if args.size else (256, 256, 128)
+    world = int(os.environ.get("WORLD_SIZE", "1"))      # weak scaling along y: the library cuts (P,P,Bounded) grids into y-slabs
     Lz, refinement, stretching = 32.0, 1.2, 12.0
     k = np.arange(1, Nz + 2)
     h = (k - 1) / Nz
     zf = Lz * ((1 + (h - 1) / refinement) * (1 - np.exp(-stretching * h)) / (1 - np.exp(-stretching)) - 1)
-    grid = ocn.RectilinearGrid(ctx, size=(Nx, Ny, Nz), x=(0.0, 2.0 * Nx), y=(0.0, 2.0 * Ny), z=zf,
+    grid = ocn.RectilinearGrid(ctx, size=(Nx, Ny * world, Nz), x=(0.0, 2.0 * Nx), y=(0.0, 2.0 * Ny * world), z=zf,
                                topology=("Periodic", "Periodic", "Bounded"))
     QT = 200.0 / (1026.0 * 3991.0)
     Qu = -1.225 / 1026.0 * 2.5e-3 * 10 * 10
@@ -71,7 +72,7 @@ def build_config3(ocn, ctx, args):
                                     coriolis=ocn.FPlane(1e-4), closure=ocn.AnisotropicMinimumDissipation(),
                                     buoyancy=ocn.SeawaterBuoyancy(thermal_expansion=2e-4, haline_contraction=8e-4),
                                     boundary_conditions=bcs)
-    rng = np.random.default_rng(3)
+    rng = np.random.default_rng(3 + int(os.environ.get("RANK", "0")))
     zc = 0.5 * (zf[1:] + zf[:-1]).reshape(1, 1, -1)
     zw = zf.reshape(1, 1, -1)
     noise = lambda z, shape: rng.standard_normal(shape) * z / Lz * (1 + z / Lz)   # noqa: E731
@@ -81,7 +82,7 @@ def build_config3(ocn, ctx, args):
     w0[:, :, 0] = 0
     w0[:, :, -1] = 0
     ocn.set_model(model, u=u0, w=w0, T=T0, S=35.0)
-    return model, 1.0, (Nx, Ny, Nz), (Nx, Ny, Nz)
+    return model, 1.0, (Nx, Ny * world, Nz), (Nx, Ny, Nz)
 
 
 def main():
@@ -206,7 +207,7 @@ def main():
                        if args.config == 2 else
                        (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} (Periodic,Periodic,Bounded) stretched z, WENO5, RK3, T+S, "
                         "FPlane, linear EOS, AMD, flux/gradient BCs, Fourier-tridiagonal Poisson (BASELINE config 3)"),
-                       "decomposition": f"z-slabs x{world}", "dt": dt},
+                       "decomposition": f"{'y' if args.config == 3 else 'z'}-slabs x{world}", "dt": dt},
             "roofline": roofline,
             "step_roofline": {"alg_bytes_per_cell_update": B_ALG_STEP, "frac_of_hbm_peak": step_frac},
             "phases_ms": {k: round(v["avg_ms"], 4) for k, v in phases.items()},

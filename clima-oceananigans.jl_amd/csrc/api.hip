@@ -179,7 +179,7 @@ static int grid_build_dev(ocn_grid* g) {
   d.sz = d.sy * (d.Ny + 2 * d.Hy + d.yb);
   // regular axes: L/N (grid_generation.jl:84; the reference rounds a BigFloat quotient once)
   d.dx = (double)((long double)g->L[0] / g->N[0]);
-  d.dy = (double)((long double)g->L[1] / g->N[1]);
+  d.dy = (double)((long double)g->L[1] / (g->dist_y ? g->Nyg : g->N[1]));
   d.rdx = 1.0 / d.dx;
   d.rdy = 1.0 / d.dy;
   d.zb = g->topo[2] == OCN_BOUNDED;
@@ -245,30 +245,39 @@ int ocn_grid_create(ocn_ctx* ctx, const ocn_grid_desc* desc, ocn_grid** out) {
     }
   }
   g->Nzg = g->N[2];
-  // OCNHIP_FORCE_DIST=1 exercises the slab code path (pack / z-plan / self exchange) on one rank, where eligible
-  const bool forced = getenv("OCNHIP_FORCE_DIST") && atoi(getenv("OCNHIP_FORCE_DIST")) != 0 &&
-                      g->topo[0] == OCN_PERIODIC && g->topo[1] == OCN_PERIODIC && g->topo[2] == OCN_PERIODIC &&
-                      g->z_regular && g->N[2] >= 6;
-  g->dist = ctx->nranks > 1 || forced;
+  g->Nyg = g->N[1];
+  // Decomposition (Distributed/multi_architectures.jl:20-47), chosen from the topology:
+  //   triply Periodic, regular z     -> z-slabs, ranks (1, 1, R): contiguous halo planes, transpose-free Poisson
+  //   (Periodic, Periodic, Bounded)  -> y-slabs, ranks (1, R, 1): every rank keeps whole columns, so walls,
+  //                                     the hydrostatic integral and the tridiagonal solve stay local
+  // OCNHIP_FORCE_DIST=1 exercises the slab code paths (pack / exchange with self) on one rank, where eligible.
+  const bool want = ctx->nranks > 1 || (getenv("OCNHIP_FORCE_DIST") && atoi(getenv("OCNHIP_FORCE_DIST")) != 0);
+  const bool xyper = g->topo[0] == OCN_PERIODIC && g->topo[1] == OCN_PERIODIC;
+  const bool zslab_ok = xyper && g->topo[2] == OCN_PERIODIC && g->z_regular && g->N[2] >= 6 * ctx->nranks;
+  const bool yslab_ok = xyper && g->topo[2] == OCN_BOUNDED && g->N[1] >= 6 * ctx->nranks;
+  if (want && ctx->nranks > 1 && !zslab_ok && !yslab_ok) {
+    ocn_set_error(ctx, "no slab decomposition for this grid: needs (Periodic, Periodic, Periodic regular) with Nz >= 6 R "
+                       "or (Periodic, Periodic, Bounded) with Ny >= 6 R");
+    delete g;
+    return OCN_EUNSUPPORTED;
+  }
+  g->dist = want && zslab_ok;
+  g->dist_y = want && !zslab_ok && yslab_ok;
   if (g->dist) {
-    // Distributed/multi_architectures.jl:20-47 -- here ranks = (1, 1, R): z-slabs of the global grid
-    if (g->topo[0] != OCN_PERIODIC || g->topo[1] != OCN_PERIODIC || g->topo[2] != OCN_PERIODIC || !g->z_regular) {
-      ocn_set_error(ctx, "slab decomposition needs a triply Periodic regular grid (the reference's distributed "
-                         "solver is triply periodic too: distributed_fft_based_poisson_solver.jl)");
-      delete g;
-      return OCN_EUNSUPPORTED;
-    }
     if (g->N[2] % ctx->nranks != 0 || g->N[1] % ctx->nranks != 0) {
       ocn_set_error(ctx, "Nz and Ny must be divisible by the number of ranks (%d)", ctx->nranks);
       delete g;
       return OCN_EINVAL;
     }
     g->N[2] = g->Nzg / ctx->nranks;
-    if (g->N[2] < 2 * 3) {
-      ocn_set_error(ctx, "slabs thinner than twice the halo are not supported");
+  }
+  if (g->dist_y) {
+    if (g->N[1] % ctx->nranks != 0) {
+      ocn_set_error(ctx, "Ny must be divisible by the number of ranks (%d)", ctx->nranks);
       delete g;
       return OCN_EINVAL;
     }
+    g->N[1] = g->Nyg / ctx->nranks;
   }
   for (int d = 0; d < 3; ++d)
     if (g->topo[d] != OCN_FLAT && !(g->L[d] > 0)) {
@@ -394,6 +403,7 @@ static int fill_fields(ocn_model* m, Field** fs, int n) {
       for (int i = 0; i < n; ++i) launch_fill_bounded(m, *fs[i], d);
     } else if (m->g->topo[d] == OCN_PERIODIC) {
       if (d == 2 && m->g->dist) rc = comm_halo_exchange_z(m, fs, n);
+      else if (d == 1 && m->g->dist_y) rc = comm_halo_exchange_y(m, fs, n);
       else launch_fill_periodic(m, F, d);
       if (rc) return rc;
     }
@@ -694,6 +704,8 @@ void ocn_model_destroy(ocn_model* m) {
   for (double* p : m->owned) hipFree(p);
   hipFree(m->d_red);
   hipFree(m->phi_below);
+  hipFree(m->ypack_s);
+  hipFree(m->ypack_r);
   poisson_destroy(m->solver);
   delete m;
 }

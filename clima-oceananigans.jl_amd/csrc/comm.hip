@@ -168,6 +168,74 @@ int comm_halo_exchange_z(ocn_model* m, Field** fs, int n) {
   return comm_exchange(c, sends, recvs);
 }
 
+// y-halo exchange for y-slabs (Bounded z): H rows of every (x, z) -- full parent extent in x and z, as the periodic
+// fill it replaces (fill_halo_regions_periodic.jl:37-65) -- are strided in memory, so they are packed into one
+// staging buffer per call, exchanged with both ring neighbours in one group, and unpacked.
+__global__ void k_pack_rows(double* __restrict__ p, long sy, long sz, int Tx, int Tz, int H, int row0,
+                            double* __restrict__ buf, int unpack) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y;
+  const int k = blockIdx.z;
+  if (x >= Tx || h >= H || k >= Tz) return;
+  const long ip = x + (long)(row0 + h) * sy + (long)k * sz;
+  const long ib = x + (long)Tx * (h + (long)H * k);
+  if (unpack) p[ip] = buf[ib];
+  else buf[ib] = p[ip];
+}
+
+int comm_halo_exchange_y(ocn_model* m, Field** fs, int n) {
+  ocn_ctx* c = m->ctx;
+  ProfScope ps(c, "halo_exchange");
+  const int R = c->nranks, r = c->rank;
+  const int up = (r + 1) % R, dn = (r + R - 1) % R;
+  const int Ny = m->gd.Ny, H = m->gd.Hy;
+  if (H == 0) return OCN_OK;
+  size_t need = 0;
+  for (int i = 0; i < n; ++i) need += 2 * (size_t)H * fs[i]->P[0] * fs[i]->T[2];
+  if (need > m->ypack_n) {
+    hipStreamSynchronize(c->stream);
+    hipFree(m->ypack_s);
+    hipFree(m->ypack_r);
+    m->ypack_s = m->ypack_r = nullptr;
+    if (hipMalloc((void**)&m->ypack_s, need * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&m->ypack_r, need * sizeof(double)) != hipSuccess) {
+      ocn_set_error(c, "y-slab halo staging allocation failed");
+      return OCN_ENOMEM;
+    }
+    m->ypack_n = need;
+  }
+  std::vector<CommOp> sends, recvs;
+  std::vector<size_t> off(n);
+  size_t o = 0;
+  const dim3 b(64, 1, 1);
+  for (int i = 0; i < n; ++i) {
+    Field* f = fs[i];
+    const int Tx = f->P[0], Tz = f->T[2];
+    const size_t blk = (size_t)H * Tx * Tz;
+    off[i] = o;
+    const dim3 gr((Tx + 63) / 64, H, Tz);
+    // block 0: my top interior rows [Ny, Ny+H) -> upper neighbour's south halo; block 1: rows [H, 2H) -> lower's north halo
+    ocn_launch(k_pack_rows, gr, b, c->stream, f->d, f->sy, f->sz, Tx, Tz, H, Ny, m->ypack_s + o, 0);
+    ocn_launch(k_pack_rows, gr, b, c->stream, f->d, f->sy, f->sz, Tx, Tz, H, H, m->ypack_s + o + blk, 0);
+    sends.push_back({m->ypack_s + o, blk * sizeof(double), up, 2 * i});
+    recvs.push_back({m->ypack_r + o, blk * sizeof(double), dn, 2 * i});
+    sends.push_back({m->ypack_s + o + blk, blk * sizeof(double), dn, 2 * i + 1});
+    recvs.push_back({m->ypack_r + o + blk, blk * sizeof(double), up, 2 * i + 1});
+    o += 2 * blk;
+  }
+  int rc = comm_exchange(c, sends, recvs);
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i) {
+    Field* f = fs[i];
+    const int Tx = f->P[0], Tz = f->T[2];
+    const size_t blk = (size_t)H * Tx * Tz;
+    const dim3 gr((Tx + 63) / 64, H, Tz);
+    ocn_launch(k_pack_rows, gr, b, c->stream, f->d, f->sy, f->sz, Tx, Tz, H, 0, m->ypack_r + off[i], 1);
+    ocn_launch(k_pack_rows, gr, b, c->stream, f->d, f->sy, f->sz, Tx, Tz, H, Ny + H, m->ypack_r + off[i] + blk, 1);
+  }
+  return OCN_OK;
+}
+
 // all-to-all of equal blocks: block q of `send` goes to rank q; block r of `recv` comes from rank r
 int comm_alltoall(ocn_ctx* c, const void* send, void* recv, size_t block_bytes) {
   ProfScope ps(c, "transpose");

@@ -40,6 +40,8 @@ struct ocn_grid {
   ocn_ctx* ctx;
   int Nzg = 0;          // global Nz (N[2] is this rank's slab)
   bool dist = false;    // z-slab decomposition active (also forced with one rank by OCNHIP_FORCE_DIST=1)
+  int Nyg = 0;          // global Ny (N[1] is this rank's slab when dist_y)
+  bool dist_y = false;  // y-slab decomposition (Bounded z: every rank keeps whole columns)
   ocn_grid_desc d;
   int N[3], H[3], topo[3];
   int PH[3];            // physical halo: H, except Flat x / y, which are stored with broadcast halos
@@ -101,6 +103,8 @@ struct ocn_model {
   double* d_red = nullptr;  // reduction scratch
   int fast_path = 0;        // 1: fused periodic WENO kernels usable
   double* phi_below = nullptr;   // (Nx,Ny): top plane of the lower neighbour's pressure (slab runs)
+  double *ypack_s = nullptr, *ypack_r = nullptr;   // y-slab halo exchange staging (send / receive)
+  size_t ypack_n = 0;
   bool gn_alias_gm = false; // after a fused AB2 step G^n and G^- are the same buffer (pointer swap instead of a copy)
 };
 
@@ -159,6 +163,7 @@ int zslab_run(ocn_ctx* ctx, void* z, void* spec, double dz2, double scale);
 // ---- comm.hip ---------------------------------------------------------------------------------------------
 int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs);
 int comm_halo_exchange_z(ocn_model* m, Field** fs, int n);
+int comm_halo_exchange_y(ocn_model* m, Field** fs, int n);
 int comm_alltoall(ocn_ctx* c, const void* send, void* recv, size_t block_bytes);
 void comm_destroy(ocn_ctx* c);
 

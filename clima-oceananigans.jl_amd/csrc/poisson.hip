@@ -24,7 +24,8 @@ struct double2_ {
 };
 
 struct PoissonSolver {
-  int kind;        // 4: Bounded / Flat x or y (dense cosine / Fourier transforms, see run_general)
+  int kind;        // 5: y-slabs with a Bounded z (run_yslab)
+                   // 4: Bounded / Flat x or y (dense cosine / Fourier transforms, see run_general)
                    // 0: 3-D FFT (z Periodic)   1: 2-D FFT (+ tridiagonal if z Bounded, plain divide if z Flat)
                    // 2: z-slabs: 2-D FFT per plane, all-to-all to ky-slabs, 1-D FFT along z, and back
   int Nx, Ny, Nz, Nxh;
@@ -47,9 +48,13 @@ struct PoissonSolver {
   double2_ *ga = nullptr, *gb = nullptr;    // complex (gR, gNy, Nz) ping-pong
   double* gm[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // cosine-transform matrices [x / y][forward / inverse]
   void* blas = nullptr;                     // rocblas_handle
+  // kind 5 (y-slabs, Bounded z), see run_yslab
+  int yw = 0, Nyg = 0;                      // kx columns per rank (padded), global Ny
+  double2_ *ysend = nullptr, *yrecv = nullptr, *yT = nullptr;
 #ifndef OCN_HOST_EMU
   hipfftHandle fwd = 0, inv = 0, zplan = 0, xinv = 0;
   hipfftHandle wxf = 0, wxi = 0, wz = 0;    // kind 4: batched 1-D x (R2C / C2R) and z (C2C) plans
+  hipfftHandle yfft = 0;                    // kind 5: contiguous 1-D complex transforms along the global y
 #endif
 };
 
@@ -100,6 +105,7 @@ static double* upload(const std::vector<double>& v) {
 }
 
 static int walls_create(ocn_model* m, PoissonSolver* s);
+static int yslab_create(ocn_model* m, PoissonSolver* s);
 
 PoissonSolver* poisson_create(ocn_model* m) {
   ocn_grid* g = m->g;
@@ -109,6 +115,15 @@ PoissonSolver* poisson_create(ocn_model* m) {
   s->Nz = g->N[2];
   s->Nxh = s->Nx / 2 + 1;
   s->kind = (g->topo[2] == OCN_PERIODIC) ? 0 : 1;
+  if (g->dist_y) {
+    s->kind = 5;
+    int rc5 = yslab_create(m, s);
+    if (rc5) {
+      poisson_destroy(s);
+      return nullptr;
+    }
+    return s;
+  }
   if (g->topo[0] != OCN_PERIODIC || g->topo[1] != OCN_PERIODIC) {
     s->kind = 4;
     int rc4 = walls_create(m, s);
@@ -247,12 +262,16 @@ void poisson_destroy(PoissonSolver* s) {
   hipFree(s->gb);
   hipFree(s->ra);
   hipFree(s->rb);
+  hipFree(s->ysend);
+  hipFree(s->yrecv);
+  hipFree(s->yT);
   for (int d = 0; d < 2; ++d)
     for (int q = 0; q < 2; ++q) hipFree(s->gm[d][q]);
 #ifndef OCN_HOST_EMU
   if (s->wxf) hipfftDestroy(s->wxf);
   if (s->wxi) hipfftDestroy(s->wxi);
   if (s->wz) hipfftDestroy(s->wz);
+  if (s->yfft) hipfftDestroy(s->yfft);
   if (s->blas) rocblas_destroy_handle((rocblas_handle)s->blas);
 #endif
   zsolve_destroy(s->zs);
@@ -402,7 +421,7 @@ __global__ void k_scale_spectrum(int Nxh, int Ny, int Nz, const double* __restri
 // the diagonal of fourier_tridiagonal_poisson_solver.jl:16-28 computed on the fly; in place on `a`.
 __global__ void k_tridiag(GridDev g, int Nxh, int Ny, int Nz, const double* __restrict__ lx,
                           const double* __restrict__ ly, double norm, double2_* __restrict__ a,
-                          double* __restrict__ t) {
+                          double* __restrict__ t, int owns_mean) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= Nxh || j >= Ny) return;
@@ -471,7 +490,7 @@ __global__ void k_tridiag(GridDev g, int Nxh, int Ny, int Nz, const double* __re
       sy_ += cur.y;
     }
   }
-  if (i == 0 && j == 0) {
+  if (owns_mean && i == 0 && j == 0) {
     // phi .-= mean(phi) (fourier_tridiagonal_poisson_solver.jl:95), done on the horizontal-mean mode
     double mx = sx / Nz, my = sy_ / Nz;
     for (int k = 0; k < Nz; ++k) {
@@ -682,7 +701,7 @@ static int run_walls(ocn_model* m) {
     const double norm = 1.0 / ((xper ? (double)Nx : 1.0) * (zper ? (double)Nz : 1.0));
     if (m->g->topo[2] == OCN_BOUNDED) {
       ocn_launch(k_tridiag, dim3((R + 63) / 64, (Ny + 3) / 4, 1), b, st, m->gd, R, Ny, Nz, (const double*)s->lx,
-                 (const double*)s->ly, norm, cur, s->tscr);
+                 (const double*)s->ly, norm, cur, s->tscr, 1);
     } else {
       if (zper) {
 #ifndef OCN_HOST_EMU
@@ -751,10 +770,151 @@ static int run_walls(ocn_model* m) {
   return OCN_OK;
 }
 
+// ---- y-slabs with a Bounded z (kind 5) -----------------------------------------------------------------------------
+// The reference has no distributed Fourier-tridiagonal solver (NonhydrostaticModels.jl:18-21).  Here every rank
+// owns Ny/R rows of whole columns: the x transform and the tridiagonal solve down z are local, and the y
+// transform needs the rows of all ranks -- one all-to-all that hands each rank a band of kx for ALL y (the
+// x <-> y transposition is folded into the pack / unpack kernels, so the y transform is contiguous), and one back.
+__global__ void k_yslab_pack(int Nxh, int Nyl, int Nz, int w, int R, double2_* __restrict__ spec, double2_* __restrict__ blocks,
+                             int unpack) {
+  // blocks[q][jl + Nyl (kxl + w z)]  <->  spec[kx + Nxh (jl + Nyl z)],  kx = q w + kxl (zero padded past Nxh)
+  const int kx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int jl = blockIdx.y * blockDim.y + threadIdx.y;
+  const int z = blockIdx.z;
+  if (kx >= w * R || jl >= Nyl || z >= Nz) return;
+  const int q = kx / w, kxl = kx - q * w;
+  const size_t ib = (size_t)q * Nyl * w * Nz + jl + (size_t)Nyl * (kxl + (size_t)w * z);
+  const size_t is = kx + (size_t)Nxh * (jl + (size_t)Nyl * z);
+  if (unpack) {
+    if (kx < Nxh) spec[is] = blocks[ib];
+  } else {
+    blocks[ib] = kx < Nxh ? spec[is] : double2_{0.0, 0.0};
+  }
+}
+__global__ void k_yslab_gather(int Nyl, int Nyg, int Nz, int w, int R, double2_* __restrict__ blocks, double2_* __restrict__ T,
+                               int scatter) {
+  // T[y + Nyg (kxl + w z)]  <->  blocks[p][jl + Nyl (kxl + w z)],  y = p Nyl + jl
+  const int y = blockIdx.x * blockDim.x + threadIdx.x;
+  const int kxl = blockIdx.y;
+  const int z = blockIdx.z;
+  if (y >= Nyg || kxl >= w || z >= Nz) return;
+  const int p = y / Nyl, jl = y - p * Nyl;
+  const size_t ib = (size_t)p * Nyl * w * Nz + jl + (size_t)Nyl * (kxl + (size_t)w * z);
+  const size_t it = y + (size_t)Nyg * (kxl + (size_t)w * z);
+  if (scatter) blocks[ib] = T[it];
+  else T[it] = blocks[ib];
+}
+
+static int yslab_create(ocn_model* m, PoissonSolver* s) {
+  ocn_grid* g = m->g;
+  const int R = m->ctx->nranks;
+  s->R = R;
+  s->rank = m->ctx->rank;
+  s->Nyg = g->Nyg;
+  s->yw = (s->Nxh + R - 1) / R;
+  const size_t nr = (size_t)s->Nx * s->Ny * s->Nz, nc = (size_t)s->Nxh * s->Ny * s->Nz;
+  const size_t nt = (size_t)s->Nyg * s->yw * s->Nz;
+  if (hipMalloc((void**)&s->rhs, nr * sizeof(double)) != hipSuccess || hipMalloc((void**)&s->spec, nc * sizeof(double2_)) != hipSuccess ||
+      hipMalloc((void**)&s->ysend, nt * sizeof(double2_)) != hipSuccess || hipMalloc((void**)&s->yrecv, nt * sizeof(double2_)) != hipSuccess ||
+      hipMalloc((void**)&s->yT, nt * sizeof(double2_)) != hipSuccess || hipMalloc((void**)&s->tscr, nt * sizeof(double)) != hipSuccess)
+    return OCN_ENOMEM;
+  std::vector<double> lxg = eigenvalues_periodic(s->Nx, g->L[0]), lxl(s->yw);
+  for (int i = 0; i < s->yw; ++i) {
+    int kx = s->rank * s->yw + i;
+    lxl[i] = lxg[kx < s->Nxh ? kx : s->Nxh - 1];     // padding columns carry zeros; any non-singular value will do
+  }
+  s->lx = upload(lxl);
+  s->ly = upload(eigenvalues_periodic(s->Nyg, g->L[1]));
+#ifndef OCN_HOST_EMU
+  int nx[1] = {s->Nx}, ny[1] = {s->Nyg};
+  if (hipfftPlanMany(&s->wxf, 1, nx, nullptr, 1, s->Nx, nullptr, 1, s->Nxh, HIPFFT_D2Z, s->Ny * s->Nz) != HIPFFT_SUCCESS ||
+      hipfftPlanMany(&s->wxi, 1, nx, nullptr, 1, s->Nxh, nullptr, 1, s->Nx, HIPFFT_Z2D, s->Ny * s->Nz) != HIPFFT_SUCCESS ||
+      hipfftPlanMany(&s->yfft, 1, ny, nullptr, 1, s->Nyg, nullptr, 1, s->Nyg, HIPFFT_Z2Z, s->yw * s->Nz) != HIPFFT_SUCCESS) {
+    ocn_set_error(m->ctx, "hipfft plan creation failed (y-slab solver)");
+    return OCN_EHIP;
+  }
+  hipfftSetStream(s->wxf, m->ctx->stream);
+  hipfftSetStream(s->wxi, m->ctx->stream);
+  hipfftSetStream(s->yfft, m->ctx->stream);
+#endif
+  return OCN_OK;
+}
+
+static int yslab_yfft(ocn_model* m, int sign) {
+  PoissonSolver* s = m->solver;
+#ifndef OCN_HOST_EMU
+  if (hipfftExecZ2Z(s->yfft, (hipfftDoubleComplex*)s->yT, (hipfftDoubleComplex*)s->yT, sign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD) !=
+      HIPFFT_SUCCESS) {
+    ocn_set_error(m->ctx, "hipfftExecZ2Z failed");
+    return OCN_EHIP;
+  }
+#else
+  const size_t nt = (size_t)s->Nyg * s->yw * s->Nz;
+  std::vector<cplx> a(nt);
+  for (size_t i = 0; i < nt; ++i) a[i] = cplx(s->yT[i].x, s->yT[i].y);
+  emu_dft_axis(a, s->Nyg, s->yw, s->Nz, 0, sign);
+  for (size_t i = 0; i < nt; ++i) s->yT[i] = {a[i].real(), a[i].imag()};
+#endif
+  return OCN_OK;
+}
+
+static int run_yslab(ocn_model* m) {
+  PoissonSolver* s = m->solver;
+  hipStream_t st = m->ctx->stream;
+  const int Nx = s->Nx, Nxh = s->Nxh, Nyl = s->Ny, Nyg = s->Nyg, Nz = s->Nz, w = s->yw, R = s->R;
+  const size_t blk = (size_t)Nyl * w * Nz * sizeof(double2_);
+  const dim3 b(64, 4, 1), gp((w * R + 63) / 64, (Nyl + 3) / 4, Nz), bg(64, 1, 1), gg((Nyg + 63) / 64, w, Nz);
+  int rc = OCN_OK;
+  {
+    ProfScope ps(m->ctx, "fft_forward");
+#ifndef OCN_HOST_EMU
+    if (hipfftExecD2Z(s->wxf, s->rhs, (hipfftDoubleComplex*)s->spec) != HIPFFT_SUCCESS) {
+      ocn_set_error(m->ctx, "hipfftExecD2Z failed");
+      return OCN_EHIP;
+    }
+#else
+    emu_x_r2c(s->rhs, s->spec, Nx, Nxh, (size_t)Nyl * Nz);
+#endif
+    ocn_launch(k_yslab_pack, gp, b, st, Nxh, Nyl, Nz, w, R, s->spec, s->ysend, 0);
+  }
+  if ((rc = comm_alltoall(m->ctx, s->ysend, s->yrecv, blk))) return rc;
+  {
+    ProfScope ps(m->ctx, "fft_forward");
+    ocn_launch(k_yslab_gather, gg, bg, st, Nyl, Nyg, Nz, w, R, s->yrecv, s->yT, 0);
+    if ((rc = yslab_yfft(m, -1))) return rc;
+  }
+  {
+    ProfScope ps(m->ctx, "spectral_solve");
+    // columns are (ky, kx_local): ky runs fastest, so the roles of lx / ly in the kernel are swapped
+    ocn_launch(k_tridiag, dim3((Nyg + 63) / 64, (w + 3) / 4, 1), b, st, m->gd, Nyg, w, Nz, (const double*)s->ly, (const double*)s->lx,
+               1.0 / ((double)Nx * Nyg), s->yT, s->tscr, s->rank == 0 ? 1 : 0);
+  }
+  {
+    ProfScope ps(m->ctx, "fft_backward");
+    if ((rc = yslab_yfft(m, +1))) return rc;
+    ocn_launch(k_yslab_gather, gg, bg, st, Nyl, Nyg, Nz, w, R, s->ysend, s->yT, 1);
+  }
+  if ((rc = comm_alltoall(m->ctx, s->ysend, s->yrecv, blk))) return rc;
+  {
+    ProfScope ps(m->ctx, "fft_backward");
+    ocn_launch(k_yslab_pack, gp, b, st, Nxh, Nyl, Nz, w, R, s->spec, s->yrecv, 1);
+#ifndef OCN_HOST_EMU
+    if (hipfftExecZ2D(s->wxi, (hipfftDoubleComplex*)s->spec, s->rhs) != HIPFFT_SUCCESS) {
+      ocn_set_error(m->ctx, "hipfftExecZ2D failed");
+      return OCN_EHIP;
+    }
+#else
+    emu_x_c2r(s->spec, s->rhs, Nx, Nxh, (size_t)Nyl * Nz);
+#endif
+  }
+  return OCN_OK;
+}
+
 static int run_solver(ocn_model* m) {
   PoissonSolver* s = m->solver;
   hipStream_t st = m->ctx->stream;
   if (s->kind == 4) return run_walls(m);
+  if (s->kind == 5) return run_yslab(m);
   {
     ProfScope ps(m->ctx, "fft_forward");
 #ifndef OCN_HOST_EMU
@@ -823,7 +983,7 @@ static int run_solver(ocn_model* m) {
       dim3 gr((s->Nxh + 63) / 64, (s->Ny + 3) / 4, 1);
       double norm = 1.0 / ((double)s->Nx * s->Ny);
       ocn_launch(k_tridiag, gr, b, st, m->gd, s->Nxh, s->Ny, s->Nz, (const double*)s->lx, (const double*)s->ly, norm,
-                 s->spec, s->tscr);
+                 s->spec, s->tscr, 1);
     } else {
       dim3 gr((s->Nxh + 63) / 64, (s->Ny + 3) / 4, s->Nz);
       double norm = 1.0 / ((double)s->Nx * s->Ny * (s->kind == 0 ? s->Nz : 1));
