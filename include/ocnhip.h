@@ -94,7 +94,9 @@ typedef struct ocn_grid_desc {
   double x0[3];        /* left end of the domain per direction            */
   double L[3];         /* extent per direction (ignored for stretched z)  */
   const double* z_faces; /* NULL or Nz+1 doubles (host)                   */
-  /* domain decomposition (Distributed/multi_architectures.jl:20-47): z-slabs. local = this rank's slab */
+  /* domain decomposition (Distributed/multi_architectures.jl:20-47): N is the GLOBAL size; after ocn_comm_init the
+   * library cuts triply periodic grids into z-slabs and (Periodic, Periodic, Bounded) grids into y-slabs and
+   * every field of the model has this rank's local shape (ocn_field_shape) */
   int32_t rank, nranks;
 } ocn_grid_desc;
 
