@@ -17,6 +17,7 @@
 struct zc {
   double x, y;
 };
+#define ZS_MR 8   // segments up to this many levels are solved in registers (k_zslab_down_reg)
 
 OCN_DEVFN double col_rho(double lam_dz2) {
   // roots of rho^2 + beta rho + 1 = 0 with -beta = 2 + s:  rho = 2 / (-beta + sqrt(beta^2 - 4))
@@ -30,7 +31,7 @@ OCN_DEVFN double col_rho(double lam_dz2) {
 // pass 1 (upward, per segment): P_i = rho P_{i-1} + f_i stored in place (zero carry-in);
 //   segment sums  SP_s = P_{m-1},  SQ_s = sum_i rho^i f_i          -> segs[(s*2 + {0,1}) * ncol + col]
 __global__ void k_zslab_up(zc* __restrict__ a, long ncol, int m, int SZ, const double* __restrict__ lxy, double dz2,
-                           zc* __restrict__ segs) {
+                           zc* __restrict__ segs, int store) {
   const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
   if (col >= ncol) return;
@@ -60,9 +61,11 @@ __global__ void k_zslab_up(zc* __restrict__ a, long ncol, int m, int SZ, const d
         pw *= rho;
         f[q] = P;
       }
+    if (store) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (i0 + q < m) p[ncol * (size_t)(i0 + q)] = f[q];
+      for (int q = 0; q < 8; ++q)
+        if (i0 + q < m) p[ncol * (size_t)(i0 + q)] = f[q];
+    }
   }
   segs[((size_t)s * 2 + 0) * ncol + col] = P;
   segs[((size_t)s * 2 + 1) * ncol + col] = SQ;
@@ -175,6 +178,77 @@ __global__ void k_zslab_down(zc* __restrict__ a, long ncol, int m, int SZ, int R
   }
 }
 
+// pass 2 for short segments (m <= MR levels): the segment's right-hand sides fit in registers, so pass 1 only
+// has to produce the sums (no in-place P array: 25 % less traffic over both passes) and the powers of rho are
+// running products instead of one exp() per level.  Same formula as k_zslab_down with f used directly.
+template <int MR>
+__global__ void k_zslab_down_reg(zc* __restrict__ a, long ncol, int m, int SZ, int R, int rank, const double* __restrict__ lxy,
+                                 double dz2, double scale, const zc* __restrict__ segs, const zc* __restrict__ gathered,
+                                 size_t msg) {
+  const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
+  if (col >= ncol) return;
+  const double lam = lxy[col] * dz2;
+  if (lam == 0.0) return;
+  zc* p = a + col + ncol * (size_t)s * m;
+  zc f[MR];
+#pragma unroll
+  for (int q = 0; q < MR; ++q)
+    if (q < m) f[q] = p[ncol * (size_t)q];
+  const double rho = col_rho(lam);
+  const double lnr = log(rho);
+  const int n = m * SZ;
+  const double rm = exp(lnr * m);
+  const double rn = exp(lnr * n);
+  const double geo = 1.0 / (1.0 - exp(lnr * ((double)n * R)));
+  zc cP = {0, 0}, cQ = {0, 0};
+  double w = 1.0;
+  for (int mm = 1; mm <= R; ++mm) {
+    const int rb = ((rank - mm) % R + R) % R, ra = (rank + mm) % R;
+    zc sp = gathered[(size_t)rb * msg + col];
+    zc sq = gathered[(size_t)ra * msg + ncol + col];
+    cP.x = fma(w, sp.x, cP.x);
+    cP.y = fma(w, sp.y, cP.y);
+    cQ.x = fma(w, sq.x, cQ.x);
+    cQ.y = fma(w, sq.y, cQ.y);
+    w *= rn;
+  }
+  cP.x *= geo; cP.y *= geo; cQ.x *= geo; cQ.y *= geo;
+  for (int t = 0; t < s; ++t) {
+    zc sp = segs[((size_t)t * 2 + 0) * ncol + col];
+    cP.x = fma(rm, cP.x, sp.x);
+    cP.y = fma(rm, cP.y, sp.y);
+  }
+  for (int t = SZ - 1; t > s; --t) {
+    zc sq = segs[((size_t)t * 2 + 1) * ncol + col];
+    cQ.x = fma(rm, cQ.x, sq.x);
+    cQ.y = fma(rm, cQ.y, sq.y);
+  }
+  const double C = rho / (rho * rho - 1.0) * scale;
+  // upward: P_i = rho P_{i-1} + f_i plus the carry from below, rho^(i+1) cP, folded in as P'_i = rho P'_{i-1} + f_i, P'_{-1} = cP
+  zc P[MR];
+  zc run = cP;
+#pragma unroll
+  for (int q = 0; q < MR; ++q)
+    if (q < m) {
+      run.x = fma(rho, run.x, f[q].x);
+      run.y = fma(rho, run.y, f[q].y);
+      P[q] = run;
+    }
+  // downward: Q'_i = rho Q'_{i+1} + f_i with Q'_m = cQ carries rho^(m-i) cQ;  x_i = C (P'_i + rho Q'_{i+1})
+  zc Q = cQ;
+#pragma unroll
+  for (int q = MR - 1; q >= 0; --q)
+    if (q < m) {
+      zc x;
+      x.x = C * fma(rho, Q.x, P[q].x);
+      x.y = C * fma(rho, Q.y, P[q].y);
+      Q.x = fma(rho, Q.x, f[q].x);
+      Q.y = fma(rho, Q.y, f[q].y);
+      p[ncol * (size_t)q] = x;
+    }
+}
+
 // the singular column (lx + ly = 0): second difference of x equals g = f - mean(f), zero-mean solution:
 //   x_k - x_0 = k d_{-1} + sum_{j<k} c_j,  c = inclusive prefix sum of g,  d_{-1} = -mean(c),  x_0 from zero mean.
 // One workgroup; every thread owns a contiguous chunk; the two prefix sums are chunk-local scans plus a
@@ -280,7 +354,7 @@ void* zslab_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::
   for (size_t j = 0; j < Ny; ++j)
     for (size_t i = 0; i < Nxh; ++i) lxy[i + Nxh * j] = lx_half[i] + ly[j];
   z->SZ = 1;
-  for (int cand : {32, 16, 8, 4, 2})
+  for (int cand : {64, 32, 16, 8, 4, 2})      // segments of 8 levels when possible (register kernel), never shorter
     if (n % cand == 0 && n / cand >= 8) { z->SZ = cand; break; }
   z->m = n / z->SZ;
   z->msg = 2 * (size_t)z->ncol + (size_t)n;
@@ -317,7 +391,7 @@ int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale) {
   {
     ProfScope ps(ctx, "spectral_solve");
     ocn_launch(k_zslab_getcol, dim3((z->n + 63) / 64), dim3(64), st, (const zc*)a, z->ncol, 0L, z->n, z->send + 2 * z->ncol);
-    ocn_launch(k_zslab_up, g, b, st, a, z->ncol, z->m, z->SZ, (const double*)z->lxy, dz2, z->segs);
+    ocn_launch(k_zslab_up, g, b, st, a, z->ncol, z->m, z->SZ, (const double*)z->lxy, dz2, z->segs, z->m > ZS_MR ? 1 : 0);
     ocn_launch(k_zslab_ranksums, g1, b, st, z->ncol, z->m, z->SZ, (const double*)z->lxy, dz2, (const zc*)z->segs, z->send);
   }
   // all-gather (the same message to every peer)
@@ -334,8 +408,12 @@ int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale) {
   }
   {
     ProfScope ps(ctx, "spectral_solve");
-    ocn_launch(k_zslab_down, g, b, st, a, z->ncol, z->m, z->SZ, z->R, z->rank, (const double*)z->lxy, dz2, scale * dz2,
-               (const zc*)z->segs, (const zc*)z->gathered, z->msg);
+    if (z->m > ZS_MR)
+      ocn_launch(k_zslab_down, g, b, st, a, z->ncol, z->m, z->SZ, z->R, z->rank, (const double*)z->lxy, dz2, scale * dz2,
+                 (const zc*)z->segs, (const zc*)z->gathered, z->msg);
+    else
+      ocn_launch(k_zslab_down_reg<ZS_MR>, g, b, st, a, z->ncol, z->m, z->SZ, z->R, z->rank, (const double*)z->lxy, dz2,
+                 scale * dz2, (const zc*)z->segs, (const zc*)z->gathered, z->msg);
     ocn_launch_sync(k_zslab_mean, dim3(1), dim3(ZM_T), st, a, z->ncol, 0L, z->n, z->R, z->rank, (const zc*)z->gathered, z->msg,
                     scale * dz2, z->work);
   }
