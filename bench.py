@@ -85,6 +85,18 @@ def build_config3(ocn, ctx, args):
     return model, 1.0, (Nx, Ny * world, Nz), (Nx, Ny, Nz)
 
 
+def build_config1(ocn, ctx, args):
+    """BASELINE config 1: examples/two_dimensional_turbulence.jl -- 128 x 128 (Periodic, Periodic, Flat), 2 pi box,
+    RK3, ScalarDiffusivity(nu = 1e-5), WENO5 in place of the script's UpwindBiasedFifthOrder."""
+    Nx, Ny = (args.size[0], args.size[1]) if args.size else (128, 128)
+    grid = ocn.RectilinearGrid(ctx, size=(Nx, Ny), extent=(2 * np.pi, 2 * np.pi), topology=("Periodic", "Periodic", "Flat"))
+    model = ocn.NonhydrostaticModel(grid, advection=ocn.WENO5(), timestepper="RungeKutta3", closure=ocn.ScalarDiffusivity(nu=1e-5))
+    rng = np.random.default_rng(1)
+    u, v = rng.standard_normal((Nx, Ny, 1)), rng.standard_normal((Nx, Ny, 1))
+    ocn.set_model(model, u=u - u.mean(), v=v - v.mean())
+    return model, 0.2 * (2 * np.pi / Nx) / 4.0, (Nx, Ny, 1), (Nx, Ny, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,7 +107,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tracers", type=int, default=0, help="passive tracers (config 2b: 1)")
     ap.add_argument("--topology", default="PPP", help="config 2 with other x/y/z topologies, e.g. PBB (debug / widening rows)")
-    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (headline, default) or 3 (ocean LES)")
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (headline, default), 1 (2-D turbulence) or 3 (ocean LES)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,6 +137,8 @@ def main():
     Nglobal = (n[0], n[1], n[2] * world)
     if args.config == 3:
         model, dt3, Nglobal, n = build_config3(ocn, ctx, args)
+    elif args.config == 1:
+        model, dt3, Nglobal, n = build_config1(ocn, ctx, args)
     else:
         topo = tuple({"P": "Periodic", "B": "Bounded"}[c] for c in args.topology.upper())
         grid = ocn.RectilinearGrid(ctx, size=Nglobal, extent=(1, 1, float(world)), topology=topo)
@@ -141,7 +155,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         umax = float(t[0])
     dt = 0.2 * (1.0 / n[0]) / umax
-    if args.config == 3:
+    if args.config != 2:
         dt = dt3
 
     for _ in range(args.warmup):
@@ -205,6 +219,8 @@ def main():
                                     + " RectilinearGrid, "
                                     f"NonhydrostaticModel WENO5(zweno) + FFT Poisson, {args.stepper}, halo 3, {args.tracers} tracers")
                        if args.config == 2 else
+                       (f"{Nglobal[0]}x{Nglobal[1]} (Periodic,Periodic,Flat) two_dimensional_turbulence, WENO5, RK3, "
+                        "ScalarDiffusivity (BASELINE config 1)") if args.config == 1 else
                        (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} (Periodic,Periodic,Bounded) stretched z, WENO5, RK3, T+S, "
                         "FPlane, linear EOS, AMD, flux/gradient BCs, Fourier-tridiagonal Poisson (BASELINE config 3)"),
                        "decomposition": f"{'y' if args.config == 3 else 'z'}-slabs x{world}", "dt": dt},

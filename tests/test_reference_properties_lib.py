@@ -91,6 +91,29 @@ def _halos(ocn):
     assert m2.halo == (3, 3, 3)                                                  # halo inflation
 
 
+def _halos_degenerate(ocn):
+    """test_halo_regions.jl:22-41 sizes, including directions with fewer cells than halo points (N = 1 with H = 1 and
+    with the WENO halo of 3: the periodic fill then feeds on halo cells it has just written), all six topologies
+    of z x {Periodic, Bounded} with walls in x / y: the library's parent arrays equal the oracle's, element by element."""
+    import oracle as O
+    rng = np.random.default_rng(0)
+    for N in [(1, 1, 1), (1, 8, 8), (8, 1, 8), (8, 8, 1), (2, 3, 2), (5, 7, 9)]:
+        for topo in [(P, P, B), (P, P, P), (B, P, B), (P, B, P), (B, B, B)]:
+            for adv in (None, "WENO5"):
+                kw = dict(size=N, extent=(100, 200, 300), halo=(1, 1, 1), topology=topo)
+                m = ocn.NonhydrostaticModel(ocn.RectilinearGrid(**kw), tracers=("c",), advection=ocn.WENO5() if adv else None)
+                om = O.NonhydrostaticModel(O.RectilinearGrid(**kw), tracers=("c",), advection=O.WENO5() if adv else None)
+                vals = {n: rng.random(f.interior().shape) for n, f in om.prognostic().items()}
+                for n, v in vals.items():
+                    m.prognostic()[n].set(v)
+                    om.prognostic()[n].set(v)
+                ocn.update_state(m)
+                from oracle.model import update_state as o_update_state
+                o_update_state(om)
+                for n in vals:
+                    assert np.array_equal(m.prognostic()[n].parent(), om.prognostic()[n].data), (N, topo, adv, n)
+
+
 def _poisson(ocn):
     import oracle as O
     from oracle.fields import Field, fill_halo_regions
@@ -199,6 +222,7 @@ def test_taylor_green_hostemu(ocn, backend):
 def test_halos_and_poisson_hostemu(ocn, backend):
     _run(ocn, backend, False)
     _halos(ocn)
+    _halos_degenerate(ocn)
     _poisson(ocn)
 
 
@@ -252,4 +276,5 @@ def test_incompressible_walls_gpu(ocn, backend, stepper):
 def test_halos_and_poisson_gpu(ocn, backend):
     _run(ocn, backend, True)
     _halos(ocn)
+    _halos_degenerate(ocn)
     _poisson(ocn)
