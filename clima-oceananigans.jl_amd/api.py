@@ -106,6 +106,9 @@ class Context:
     def profile(self, on=True):
         check(self.lib.ocn_profile_enable(self.h, int(on)), self.h)
 
+    def profile_filter(self, phase=None):
+        check(self.lib.ocn_profile_filter(self.h, phase.encode() if phase else None), self.h)
+
     def profile_reset(self):
         check(self.lib.ocn_profile_reset(self.h), self.h)
 

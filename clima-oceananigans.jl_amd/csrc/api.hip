@@ -22,7 +22,7 @@ void ocn_set_error(ocn_ctx* ctx, const char* fmt, ...) {
 
 // ---- profiling -------------------------------------------------------------------------------------------
 ProfScope::ProfScope(ocn_ctx* ctx, const char* nm) : c(ctx), name(nm) {
-  if (!c->profiling) return;
+  if (!c->profiling || (!c->prof_only.empty() && c->prof_only != nm)) return;
   hipEventCreate(&a);
   hipEventCreate(&b);
   hipEventRecord(a, c->stream);
@@ -93,6 +93,11 @@ int ocn_profile_enable(ocn_ctx* ctx, int on) {
   if (!ctx) return OCN_EINVAL;
   if (!on) prof_collect(ctx);
   ctx->profiling = on != 0;
+  return OCN_OK;
+}
+int ocn_profile_filter(ocn_ctx* ctx, const char* phase) {
+  if (!ctx) return OCN_EINVAL;
+  ctx->prof_only = phase ? phase : "";
   return OCN_OK;
 }
 int ocn_profile_reset(ocn_ctx* ctx) {

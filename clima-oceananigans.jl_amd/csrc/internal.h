@@ -22,6 +22,7 @@ struct ocn_ctx {
   char err[512] = {0};
   bool profiling = false;
   std::map<std::string, ProfPhase> prof;
+  std::string prof_only;   // when set, only this phase records events (each record costs ~4 us of stream time)
   // multi-GPU
   int rank = 0, nranks = 1;
   void* comm = nullptr;  // ncclComm_t

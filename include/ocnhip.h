@@ -202,6 +202,9 @@ int ocn_comm_rank(const ocn_ctx* ctx, int* rank, int* nranks);
 /* average device time [ms] of the `n` most recent launches of the named phase, measured with HIP
  * events on the context stream when profiling is enabled */
 int ocn_profile_enable(ocn_ctx* ctx, int on);
+/* restrict event recording to one phase (NULL / "": all phases).  Every recorded event costs a few microseconds of
+ * stream time, so a benchmark that times whole steps records only the phase it reports. */
+int ocn_profile_filter(ocn_ctx* ctx, const char* phase);
 int ocn_profile_read(ocn_ctx* ctx, const char* phase, double* avg_ms, int64_t* count);
 int ocn_profile_reset(ocn_ctx* ctx);
 
