@@ -163,11 +163,14 @@ def main():
     # and a dozen of them per step is 3 % of a 1.4 ms step.
     PH_ALL = list(B_ALG_PHASE) + ["fused_tracer_step", "fill_halos", "store", "copy_pressure", "time_step", "halo_exchange",
                                   "transpose", "amd_diffusivities", "hydrostatic"]
-    # The card needs ~40 ms of load to leave its idle clocks (a 5-step run measures 1.52 ms/step, a 200-step run
-    # 1.32): when fewer than 30 warm-up steps are requested, untimed spin-up steps make up the difference.
-    spinup = max(0, 30 - args.warmup) if args.config == 2 and not args.size else 0
-    for _ in range(spinup):
+    # The card needs ~40 ms of load to leave its idle clocks (a 5-step run of config 2 measures 1.52 ms/step, a 200-step
+    # run 1.32): untimed spin-up steps run until 80 ms of stepping have passed (none if the warm-up already covers that).
+    spinup = 0
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.08:
         ocn.time_step(model, dt)
+        ctx.sync()
+        spinup += 1
     nprobe = min(2, args.warmup)
     for _ in range(args.warmup - nprobe):
         ocn.time_step(model, dt)
