@@ -29,6 +29,12 @@ CASES = {
     "ppp_c4": dict(size=(8, 10, 12), topo=(P, P, P), extent=(1, 1, 1), adv="C4", stepper="RK3", steps=2, dt=2e-3),
     "ppp_c2_default": dict(size=(8, 8, 8), topo=(P, P, P), extent=(1, 1, 1), adv="C2", stepper="AB2", steps=2, dt=2e-3,
                            halo=(1, 1, 1)),
+    # adaptive time stepping (TimeStepWizard): every change of dt is an Euler step with G^- zeroed
+    # (quasi_adams_bashforth_2.jl:74-84), on the fused path (pointer-rotated G buffers) and on the general one
+    "ppp_weno_ab2_varying_dt": dict(size=(12, 10, 8), topo=(P, P, P), extent=(1, 1, 1), adv="WENO5", stepper="AB2", steps=5,
+                                    dt=2e-3, dts=[2e-3, 2e-3, 1e-3, 1e-3, 3e-3], tracers=("c",)),
+    "ppb_c4_ab2_varying_dt": dict(size=(8, 8, 8), topo=(P, P, B), extent=(1, 1, 1), adv="C4", stepper="AB2", steps=5, dt=2e-3,
+                                  dts=[2e-3, 1e-3, 1e-3, 1e-3, 2e-3], tracers=("b",), buoyancy="b", closure=(1e-3, 1e-3)),
     # bounded z, regular (reference: FFT + cosine transform; here: Fourier-tridiagonal, same discrete system)
     "ppb_weno_full": dict(size=(12, 10, 9), topo=(P, P, B), extent=(1, 1, 1), adv="WENO5", stepper="RK3", steps=2, dt=2e-3,
                           tracers=("T", "S"), closure=(1e-3, 2e-3), coriolis=1e-1, buoyancy="TS"),
@@ -229,8 +235,9 @@ def run_case(ocn, name, check_each_step=True):
             worst[k] = max(worst.get(k, 0.0), err)
     compare("init")
     for s in range(cfg["steps"]):
-        O.time_step(om, cfg["dt"])
-        ocn.time_step(dm, cfg["dt"])
+        dt = cfg["dts"][s] if "dts" in cfg else cfg["dt"]   # a changing time step makes AB2 fall back to Euler (:74)
+        O.time_step(om, dt)
+        ocn.time_step(dm, dt)
         if check_each_step or s == cfg["steps"] - 1:
             compare(f"step{s}")
     assert abs(om.time - dm.time) < 1e-14 and om.iteration == dm.iteration

@@ -278,3 +278,50 @@ def test_halos_and_poisson_gpu(ocn, backend):
     _halos(ocn)
     _halos_degenerate(ocn)
     _poisson(ocn)
+
+
+# ---- phase-level entry points (what a Julia shim overloading one phase at a time would call) ---------------------------
+def _phase_level_equals_time_step(ocn, cfg_name):
+    """time_step! assembled by hand from the phase-level C entry points (quasi_adams_bashforth_2.jl:70-104 order:
+    tendencies, ab2_step, pressure correction, velocity correction, store, update_state) must reproduce ocn_time_step --
+    also right after fused steps, when G^n / G^- are pointer-rotated inside the library."""
+    import ctypes as C
+    import parity_cases as pc
+    cfg = pc.CASES[cfg_name]
+    a, b = pc.build(ocn, cfg), pc.build(ocn, cfg)
+    lib = a.lib
+    dt, chi = cfg["dt"], 0.1
+    for step in range(3):
+        ocn.time_step(a, dt)
+        if step == 1:
+            ocn.time_step(b, dt)             # one library-driven step in between (leaves rotated / aliased buffers)
+            continue
+        euler = step == 0
+        if euler:                            # first step: chi = -1/2 and G^- = 0 (:74-84)
+            for n, f in b.Gm.items():
+                f.set_parent(np.zeros(f.total))
+        assert lib.ocn_compute_tendencies(b.h) == 0
+        assert lib.ocn_ab2_step(b.h, C.c_double(dt), C.c_double(-0.5 if euler else chi)) == 0
+        assert lib.ocn_pressure_correction(b.h, C.c_double(dt)) == 0
+        assert lib.ocn_pressure_correct_velocities(b.h, C.c_double(dt)) == 0
+        assert lib.ocn_store_tendencies(b.h) == 0
+        assert lib.ocn_update_state(b.h) == 0
+        # the caller of the phase-level entry points owns the clock (TimeSteppers/clock.jl; previous_dt decides Euler vs AB2)
+        assert lib.ocn_set_clock(b.h, C.c_double((step + 1) * dt), C.c_int64(step + 1), C.c_double(dt)) == 0
+    for n in a.prognostic():
+        x, y = a.prognostic()[n].parent(), b.prognostic()[n].parent()
+        assert np.abs(x - y).max() <= 1e-12 * np.abs(x).max(), n
+    assert np.abs(a.pNHS.parent() - b.pNHS.parent()).max() <= 1e-11 * np.abs(a.pNHS.parent()).max()
+
+
+@pytest.mark.parametrize("cfg_name", ["ppp_weno_ab2", "ppb_c2_btracer", "pbb_u5_channel"])
+def test_phase_level_equals_time_step_hostemu(ocn, backend, cfg_name):
+    _run(ocn, backend, False)
+    _phase_level_equals_time_step(ocn, cfg_name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name", ["ppp_weno_ab2", "ppb_c2_btracer", "pbb_u5_channel"])
+def test_phase_level_equals_time_step_gpu(ocn, backend, cfg_name):
+    _run(ocn, backend, True)
+    _phase_level_equals_time_step(ocn, cfg_name)
