@@ -166,11 +166,16 @@ def main():
     # The card needs ~40 ms of load to leave its idle clocks (a 5-step run of config 2 measures 1.52 ms/step, a 200-step
     # run 1.32): untimed spin-up steps run until 80 ms of stepping have passed (none if the warm-up already covers that).
     spinup = 0
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.08:
-        ocn.time_step(model, dt)
-        ctx.sync()
-        spinup += 1
+    if world > 1:
+        for _ in range(40):            # every step is collective: all ranks must run the same number of them
+            ocn.time_step(model, dt)
+        spinup = 40
+    else:
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.08:
+            ocn.time_step(model, dt)
+            ctx.sync()
+            spinup += 1
     nprobe = min(2, args.warmup)
     for _ in range(args.warmup - nprobe):
         ocn.time_step(model, dt)
