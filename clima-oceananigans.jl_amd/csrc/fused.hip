@@ -36,7 +36,8 @@ struct FusedArgs {
   int use_m;
   int KZ;                         // levels per z-chunk
   int BYo;                        // output rows per workgroup (= blockDim.y - 1)
-  int ntiles;                     // y-tiles (v3: segment decomposition)
+  int ntiles;                     // y-tiles (v3: segment decomposition); x-tiled variant: ntx * nty
+  int ntx, BXo;                   // x-tiled variant: tiles along x, output columns per tile
   int dbg_nobar;                  // timing experiments only (OCNHIP_DBG_NOBAR): results are wrong
 };
 
@@ -396,6 +397,216 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
 #undef SLB
 }
 
+// ---- x-tiled variant of k_tend_step3 for rows wider than a workgroup (Nx > 256) ------------------------------------
+// A workgroup owns BXo < BX output columns of BY-1 output rows.  Thread column `nout` is a ghost column: it only
+// produces the WEST-face fluxes that the last output column needs as its EAST fluxes (the same device as the ghost
+// row in y); x halos of the slab are read from the arrays' own halo columns (the projection keeps their periodic
+// images current) instead of being wrapped inside LDS.  Tiles are (x-tile, y-tile) pairs, x fastest.
+template <int ADV, int BX, int BY>
+__global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) {
+  constexpr bool EARLY = true, FENCE3 = false;
+  constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
+  constexpr int NG = (NR + BY - 1) / BY;   // row groups of the cooperative slab load
+  OCN_SHARED double slab[3 * NR * SX];     // [field][row][column]; element (f, r, s) <-> (j0 - 3 + r, s - 3)
+  OCN_SHARED double fx[6 * T];             // flux exchange
+  OCN_SHARED double own[6 * T];            // carry: horizontal divergence + bottom fluxes of the previous level
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tid = ty * BX + tx;
+  const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
+  const double rdx = g.rdx, rdy = g.rdy, rdz = 1.0 / g.dz;
+  const bool ghost = (ty == BY - 1);
+  const int nid_e = ty * BX + (tx + 1 < BX ? tx + 1 : tx);   // the east neighbour is the next thread (output or ghost column)
+  const int nid_n = (ty + 1 < BY ? ty + 1 : ty) * BX + tx;
+  // Work decomposition: the (y-tile, level) space is cut into gridDim.x equal segments of consecutive levels
+  // (tile-major), so every workgroup marches the same number of levels whatever Ny/(BY-1) is -- no partial
+  // last round.  XCD-aware: workgroups b and b+8 share an L2, so each XCD gets a contiguous band of segments.
+  const int nseg = gridDim.x, per = nseg / 8;
+  const long seg = (long)(blockIdx.x % 8) * per + blockIdx.x / 8;
+  const long total = (long)a.ntiles * g.Nz;
+  long lo = seg * total / nseg;
+  const long hi = (seg + 1) * total / nseg;
+  while (lo < hi) {
+  const int tile = (int)(lo / g.Nz);
+  const int k0 = (int)(lo - (long)tile * g.Nz);
+  const int ytile = tile / a.ntx, xt = tile - ytile * a.ntx;
+  const int i0 = xt * a.BXo;
+  const int nout = (g.Nx - i0 < a.BXo) ? g.Nx - i0 : a.BXo;   // output columns of this x-tile; column `nout` is the ghost column
+  const int i = i0 + tx;
+  const bool ocol = tx < nout, col_ok = tx <= nout, ldcol = tx < nout + 7;
+  const int k1 = (k0 + (hi - lo) < g.Nz) ? (int)(k0 + (hi - lo)) : g.Nz;
+  lo += k1 - k0;
+  const int j0 = ytile * (BY - 1);
+  const int j = j0 + ty;
+  const bool row_ok = j < g.Ny;
+  const bool do_y = ocol && j <= g.Ny;
+  const bool full = ocol && row_ok && !ghost;
+  const bool do_x = col_ok && row_ok && !ghost;      // west-face fluxes, ghost column included
+  const unsigned cxy = a.org + (unsigned)(col_ok ? i : 0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
+
+  // cooperative slab load: thread row ty handles slab rows r = ty + BY*gq of every field
+  const unsigned grow = a.org + (unsigned)((ldcol ? i0 + tx : i0 + 3) - 3) * sxb;   // slab column tx <-> global column i0 - 3 + tx
+  double pf[3][NG];
+  auto prefetch = [&](int k) {
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+      int r = ty + BY * gq;
+      if (r < NR) {
+        int jg = j0 - 3 + r;
+        if (jg > g.Ny + 2) jg = g.Ny + 2;              // rows past the halo are never used
+        unsigned o = grow + (unsigned)(jg + 3) * syb - 3u * syb + (unsigned)k * szb;
+        pf[0][gq] = ldo(a.u, o);
+        pf[1][gq] = ldo(a.v, o);
+        pf[2][gq] = ldo(a.w, o);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+      int r = ty + BY * gq;
+      if (r < NR && ldcol) {
+#pragma unroll
+        for (int fl = 0; fl < 3; ++fl) slab[(fl * NR + r) * SX + tx] = pf[fl][gq];   // x halos come from the arrays' own halos
+      }
+    }
+  };
+  // lowest corner of this thread's stencil footprint: element (f, ty + d, tx + e) = S[f*NR*SX + d*SX + e],
+  // own cell at d = e = 3.  All offsets below are compile-time constants.
+  const double* S = slab + ty * SX + tx;
+#define SLB(f, d, e) S[(f) * NR * SX + (d) * SX + (e)]
+
+  double zu[6], zv[6], zw[6];
+  {
+    const unsigned c = cxy + (unsigned)k0 * szb;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      zu[q] = ldo(a.u, c + (unsigned)(q - 3) * szb);
+      zv[q] = ldo(a.v, c + (unsigned)(q - 3) * szb);
+      zw[q] = ldo(a.w, c + (unsigned)(q - 3) * szb);
+    }
+  }
+  prefetch(k0);
+  for (int k = k0; k <= k1; ++k) {
+    const unsigned c = cxy + (unsigned)k * szb;
+    const bool last = (k == k1);
+    commit();
+    if (!(a.dbg_nobar & 2)) __syncthreads();
+    if (EARLY && !last) prefetch(k + 1);   // next level's slab in flight during the whole flux stage
+    double gm0 = 0, gm1 = 0, gm2 = 0;      // G^- of the level finalized below, also fetched early
+    if (EARLY && a.use_m && full && k > k0) {
+      gm0 = ldo(a.gmu, c - szb);
+      gm1 = ldo(a.gmv, c - szb);
+      gm2 = ldo(a.gmw, c - szb);
+    }
+    auto symz = [&](const double* z) { return sym4_v(z[1], z[2], z[3], z[4]); };
+    auto reconz = [&](const double* z, double ut) {
+      bool pos = ut > 0.0;
+      return recon5<ADV>(pos ? z[0] : z[5], pos ? z[1] : z[4], pos ? z[2] : z[3], pos ? z[3] : z[2],
+                         pos ? z[4] : z[1], pos);
+    };
+    auto sym_v = [&](double m2, double m1, double c0, double c1) { return sym4_v(m2, m1, c0, c1); };  // midway m1|c0
+    auto rec_v = [&](double m3, double m2, double m1, double c0, double c1, double c2, double ut) {
+      bool pos = ut > 0.0;                                            // face between m1 and c0
+      return recon5<ADV>(pos ? m3 : c2, pos ? m2 : c1, pos ? m1 : c0, pos ? c0 : m1, pos ? c1 : m2, pos);
+    };
+#define XSYM(f) sym_v(SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4))
+#define YSYM(f) sym_v(SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3))
+#define XREC(f, ut) rec_v(SLB(f, 3, 0), SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4), SLB(f, 3, 5), ut)
+#define YREC(f, ut) rec_v(SLB(f, 0, 3), SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3), SLB(f, 5, 3), ut)
+    if (!last) {
+      if (do_x) {
+        double utu = XSYM(0);                          // centre i-1
+        fx[0 * T + tid] = utu * XREC(0, utu);
+        if (FENCE3) OCN_SCHED_FENCE();
+        double utv = YSYM(0);                          // u interpolated in y to the v row
+        fx[1 * T + tid] = utv * XREC(1, utv);
+        if (FENCE3) OCN_SCHED_FENCE();
+        double utw = symz(zu);                         // u interpolated in z to the w level
+        fx[2 * T + tid] = utw * XREC(2, utw);
+        if (FENCE3) OCN_SCHED_FENCE();
+      }
+      if (do_y) {
+        double vtu = XSYM(1);                          // v interpolated in x to the u column
+        fx[3 * T + tid] = vtu * YREC(0, vtu);
+        if (FENCE3) OCN_SCHED_FENCE();
+        double vtv = YSYM(1);                          // centre j-1
+        fx[4 * T + tid] = vtv * YREC(1, vtv);
+        if (FENCE3) OCN_SCHED_FENCE();
+        double vtw = symz(zv);
+        fx[5 * T + tid] = vtw * YREC(2, vtw);
+        if (FENCE3) OCN_SCHED_FENCE();
+      }
+    }
+    double Fwu = 0, Fwv = 0, Fww = 0;
+    if (full) {
+      double wtu = XSYM(2);
+      Fwu = wtu * reconz(zu, wtu);
+      if (FENCE3) OCN_SCHED_FENCE();
+      double wtv = YSYM(2);
+      Fwv = wtv * reconz(zv, wtv);
+      if (FENCE3) OCN_SCHED_FENCE();
+      double wtw = symz(zw);
+      Fww = wtw * reconz(zw, wtw);
+    }
+#undef XSYM
+#undef YSYM
+#undef XREC
+#undef YREC
+    if (!(a.dbg_nobar & 1)) __syncthreads();
+    if (!EARLY && !last) prefetch(k + 1);  // in flight during the (cheap) finalize stage; committed at the loop top
+    if (full) {
+      if (k > k0) {
+        const unsigned cm1 = c - szb;
+        double Gu = -(own[0 * T + tid] + (Fwu - own[3 * T + tid]) * rdz);
+        double Gv = -(own[1 * T + tid] + (Fwv - own[4 * T + tid]) * rdz);
+        double Gw = -(own[2 * T + tid] + (Fww - own[5 * T + tid]) * rdz);
+        sto(a.gnu, cm1, Gu);
+        sto(a.gnv, cm1, Gv);
+        sto(a.gnw, cm1, Gw);
+        double iu, iv, iw;
+        if (a.use_m) {
+          if (!EARLY) {
+            gm0 = ldo(a.gmu, cm1);
+            gm1 = ldo(a.gmv, cm1);
+            gm2 = ldo(a.gmw, cm1);
+          }
+          iu = a.dt * (a.cn * Gu + a.cm * gm0);
+          iv = a.dt * (a.cn * Gv + a.cm * gm1);
+          iw = a.dt * (a.cn * Gw + a.cm * gm2);
+        } else {
+          iu = a.dt * a.cn * Gu;
+          iv = a.dt * a.cn * Gv;
+          iw = a.dt * a.cn * Gw;
+        }
+        sto(a.us, cm1, zu[2] + iu);
+        sto(a.vs, cm1, zv[2] + iv);
+        sto(a.ws, cm1, zw[2] + iw);
+      }
+      if (!last) {
+        own[0 * T + tid] = (fx[0 * T + nid_e] - fx[0 * T + tid]) * rdx + (fx[3 * T + nid_n] - fx[3 * T + tid]) * rdy;
+        own[1 * T + tid] = (fx[1 * T + nid_e] - fx[1 * T + tid]) * rdx + (fx[4 * T + nid_n] - fx[4 * T + tid]) * rdy;
+        own[2 * T + tid] = (fx[2 * T + nid_e] - fx[2 * T + tid]) * rdx + (fx[5 * T + nid_n] - fx[5 * T + tid]) * rdy;
+        own[3 * T + tid] = Fwu;
+        own[4 * T + tid] = Fwv;
+        own[5 * T + tid] = Fww;
+      }
+    }
+    if (!last) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        zu[q] = zu[q + 1];
+        zv[q] = zv[q + 1];
+        zw[q] = zw[q + 1];
+      }
+      zu[5] = ldo(a.u, c + 3 * szb);
+      zv[5] = ldo(a.v, c + 3 * szb);
+      zw[5] = ldo(a.w, c + 3 * szb);
+    }
+  }
+  }  // segments
+#undef SLB
+}
+
 // ---- Poisson right-hand side with wrap indexing (no halo fill of the predictor) ----------------------
 __global__ void k_rhs_wrap(GridDev g, const double* __restrict__ us, const double* __restrict__ vs,
                            const double* __restrict__ ws, double rdt, int zwrap, double* __restrict__ rhs) {
@@ -530,7 +741,6 @@ bool fused_available(const ocn_model* m) {
   if (m->d.closure != OCN_CLOSURE_NONE || m->d.coriolis_fplane || m->d.buoyancy != OCN_BUOYANCY_NONE) return false;
   for (int d = 0; d < 3; ++d)
     if (g->H[d] < 3 || g->N[d] < 2 * g->H[d]) return false;
-  if (g->N[0] > FUSED_MAX_THREADS / 2) return false;   // a workgroup must own complete x rows (+ a ghost row)
   if (m->u.n * sizeof(double) >= (1ull << 31)) return false;   // 32-bit byte offsets
   if (getenv("OCNHIP_NO_FUSED")) return false;
   return true;
@@ -569,7 +779,8 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
   hipStream_t s = m->ctx->stream;
   static const bool fence = getenv("OCNHIP_FENCE") && atoi(getenv("OCNHIP_FENCE")) != 0;
   static const int variant = getenv("OCNHIP_FUSED_VARIANT") ? atoi(getenv("OCNHIP_FUSED_VARIANT")) : 3;
-  if (variant == 3 && m->gd.Nx <= 256) {
+  const int xt_env0 = getenv("OCNHIP_FUSED_XT") ? atoi(getenv("OCNHIP_FUSED_XT")) : 0;   // read per launch: tests toggle it
+  if (variant == 3 && m->gd.Nx <= 256 && xt_env0 != 1) {
     // v3 is compiled for three workgroup shapes (complete x rows of up to 64 / 128 / 256 cells)
     const GridDev& gd = m->gd;
     int bx = gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
@@ -609,6 +820,44 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
       default: V3_CASE(ADV_U5) break;
     }
 #undef V3_CASE
+    return;
+  }
+  const int xt_env = xt_env0;   // 1: force the x-tiled kernel (tests)
+  if (variant == 3 || m->gd.Nx > FUSED_MAX_THREADS / 2) {
+    // rows wider than a workgroup: x-tiled kernel, 192 x 5 threads (up to 185 output columns x 4 output rows per tile)
+    const GridDev& gd = m->gd;
+    const bool small = xt_env == 1 && gd.Nx <= 57 * 4;          // test shape: 64 x 4 threads, up to 57 output columns
+    const int bx = small ? 64 : 192, by = small ? 4 : 5;
+    const int cap = bx - 7;
+    a.ntx = (gd.Nx + cap - 1) / cap;
+    if (small && a.ntx < 2) a.ntx = 2;                           // make the test exercise an interior tile boundary
+    a.BXo = (gd.Nx + a.ntx - 1) / a.ntx;
+    a.BYo = by - 1;
+    const int nty = (gd.Ny + by - 2) / (by - 1);
+    a.ntiles = a.ntx * nty;
+    static int ncu2 = 0;
+    if (!ncu2) {
+#ifndef OCN_HOST_EMU
+      hipDeviceProp_t prop;
+      ncu2 = (hipGetDeviceProperties(&prop, m->ctx->device) == hipSuccess) ? prop.multiProcessorCount : 256;
+#else
+      ncu2 = 8;
+#endif
+    }
+    int nseg = ncu2;
+    long total = (long)a.ntiles * gd.Nz;
+    if (nseg > total / 4) nseg = (int)(total / 4 > 8 ? total / 4 : 8);
+    nseg = ((nseg + 7) / 8) * 8;
+    dim3 blk(bx, by, 1), grd(nseg, 1, 1);
+#define V3X_CASE(ADVV)                                                                     \
+    if (small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4>, grd, blk, s, m->gd, a);         \
+    else ocn_launch_sync(k_tend_step3x<ADVV, 192, 5>, grd, blk, s, m->gd, a);
+    switch (m->d.advection) {
+      case ADV_WENO_Z: V3X_CASE(ADV_WENO_Z) break;
+      case ADV_WENO_JS: V3X_CASE(ADV_WENO_JS) break;
+      default: V3X_CASE(ADV_U5) break;
+    }
+#undef V3X_CASE
     return;
   }
   switch (m->d.advection) {

@@ -62,6 +62,25 @@ def test_headline_kernels_vs_oracle(ocn, N, stepper, tracers):
         assert np.abs(a.parent() - b.data).max() <= 2e-11 * np.abs(b.data).max()
 
 
+@pytest.mark.parametrize("N", [(320, 24, 16), (512, 16, 12), (700, 12, 8)])
+def test_wide_rows_vs_oracle(ocn, N):
+    """Rows wider than a workgroup (Nx > 256) take the x-tiled tendency kernel: 2 to 4 x-tiles per row, vs the oracle."""
+    import oracle as O
+    rng = np.random.default_rng(8)
+    init = {n: rng.random(N) - 0.5 for n in "uvw"}
+    kw = dict(size=N, extent=(N[0] / 64, N[1] / 64, N[2] / 64), topology=("Periodic",) * 3)
+    m = ocn.NonhydrostaticModel(ocn.RectilinearGrid(**kw), advection=ocn.WENO5())
+    om = O.NonhydrostaticModel(O.RectilinearGrid(**kw), advection=O.WENO5())
+    ocn.set_model(m, **init)
+    O.set_model(om, **init)
+    dt = 0.2 / 64 / np.abs(om.u.data).max()
+    for _ in range(2):
+        ocn.time_step(m, dt)
+        O.time_step(om, dt)
+    for a, b in ((m.u, om.u), (m.v, om.v), (m.w, om.w), (m.pNHS, om.pNHS)):
+        assert np.abs(a.parent() - b.data).max() <= 2e-11 * np.abs(b.data).max()
+
+
 def test_full_size_properties(ocn):
     """BASELINE config 2 (256^3, WENO5, AB2): projection leaves max|div U| ~ roundoff, halos are periodic
     images, and the Poisson solve satisfies lap(phi) = R to roundoff."""

@@ -13,3 +13,14 @@ def test_case_matches_oracle(ocn, backend, name):
     worst = run_case(ocn, name)
     bad = {k: v for k, v in worst.items() if v > CASES[name].get("tol", 2e-11)}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["ppp_weno_ab2", "ppp_weno_rk3_2tracers", "ppp_wenojs_tracer"])
+def test_x_tiled_tendency_kernel(ocn, backend, name, monkeypatch):
+    """The kernel for rows wider than a workgroup (Nx > 256), forced onto small grids with two x-tiles per row."""
+    if backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    monkeypatch.setenv("OCNHIP_FUSED_XT", "1")
+    worst = run_case(ocn, name)
+    bad = {k: v for k, v in worst.items() if v > 2e-11}
+    assert not bad, bad
