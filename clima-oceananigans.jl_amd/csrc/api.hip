@@ -192,7 +192,10 @@ static int grid_build_dev(ocn_grid* g) {
   d.dz = d.zflat ? 1.0 : (double)((long double)g->L[2] / (g->dist ? g->Nzg : g->N[2]));
   hipFree(g->d_dzc);
   hipFree(g->d_dzf);
-  g->d_dzc = g->d_dzf = nullptr;
+  hipFree(g->d_rdzc);
+  hipFree(g->d_rdzf);
+  g->d_dzc = g->d_dzf = g->d_rdzc = g->d_rdzf = nullptr;
+  d.rdz = 1.0 / d.dz;
   if (!g->z_regular) {
     stretched_spacings(g->zF_int, g->N[2], g->H[2], g->topo[2] == OCN_BOUNDED, g->h_dzc, g->h_dzf);
     OCN_HIP_CHECK(g->ctx, hipMalloc((void**)&g->d_dzc, g->h_dzc.size() * sizeof(double)));
@@ -201,6 +204,15 @@ static int grid_build_dev(ocn_grid* g) {
     OCN_HIP_CHECK(g->ctx, hipMemcpy(g->d_dzf, g->h_dzf.data(), g->h_dzf.size() * sizeof(double), hipMemcpyHostToDevice));
     d.dzc = g->d_dzc;
     d.dzf = g->d_dzf;
+    std::vector<double> rc(g->h_dzc.size()), rf(g->h_dzf.size());
+    for (size_t i = 0; i < rc.size(); ++i) rc[i] = 1.0 / g->h_dzc[i];
+    for (size_t i = 0; i < rf.size(); ++i) rf[i] = 1.0 / g->h_dzf[i];
+    OCN_HIP_CHECK(g->ctx, hipMalloc((void**)&g->d_rdzc, rc.size() * sizeof(double)));
+    OCN_HIP_CHECK(g->ctx, hipMalloc((void**)&g->d_rdzf, rf.size() * sizeof(double)));
+    OCN_HIP_CHECK(g->ctx, hipMemcpy(g->d_rdzc, rc.data(), rc.size() * sizeof(double), hipMemcpyHostToDevice));
+    OCN_HIP_CHECK(g->ctx, hipMemcpy(g->d_rdzf, rf.data(), rf.size() * sizeof(double), hipMemcpyHostToDevice));
+    d.rdzc = g->d_rdzc;
+    d.rdzf = g->d_rdzf;
   }
   return OCN_OK;
 }
@@ -303,6 +315,8 @@ void ocn_grid_destroy(ocn_grid* g) {
   if (!g) return;
   hipFree(g->d_dzc);
   hipFree(g->d_dzf);
+  hipFree(g->d_rdzc);
+  hipFree(g->d_rdzf);
   delete g;
 }
 
@@ -667,6 +681,10 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
     ocn_model_destroy(m);
     return OCN_ENOMEM;
   }
+  if (desc->closure == OCN_CLOSURE_AMD && amd_build_table(m) != OCN_OK) {
+    ocn_model_destroy(m);
+    return OCN_ENOMEM;
+  }
   if (hipMalloc((void**)&m->d_red, 64) != hipSuccess) {
     ocn_model_destroy(m);
     return OCN_ENOMEM;
@@ -709,6 +727,7 @@ void ocn_model_destroy(ocn_model* m) {
   for (double* p : m->owned) hipFree(p);
   hipFree(m->d_red);
   hipFree(m->phi_below);
+  hipFree(m->amd_tab);
   hipFree(m->ypack_s);
   hipFree(m->ypack_r);
   poisson_destroy(m->solver);

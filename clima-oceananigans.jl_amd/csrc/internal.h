@@ -52,6 +52,7 @@ struct ocn_grid {
   std::vector<double> h_dzc, h_dzf;      // host spacings incl. halos (stretched), layout as GridDev
   double* d_dzc = nullptr;
   double* d_dzf = nullptr;
+  double *d_rdzc = nullptr, *d_rdzf = nullptr;
   GridDev dev;                           // for the current halo
 };
 
@@ -103,6 +104,7 @@ struct ocn_model {
   int stage = 1;
   double* d_red = nullptr;  // reduction scratch
   int fast_path = 0;        // 1: fused periodic WENO kernels usable
+  double* amd_tab = nullptr;     // per-level factors of the AMD predictors (kernels.hip amd_build_table)
   double* phi_below = nullptr;   // (Nx,Ny): top plane of the lower neighbour's pressure (slab runs)
   double *ypack_s = nullptr, *ypack_r = nullptr;   // y-slab halo exchange staging (send / receive)
   size_t ypack_n = 0;
@@ -129,6 +131,7 @@ void launch_hydrostatic(ocn_model* m);
 void launch_copy_to_field(ocn_model* m, const double* src, Field& f);
 void launch_maxdiv(ocn_model* m, double* out_dev);
 void launch_amd(ocn_model* m);
+int amd_build_table(ocn_model* m);
 
 // ---- fused.hip -----------------------------------------------------------------------------------------
 bool fused_available(const ocn_model* m);

@@ -63,8 +63,8 @@ __global__ void k_tend_uvw(GridDev g, Phys ph, const double* __restrict__ u, con
   const bool xb = WALLS && g.xb != 0, yb = WALLS && g.yb != 0, zb = g.zb != 0, zf = g.zflat != 0;   // WALLS: Bounded x or y
   const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz, nb = g.nb;
   const double rdx = g.rdx, rdy = g.rdy;
-  const double rdzc = zf ? 0.0 : 1.0 / g_dzc(g, k);
-  const double rdzf = zf ? 0.0 : 1.0 / g_dzf(g, k);
+  const double rdzc = zf ? 0.0 : g_rdzc(g, k);
+  const double rdzf = zf ? 0.0 : g_rdzf(g, k);
   double gu = 0, gv = 0, gw = 0;
 
   if (ADV != ADV_NONE) {
@@ -124,7 +124,7 @@ __global__ void k_tend_uvw(GridDev g, Phys ph, const double* __restrict__ u, con
   }
   // ---- viscous stress divergence (closure_kernel_operators.jl:22-41; fluxes -2 nu Sigma) ----
   if (ph.closure != OCN_CLOSURE_NONE) {
-    auto rzf = [&](int kf) { return zf ? 0.0 : 1.0 / g_dzf(g, kf); };
+    auto rzf = [&](int kf) { return zf ? 0.0 : g_rdzf(g, kf); };
     auto S11 = [&](long p) { return (u[p + 1] - u[p]) * rdx; };
     auto S22 = [&](long p) { return (v[p + sy] - v[p]) * rdy; };
     auto S33 = [&](long p, int kc) { return zf ? 0.0 : (w[p + sz] - w[p]) / g_dzc(g, kc); };
@@ -164,7 +164,7 @@ __global__ void k_tend_c(GridDev g, const double* __restrict__ u, const double* 
   const int kk = k + 1;
   const bool zb = g.zb != 0, zf = g.zflat != 0;
   const double rdx = g.rdx, rdy = g.rdy;
-  const double rdzc = zf ? 0.0 : 1.0 / g_dzc(g, k);
+  const double rdzc = zf ? 0.0 : g_rdzc(g, k);
   double gc = 0;
   if (ADV != ADV_NONE) {
     // tracer_advection_operators.jl:31-35; advecting velocity un-interpolated
@@ -605,17 +605,23 @@ struct AmdCtx {
   const double *u, *v, *w;
   long sy, sz;
   double rdx, rdy, Dx, Dy;
+  double xy, yx;            // Dx / Dy, Dy / Dx
+  // per-level factors, entry [k + Hz] for k in [-Hz, Nz + Hz] (built once on the host, see amd_build_table): the
+  // kernel used to spend two thirds of its instructions on FP64 divisions whose operands are the same for every
+  // thread of a level.
+  const double *Dz, *xz, *zx, *yz, *zy, *rdzf, *rdzc, *d2;
+  int Hz;
 };
-OCN_DEVFN double amd_Dz(const AmdCtx& a, int k) { return 2.0 * g_dzc(a.g, k); }
+OCN_DEVFN double amd_Dz(const AmdCtx& a, int k) { return a.Dz[k + a.Hz]; }
 OCN_DEVFN double amd_dxu(const AmdCtx& a, long p) { return (a.u[p + 1] - a.u[p]) * a.rdx; }
 OCN_DEVFN double amd_dyv(const AmdCtx& a, long p) { return (a.v[p + a.sy] - a.v[p]) * a.rdy; }
-OCN_DEVFN double amd_dzw(const AmdCtx& a, long p, int k) { return (a.w[p + a.sz] - a.w[p]) / g_dzc(a.g, k); }
-OCN_DEVFN double amd_ndxv(const AmdCtx& a, long p) { return a.Dx / a.Dy * ((a.v[p] - a.v[p - 1]) * a.rdx); }
-OCN_DEVFN double amd_ndyu(const AmdCtx& a, long p) { return a.Dy / a.Dx * ((a.u[p] - a.u[p - a.sy]) * a.rdy); }
-OCN_DEVFN double amd_ndxw(const AmdCtx& a, long p, int k) { return a.Dx / amd_Dz(a, k) * ((a.w[p] - a.w[p - 1]) * a.rdx); }
-OCN_DEVFN double amd_ndzu(const AmdCtx& a, long p, int k) { return amd_Dz(a, k) / a.Dx * ((a.u[p] - a.u[p - a.sz]) / g_dzf(a.g, k)); }
-OCN_DEVFN double amd_ndyw(const AmdCtx& a, long p, int k) { return a.Dy / amd_Dz(a, k) * ((a.w[p] - a.w[p - a.sy]) * a.rdy); }
-OCN_DEVFN double amd_ndzv(const AmdCtx& a, long p, int k) { return amd_Dz(a, k) / a.Dy * ((a.v[p] - a.v[p - a.sz]) / g_dzf(a.g, k)); }
+OCN_DEVFN double amd_dzw(const AmdCtx& a, long p, int k) { return (a.w[p + a.sz] - a.w[p]) * a.rdzc[k + a.Hz]; }
+OCN_DEVFN double amd_ndxv(const AmdCtx& a, long p) { return a.xy * ((a.v[p] - a.v[p - 1]) * a.rdx); }
+OCN_DEVFN double amd_ndyu(const AmdCtx& a, long p) { return a.yx * ((a.u[p] - a.u[p - a.sy]) * a.rdy); }
+OCN_DEVFN double amd_ndxw(const AmdCtx& a, long p, int k) { return a.xz[k + a.Hz] * ((a.w[p] - a.w[p - 1]) * a.rdx); }
+OCN_DEVFN double amd_ndzu(const AmdCtx& a, long p, int k) { return a.zx[k + a.Hz] * ((a.u[p] - a.u[p - a.sz]) * a.rdzf[k + a.Hz]); }
+OCN_DEVFN double amd_ndyw(const AmdCtx& a, long p, int k) { return a.yz[k + a.Hz] * ((a.w[p] - a.w[p - a.sy]) * a.rdy); }
+OCN_DEVFN double amd_ndzv(const AmdCtx& a, long p, int k) { return a.zy[k + a.Hz] * ((a.v[p] - a.v[p - a.sz]) * a.rdzf[k + a.Hz]); }
 OCN_DEVFN double amd_S12(const AmdCtx& a, long p) { return 0.5 * (amd_ndyu(a, p) + amd_ndxv(a, p)); }
 OCN_DEVFN double amd_S13(const AmdCtx& a, long p, int k) { return 0.5 * (amd_ndzu(a, p, k) + amd_ndxw(a, p, k)); }
 OCN_DEVFN double amd_S23(const AmdCtx& a, long p, int k) { return 0.5 * (amd_ndzv(a, p, k) + amd_ndyw(a, p, k)); }
@@ -671,8 +677,7 @@ __global__ void k_amd_all(AmdCtx a, double Cnu, double* __restrict__ nu, AmdTrac
   const double yz_dyw2 = amd_Iyz(a, c, k, [&](long p, int kk) { return sq(ndyw(p, kk)); });
   const double yz_dzv2 = amd_Iyz(a, c, k, [&](long p, int kk) { return sq(ndzv(p, kk)); });
   const double q = sq(dxu) + sq(dyv) + sq(dzw) + xy_dxv2 + xy_dyu2 + xz_dxw2 + xz_dzu2 + yz_dyw2 + yz_dzv2;
-  const double Dz = amd_Dz(a, k);
-  const double d2 = 3.0 / (1.0 / (a.Dx * a.Dx) + 1.0 / (a.Dy * a.Dy) + 1.0 / (Dz * Dz));
+  const double d2 = a.d2[k + a.Hz];
   double nus = 0.0;
   if (q != 0.0) {
     const double r1 = S11 * sq(dxu) + S22 * xy_dxv2 + S33 * xz_dxw2 +
@@ -697,7 +702,7 @@ __global__ void k_amd_all(AmdCtx a, double Cnu, double* __restrict__ nu, AmdTrac
     // normalised tracer gradients at fcc / cfc / ccf
     auto nx = [&](long p) { return a.Dx * ((q_[p] - q_[p - 1]) * a.rdx); };
     auto ny = [&](long p) { return a.Dy * ((q_[p] - q_[p - sy]) * a.rdy); };
-    auto nz = [&](long p, int kk) { return amd_Dz(a, kk) * ((q_[p] - q_[p - sz]) / g_dzf(g, kk)); };
+    auto nz = [&](long p, int kk) { return amd_Dz(a, kk) * ((q_[p] - q_[p - sz]) * a.rdzf[kk + a.Hz]); };
     const double x0 = nx(c), x1 = nx(c + 1), y0 = ny(c), y1 = ny(c + sy), z0 = nz(c, k), z1 = nz(c + sz, k + 1);
     const double Ix_c = 0.5 * (x0 + x1), Iy_c = 0.5 * (y0 + y1), Iz_c = 0.5 * (z0 + z1);
     const double Ix_c2 = 0.5 * (sq(x0) + sq(x1)), Iy_c2 = 0.5 * (sq(y0) + sq(y1)), Iz_c2 = 0.5 * (sq(z0) + sq(z1));
@@ -714,6 +719,33 @@ __global__ void k_amd_all(AmdCtx a, double Cnu, double* __restrict__ nu, AmdTrac
 }
 
 // calculate_diffusivities!(diffusivity_fields, closure::AMD, model)  (anisotropic_minimum_dissipation.jl:180-205)
+// per-level factors of the AMD predictors (filter widths 2 dz_c(k) :213-226, their ratios, 1/dz, delta^2 :150)
+int amd_build_table(ocn_model* m) {
+  const ocn_grid* g = m->g;
+  const GridDev& gd = m->gd;
+  const int H = gd.Hz, L = gd.Nz + 2 * H + 1;
+  auto dzc = [&](int k) { return g->z_regular ? gd.dz : g->h_dzc[k + H]; };
+  auto dzf = [&](int k) { return g->z_regular ? gd.dz : g->h_dzf[k + H + 1]; };
+  const double Dx = 2.0 * gd.dx, Dy = 2.0 * gd.dy;
+  std::vector<double> t(8 * (size_t)L);
+  for (int k = -H; k <= gd.Nz + H; ++k) {
+    const int e = k + H;
+    const double Dz = 2.0 * dzc(k);
+    t[e] = Dz;
+    t[L + e] = Dx / Dz;
+    t[2 * L + e] = Dz / Dx;
+    t[3 * L + e] = Dy / Dz;
+    t[4 * L + e] = Dz / Dy;
+    t[5 * L + e] = 1.0 / dzf(k);
+    t[6 * L + e] = 1.0 / dzc(k);
+    const double ix = 1.0 / (Dx * Dx), iy = 1.0 / (Dy * Dy), iz = 1.0 / (Dz * Dz);
+    t[7 * L + e] = 3.0 / (ix + iy + iz);
+  }
+  if (hipMalloc((void**)&m->amd_tab, t.size() * sizeof(double)) != hipSuccess) return OCN_ENOMEM;
+  hipMemcpy(m->amd_tab, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice);
+  return OCN_OK;
+}
+
 void launch_amd(ocn_model* m) {
   ProfScope ps(m->ctx, "amd_diffusivities");
   const GridDev& g = m->gd;
@@ -722,6 +754,12 @@ void launch_amd(ocn_model* m) {
   a.u = m->u.interior(); a.v = m->v.interior(); a.w = m->w.interior();
   a.sy = g.sy; a.sz = g.sz; a.rdx = g.rdx; a.rdy = g.rdy;
   a.Dx = 2.0 * g.dx; a.Dy = 2.0 * g.dy;
+  a.xy = a.Dx / a.Dy; a.yx = a.Dy / a.Dx;
+  const int L = g.Nz + 2 * g.Hz + 1;
+  const double* tab = m->amd_tab;
+  a.Dz = tab; a.xz = tab + L; a.zx = tab + 2 * L; a.yz = tab + 3 * L; a.zy = tab + 4 * L; a.rdzf = tab + 5 * L;
+  a.rdzc = tab + 6 * L; a.d2 = tab + 7 * L;
+  a.Hz = g.Hz;
   static const dim3 b = tuned_block("OCNHIP_AMD_BLOCK", dim3(64, 4, 1));
   const dim3 gr = grid3(g, b);
   AmdTracers T;

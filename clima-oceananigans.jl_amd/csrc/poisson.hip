@@ -428,8 +428,8 @@ __global__ void k_tridiag(GridDev g, int Nxh, int Ny, int Nz, const double* __re
   const size_t ncol = (size_t)Nxh * Ny, col = i + (size_t)Nxh * j;
   const double lam = lx[i] + ly[j];
   auto diag = [&](int k) -> double {  // k: 0-based centre index
-    double up = (k < Nz - 1) ? 1.0 / g_dzf(g, k + 1) : 0.0;
-    double lo = (k > 0) ? 1.0 / g_dzf(g, k) : 0.0;
+    double up = (k < Nz - 1) ? g_rdzf(g, k + 1) : 0.0;
+    double lo = (k > 0) ? g_rdzf(g, k) : 0.0;
     return -(up + lo) - g_dzc(g, k) * lam;
   };
   // Only Nxh*Ny threads exist (a few waves per CU) and every level depends on the one before, so the sweep is
@@ -451,7 +451,7 @@ __global__ void k_tridiag(GridDev g, int Nxh, int Ny, int Nz, const double* __re
     for (int q = 0; q < PF; ++q) {
       const int k = k0 + q;
       if (k >= Nz || kbreak != Nz) break;
-      double off = 1.0 / g_dzf(g, k);  // a^{k-1} = c^{k-1} = 1/dzf(k) (1-based face k+1 -> 0-based face k)
+      double off = g_rdzf(g, k);  // a^{k-1} = c^{k-1} = 1/dzf(k) (1-based face k+1 -> 0-based face k)
       double tk = off / beta;
       t[col + ncol * k] = tk;
       beta = diag(k) - off * tk;

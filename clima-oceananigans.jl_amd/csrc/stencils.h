@@ -21,6 +21,8 @@ struct GridDev {
   double rdx, rdy;
   const double* dzc;        // stretched z: spacing at centres, entry [k + Hz]   (k = 0-based centre index)
   const double* dzf;        //              spacing at faces,   entry [k + Hz + 1] (k = 0-based face index)
+  const double *rdzc, *rdzf;  // their reciprocals (same entries), so kernels never divide by a per-level constant
+  double rdz;               // 1 / dz
   int xb, yb, zb;           // Bounded directions
   int zflat;                // z Flat (Flat x / y are stored with broadcast halos and need no flag)
   int nb;                   // boundary buffer of the advection scheme
@@ -28,6 +30,8 @@ struct GridDev {
 
 OCN_DEVFN double g_dzc(const GridDev& g, int k) { return g.dzc ? g.dzc[k + g.Hz] : g.dz; }
 OCN_DEVFN double g_dzf(const GridDev& g, int k) { return g.dzf ? g.dzf[k + g.Hz + 1] : g.dz; }
+OCN_DEVFN double g_rdzc(const GridDev& g, int k) { return g.rdzc ? g.rdzc[k + g.Hz] : g.rdz; }
+OCN_DEVFN double g_rdzf(const GridDev& g, int k) { return g.rdzf ? g.rdzf[k + g.Hz + 1] : g.rdz; }
 
 // ---- second / fourth order symmetric interpolation -------------------------------------------------
 // value midway between p[0] and p[s]
