@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--stepper", default="AB2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tracers", type=int, default=0, help="passive tracers (config 2b: 1)")
+    ap.add_argument("--nu", type=float, default=0.0, help="config 2 with ScalarDiffusivity(nu = kappa = NU) (DNS-style; 0: inviscid headline)")
     ap.add_argument("--topology", default="PPP", help="config 2 with other x/y/z topologies, e.g. PBB (debug / widening rows)")
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (headline, default), 1 (2-D turbulence) or 3 (ocean LES)")
     args = ap.parse_args()
@@ -143,7 +144,8 @@ def main():
         topo = tuple({"P": "Periodic", "B": "Bounded"}[c] for c in args.topology.upper())
         grid = ocn.RectilinearGrid(ctx, size=Nglobal, extent=(1, 1, float(world)), topology=topo)
         tnames = tuple(f"c{i}" for i in range(args.tracers))
-        model = ocn.NonhydrostaticModel(grid, advection=ocn.WENO5(), timestepper=args.stepper, tracers=tnames)
+        closure = ocn.ScalarDiffusivity(nu=args.nu, kappa=args.nu) if args.nu else None
+        model = ocn.NonhydrostaticModel(grid, advection=ocn.WENO5(), timestepper=args.stepper, tracers=tnames, closure=closure)
         rng = np.random.default_rng(1 + rank)
         init = dict(u=rng.random(model.u.size) - 0.5, v=rng.random(model.v.size) - 0.5, w=rng.random(model.w.size) - 0.5)
         init.update({t: rng.random(model.tracers[t].size) for t in tnames})
@@ -251,7 +253,8 @@ def main():
             "config": {"workload": (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} "
                                     + ("triply-periodic" if args.topology.upper() == "PPP" else f"topology {args.topology.upper()}")
                                     + " RectilinearGrid, "
-                                    f"NonhydrostaticModel WENO5(zweno) + FFT Poisson, {args.stepper}, halo 3, {args.tracers} tracers")
+                                    f"NonhydrostaticModel WENO5(zweno) + FFT Poisson, {args.stepper}, halo 3, {args.tracers} tracers"
+                                    + (f", ScalarDiffusivity nu={args.nu}" if args.nu else ""))
                        if args.config == 2 else
                        (f"{Nglobal[0]}x{Nglobal[1]} (Periodic,Periodic,Flat) two_dimensional_turbulence, WENO5, RK3, "
                         "ScalarDiffusivity (BASELINE config 1)") if args.config == 1 else

@@ -39,6 +39,7 @@ struct FusedArgs {
   int ntiles;                     // y-tiles (v3: segment decomposition); x-tiled variant: ntx * nty
   int ntx, BXo;                   // x-tiled variant: tiles along x, output columns per tile
   int dbg_nobar;                  // timing experiments only (OCNHIP_DBG_NOBAR): results are wrong
+  double nu;                      // ScalarDiffusivity viscosity (0: none); see the viscous-flux note in k_tend_step3
 };
 
 OCN_DEVFN void sto(double* base, unsigned boff, double v) { *(double*)((char*)base + boff) = v; }
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(FUSED_MAX_THREADS) k_tend_step(GridDev g, Fuse
 // base address (workgroup shape is a template parameter, so row / field strides are immediates).
 //   LDS: slab 3*(BY+5)*(BX+6) + flux exchange 6*T + carry 6*T doubles  (BX = 256, BY = 4: 151.3 KB of 160)
 #define SLAB_MAXG 3
-template <int ADV, int BX, int BY, bool EARLY, bool FENCE3>
+template <int ADV, int BX, int BY, bool EARLY, bool FENCE3, bool VISC>
 __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
   constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
   constexpr int NG = (NR + BY - 1) / BY;   // row groups of the cooperative slab load
@@ -275,6 +276,11 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
       zw[q] = ldo(a.w, c + (unsigned)(q - 3) * szb);
     }
   }
+  double dprev = 0.0;
+  if (VISC) {   // div U of the cell below the first level of this march
+    const unsigned cb = cxy + (unsigned)k0 * szb - szb;
+    dprev = (ldo(a.u, cb + sxb) - zu[2]) * rdx + (ldo(a.v, cb + syb) - zv[2]) * rdy + (zw[3] - zw[2]) * rdz;
+  }
   prefetch(k0);
   for (int k = k0; k <= k1; ++k) {
     const unsigned c = cxy + (unsigned)k * szb;
@@ -287,6 +293,18 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
       gm0 = ldo(a.gmu, c - szb);
       gm1 = ldo(a.gmv, c - szb);
       gm2 = ldo(a.gmw, c - szb);
+    }
+    // ScalarDiffusivity (closure_kernel_operators.jl:22-41 with constant nu): div(2 nu Sigma)_i = nu (lap u_i + d_i div U),
+    // exactly (centred differences commute on a uniform grid).  Both parts are face fluxes at the very places of
+    // the advective ones: -nu d(u_i)/dn through every face, plus -nu div U through the centre-located face of the
+    // normal component -- so they ride along in fx / Fw with no extra storage.  div U at the west / south cells
+    // needs w one level up in the neighbouring column (two extra loads); at the cell below it is the value this
+    // thread computed one level earlier (dprev).
+    constexpr bool visc = VISC;   // compile-time: the inviscid kernel must not pay registers for these terms
+    double wxm = 0, wym = 0;
+    if (visc && !last) {
+      wxm = ldo(a.w, c + szb - sxb);
+      wym = ldo(a.w, c + szb - syb);
     }
     auto symz = [&](const double* z) { return sym4_v(z[1], z[2], z[3], z[4]); };
     auto reconz = [&](const double* z, double ut) {
@@ -306,24 +324,36 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
     if (!last) {
       if (full) {
         double utu = XSYM(0);                          // centre i-1
-        fx[0 * T + tid] = utu * XREC(0, utu);
+        double f0 = utu * XREC(0, utu);
+        if (visc) {
+          const double dux = (SLB(0, 3, 3) - SLB(0, 3, 2)) * rdx;
+          const double divw = dux + (SLB(1, 4, 2) - SLB(1, 3, 2)) * rdy + (wxm - SLB(2, 3, 2)) * rdz;   // div U at (i-1, j, k)
+          f0 -= a.nu * (dux + divw);
+        }
+        fx[0 * T + tid] = f0;
         if (FENCE3) OCN_SCHED_FENCE();
         double utv = YSYM(0);                          // u interpolated in y to the v row
-        fx[1 * T + tid] = utv * XREC(1, utv);
+        fx[1 * T + tid] = utv * XREC(1, utv) - (visc ? a.nu * (SLB(1, 3, 3) - SLB(1, 3, 2)) * rdx : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
         double utw = symz(zu);                         // u interpolated in z to the w level
-        fx[2 * T + tid] = utw * XREC(2, utw);
+        fx[2 * T + tid] = utw * XREC(2, utw) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 3, 2)) * rdx : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
       }
       if (do_y) {
         double vtu = XSYM(1);                          // v interpolated in x to the u column
-        fx[3 * T + tid] = vtu * YREC(0, vtu);
+        fx[3 * T + tid] = vtu * YREC(0, vtu) - (visc ? a.nu * (SLB(0, 3, 3) - SLB(0, 2, 3)) * rdy : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
         double vtv = YSYM(1);                          // centre j-1
-        fx[4 * T + tid] = vtv * YREC(1, vtv);
+        double f4 = vtv * YREC(1, vtv);
+        if (visc) {
+          const double dvy = (SLB(1, 3, 3) - SLB(1, 2, 3)) * rdy;
+          const double divs = (SLB(0, 2, 4) - SLB(0, 2, 3)) * rdx + dvy + (wym - SLB(2, 2, 3)) * rdz;   // div U at (i, j-1, k)
+          f4 -= a.nu * (dvy + divs);
+        }
+        fx[4 * T + tid] = f4;
         if (FENCE3) OCN_SCHED_FENCE();
         double vtw = symz(zv);
-        fx[5 * T + tid] = vtw * YREC(2, vtw);
+        fx[5 * T + tid] = vtw * YREC(2, vtw) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 2, 3)) * rdy : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
       }
     }
@@ -337,6 +367,13 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
       if (FENCE3) OCN_SCHED_FENCE();
       double wtw = symz(zw);
       Fww = wtw * reconz(zw, wtw);
+      if (visc) {
+        Fwu -= a.nu * (zu[3] - zu[2]) * rdz;
+        Fwv -= a.nu * (zv[3] - zv[2]) * rdz;
+        const double dwz = (zw[3] - zw[2]) * rdz;
+        Fww -= a.nu * (dwz + dprev);                    // dprev = div U at (i, j, k-1)
+        if (!last) dprev = (SLB(0, 3, 4) - SLB(0, 3, 3)) * rdx + (SLB(1, 4, 3) - SLB(1, 3, 3)) * rdy + (zw[4] - zw[3]) * rdz;
+      }
     }
 #undef XSYM
 #undef YSYM
@@ -402,7 +439,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
 // produces the WEST-face fluxes that the last output column needs as its EAST fluxes (the same device as the ghost
 // row in y); x halos of the slab are read from the arrays' own halo columns (the projection keeps their periodic
 // images current) instead of being wrapped inside LDS.  Tiles are (x-tile, y-tile) pairs, x fastest.
-template <int ADV, int BX, int BY>
+template <int ADV, int BX, int BY, bool VISC>
 __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) {
   constexpr bool EARLY = true, FENCE3 = false;
   constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
@@ -485,6 +522,11 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
       zw[q] = ldo(a.w, c + (unsigned)(q - 3) * szb);
     }
   }
+  double dprev = 0.0;
+  if (VISC) {   // div U of the cell below the first level of this march
+    const unsigned cb = cxy + (unsigned)k0 * szb - szb;
+    dprev = (ldo(a.u, cb + sxb) - zu[2]) * rdx + (ldo(a.v, cb + syb) - zv[2]) * rdy + (zw[3] - zw[2]) * rdz;
+  }
   prefetch(k0);
   for (int k = k0; k <= k1; ++k) {
     const unsigned c = cxy + (unsigned)k * szb;
@@ -497,6 +539,18 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
       gm0 = ldo(a.gmu, c - szb);
       gm1 = ldo(a.gmv, c - szb);
       gm2 = ldo(a.gmw, c - szb);
+    }
+    // ScalarDiffusivity (closure_kernel_operators.jl:22-41 with constant nu): div(2 nu Sigma)_i = nu (lap u_i + d_i div U),
+    // exactly (centred differences commute on a uniform grid).  Both parts are face fluxes at the very places of
+    // the advective ones: -nu d(u_i)/dn through every face, plus -nu div U through the centre-located face of the
+    // normal component -- so they ride along in fx / Fw with no extra storage.  div U at the west / south cells
+    // needs w one level up in the neighbouring column (two extra loads); at the cell below it is the value this
+    // thread computed one level earlier (dprev).
+    constexpr bool visc = VISC;   // compile-time: the inviscid kernel must not pay registers for these terms
+    double wxm = 0, wym = 0;
+    if (visc && !last) {
+      wxm = ldo(a.w, c + szb - sxb);
+      wym = ldo(a.w, c + szb - syb);
     }
     auto symz = [&](const double* z) { return sym4_v(z[1], z[2], z[3], z[4]); };
     auto reconz = [&](const double* z, double ut) {
@@ -516,24 +570,36 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
     if (!last) {
       if (do_x) {
         double utu = XSYM(0);                          // centre i-1
-        fx[0 * T + tid] = utu * XREC(0, utu);
+        double f0 = utu * XREC(0, utu);
+        if (visc) {
+          const double dux = (SLB(0, 3, 3) - SLB(0, 3, 2)) * rdx;
+          const double divw = dux + (SLB(1, 4, 2) - SLB(1, 3, 2)) * rdy + (wxm - SLB(2, 3, 2)) * rdz;   // div U at (i-1, j, k)
+          f0 -= a.nu * (dux + divw);
+        }
+        fx[0 * T + tid] = f0;
         if (FENCE3) OCN_SCHED_FENCE();
         double utv = YSYM(0);                          // u interpolated in y to the v row
-        fx[1 * T + tid] = utv * XREC(1, utv);
+        fx[1 * T + tid] = utv * XREC(1, utv) - (visc ? a.nu * (SLB(1, 3, 3) - SLB(1, 3, 2)) * rdx : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
         double utw = symz(zu);                         // u interpolated in z to the w level
-        fx[2 * T + tid] = utw * XREC(2, utw);
+        fx[2 * T + tid] = utw * XREC(2, utw) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 3, 2)) * rdx : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
       }
       if (do_y) {
         double vtu = XSYM(1);                          // v interpolated in x to the u column
-        fx[3 * T + tid] = vtu * YREC(0, vtu);
+        fx[3 * T + tid] = vtu * YREC(0, vtu) - (visc ? a.nu * (SLB(0, 3, 3) - SLB(0, 2, 3)) * rdy : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
         double vtv = YSYM(1);                          // centre j-1
-        fx[4 * T + tid] = vtv * YREC(1, vtv);
+        double f4 = vtv * YREC(1, vtv);
+        if (visc) {
+          const double dvy = (SLB(1, 3, 3) - SLB(1, 2, 3)) * rdy;
+          const double divs = (SLB(0, 2, 4) - SLB(0, 2, 3)) * rdx + dvy + (wym - SLB(2, 2, 3)) * rdz;   // div U at (i, j-1, k)
+          f4 -= a.nu * (dvy + divs);
+        }
+        fx[4 * T + tid] = f4;
         if (FENCE3) OCN_SCHED_FENCE();
         double vtw = symz(zv);
-        fx[5 * T + tid] = vtw * YREC(2, vtw);
+        fx[5 * T + tid] = vtw * YREC(2, vtw) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 2, 3)) * rdy : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
       }
     }
@@ -547,6 +613,13 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
       if (FENCE3) OCN_SCHED_FENCE();
       double wtw = symz(zw);
       Fww = wtw * reconz(zw, wtw);
+      if (visc) {
+        Fwu -= a.nu * (zu[3] - zu[2]) * rdz;
+        Fwv -= a.nu * (zv[3] - zv[2]) * rdz;
+        const double dwz = (zw[3] - zw[2]) * rdz;
+        Fww -= a.nu * (dwz + dprev);                    // dprev = div U at (i, j, k-1)
+        if (!last) dprev = (SLB(0, 3, 4) - SLB(0, 3, 3)) * rdx + (SLB(1, 4, 3) - SLB(1, 3, 3)) * rdy + (zw[4] - zw[3]) * rdz;
+      }
     }
 #undef XSYM
 #undef YSYM
@@ -690,6 +763,7 @@ struct TracerArgs {
   double *gn, *cnew;
   double dt, cn, cm;
   int use_m, KZ, zwrap;
+  double kappa;                        // ScalarDiffusivity kappa of this tracer (0: none): -kappa dc/dn rides in every face flux
 };
 
 template <int ADV>
@@ -709,15 +783,18 @@ __global__ void __launch_bounds__(256) k_tracer_step(GridDev g, TracerArgs a) {
     const double wt = a.w[p];
     const bool pos = wt > 0.0;
     return wt * recon5<ADV>(pos ? zc[0] : zc[5], pos ? zc[1] : zc[4], pos ? zc[2] : zc[3], pos ? zc[3] : zc[2],
-                            pos ? zc[4] : zc[1], pos);
+                            pos ? zc[4] : zc[1], pos) - a.kappa * (zc[3] - zc[2]) * rdz;
   };
   double fb = fz(c);
   for (int k = k0; k < k1; ++k, c += sz) {
     // west / east and south / north fluxes (advecting velocity un-interpolated: upwind_biased_advective_fluxes.jl:103-119)
     const double uw = a.u[c], ue = a.u[c + 1], vs_ = a.v[c], vn = a.v[c + sy];
-    const double fxw = uw * recon_mem<ADV>(a.c + c, 1, uw), fxe = ue * recon_mem<ADV>(a.c + c + 1, 1, ue);
-    const double fys = vs_ * recon_mem<ADV>(a.c + c, sy, vs_), fyn = vn * recon_mem<ADV>(a.c + c + sy, sy, vn);
     const double cc = zc[3];
+    // div(kappa grad c) with constant kappa (closure_kernel_operators.jl:43-48) as diffusive face fluxes
+    const double fxw = uw * recon_mem<ADV>(a.c + c, 1, uw) - a.kappa * (cc - a.c[c - 1]) * rdx;
+    const double fxe = ue * recon_mem<ADV>(a.c + c + 1, 1, ue) - a.kappa * (a.c[c + 1] - cc) * rdx;
+    const double fys = vs_ * recon_mem<ADV>(a.c + c, sy, vs_) - a.kappa * (cc - a.c[c - sy]) * rdy;
+    const double fyn = vn * recon_mem<ADV>(a.c + c + sy, sy, vn) - a.kappa * (a.c[c + sy] - cc) * rdy;
     // advance the window to level k+1 and take its bottom flux = this level's top flux
 #pragma unroll
     for (int q = 0; q < 5; ++q) zc[q] = zc[q + 1];
@@ -738,7 +815,9 @@ bool fused_available(const ocn_model* m) {
   if (!g->z_regular) return false;
   int adv = m->d.advection;
   if (adv != ADV_WENO_Z && adv != ADV_WENO_JS && adv != ADV_U5) return false;
-  if (m->d.closure != OCN_CLOSURE_NONE || m->d.coriolis_fplane || m->d.buoyancy != OCN_BUOYANCY_NONE) return false;
+  // ScalarDiffusivity (constant nu, kappa) rides in the face fluxes of the fused kernels; other closures, Coriolis and
+  // buoyancy take the general path
+  if (m->d.closure == OCN_CLOSURE_AMD || m->d.coriolis_fplane || m->d.buoyancy != OCN_BUOYANCY_NONE) return false;
   for (int d = 0; d < 3; ++d)
     if (g->H[d] < 3 || g->N[d] < 2 * g->H[d]) return false;
   if (m->u.n * sizeof(double) >= (1ull << 31)) return false;   // 32-bit byte offsets
@@ -774,13 +853,14 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
   a.org = (unsigned)((m->u.Hx + m->u.Hy * m->u.sy + m->u.Hz * m->u.sz) * sizeof(double));
   a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
   a.dbg_nobar = 0;
+  a.nu = m->d.closure == OCN_CLOSURE_SCALAR ? m->d.nu : 0.0;
   dim3 block, grid;
   fused_geometry(m, block, grid, a.KZ, a.BYo);
   hipStream_t s = m->ctx->stream;
   static const bool fence = getenv("OCNHIP_FENCE") && atoi(getenv("OCNHIP_FENCE")) != 0;
   static const int variant = getenv("OCNHIP_FUSED_VARIANT") ? atoi(getenv("OCNHIP_FUSED_VARIANT")) : 3;
   const int xt_env0 = getenv("OCNHIP_FUSED_XT") ? atoi(getenv("OCNHIP_FUSED_XT")) : 0;   // read per launch: tests toggle it
-  if (variant == 3 && m->gd.Nx <= 256 && xt_env0 != 1) {
+  if ((variant == 3 || a.nu != 0.0) && m->gd.Nx <= 256 && xt_env0 != 1) {
     // v3 is compiled for three workgroup shapes (complete x rows of up to 64 / 128 / 256 cells)
     const GridDev& gd = m->gd;
     int bx = gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
@@ -808,12 +888,16 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
     nseg = ((nseg + 7) / 8) * 8;
     dim3 blk(bx, by, 1), grd(nseg, 1, 1);
 #define V3_CASE(ADVV)                                                                               \
-    if (bx == 256 && by == 3) ocn_launch_sync(k_tend_step3<ADVV, 256, 3, true, false>, grd, blk, s, m->gd, a);   \
-    else if (bx == 256 && early && fence) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, true>, grd, blk, s, m->gd, a); \
-    else if (bx == 256 && early) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false>, grd, blk, s, m->gd, a); \
-    else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, false, true>, grd, blk, s, m->gd, a);        \
-    else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false>, grd, blk, s, m->gd, a);        \
-    else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false>, grd, blk, s, m->gd, a);
+    if (a.nu != 0.0) {                                                                                \
+      if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, true>, grd, blk, s, m->gd, a);     \
+      else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, true>, grd, blk, s, m->gd, a); \
+      else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, true>, grd, blk, s, m->gd, a);                \
+    } else if (bx == 256 && by == 3) ocn_launch_sync(k_tend_step3<ADVV, 256, 3, true, false, false>, grd, blk, s, m->gd, a);   \
+    else if (bx == 256 && early && fence) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, true, false>, grd, blk, s, m->gd, a); \
+    else if (bx == 256 && early) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, false>, grd, blk, s, m->gd, a); \
+    else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, false, true, false>, grd, blk, s, m->gd, a);        \
+    else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, false>, grd, blk, s, m->gd, a);        \
+    else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, false>, grd, blk, s, m->gd, a);
     switch (m->d.advection) {
       case ADV_WENO_Z: V3_CASE(ADV_WENO_Z) break;
       case ADV_WENO_JS: V3_CASE(ADV_WENO_JS) break;
@@ -823,7 +907,7 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
     return;
   }
   const int xt_env = xt_env0;   // 1: force the x-tiled kernel (tests)
-  if (variant == 3 || m->gd.Nx > FUSED_MAX_THREADS / 2) {
+  if (variant == 3 || m->gd.Nx > FUSED_MAX_THREADS / 2 || a.nu != 0.0) {   // (v2 has no viscous terms)
     // rows wider than a workgroup: x-tiled kernel, 192 x 5 threads (up to 185 output columns x 4 output rows per tile)
     const GridDev& gd = m->gd;
     const bool small = xt_env == 1 && gd.Nx <= 57 * 4;          // test shape: 64 x 4 threads, up to 57 output columns
@@ -850,8 +934,10 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
     nseg = ((nseg + 7) / 8) * 8;
     dim3 blk(bx, by, 1), grd(nseg, 1, 1);
 #define V3X_CASE(ADVV)                                                                     \
-    if (small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4>, grd, blk, s, m->gd, a);         \
-    else ocn_launch_sync(k_tend_step3x<ADVV, 192, 5>, grd, blk, s, m->gd, a);
+    if (small && a.nu != 0.0) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, true>, grd, blk, s, m->gd, a);   \
+    else if (small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, false>, grd, blk, s, m->gd, a);            \
+    else if (a.nu != 0.0) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, true>, grd, blk, s, m->gd, a);     \
+    else ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, false>, grd, blk, s, m->gd, a);
     switch (m->d.advection) {
       case ADV_WENO_Z: V3X_CASE(ADV_WENO_Z) break;
       case ADV_WENO_JS: V3X_CASE(ADV_WENO_JS) break;
@@ -932,6 +1018,7 @@ void launch_tracer_steps(ocn_model* m, double dt, double cn, double cm, int use_
     a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
     a.KZ = 32;
     a.zwrap = m->g->dist ? 0 : 1;
+    a.kappa = m->d.closure == OCN_CLOSURE_SCALAR ? m->d.kappa[t] : 0.0;
     dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, (g.Nz + a.KZ - 1) / a.KZ);
     switch (m->d.advection) {
       case ADV_WENO_Z: ocn_launch(k_tracer_step<ADV_WENO_Z>, gr, b, m->ctx->stream, g, a); break;

@@ -29,6 +29,11 @@ CASES = {
     "ppp_c4": dict(size=(8, 10, 12), topo=(P, P, P), extent=(1, 1, 1), adv="C4", stepper="RK3", steps=2, dt=2e-3),
     "ppp_c2_default": dict(size=(8, 8, 8), topo=(P, P, P), extent=(1, 1, 1), adv="C2", stepper="AB2", steps=2, dt=2e-3,
                            halo=(1, 1, 1)),
+    # DNS-style: triply periodic with ScalarDiffusivity stays on the fused path (viscous / diffusive face fluxes)
+    "ppp_weno_visc_ab2": dict(size=(12, 10, 9), topo=(P, P, P), extent=(1, 1.2, 0.9), adv="WENO5", stepper="AB2", steps=3,
+                              dt=2e-3, tracers=("c",), closure=(2e-2, 3e-2)),
+    "ppp_weno_visc_rk3_noproj": dict(size=(10, 12, 8), topo=(P, P, P), extent=(1, 1, 1), adv="WENO5", stepper="RK3", steps=2,
+                                     dt=2e-3, tracers=("a", "b2"), closure=(5e-2, 1e-2), project_init=False),
     # adaptive time stepping (TimeStepWizard): every change of dt is an Euler step with G^- zeroed
     # (quasi_adams_bashforth_2.jl:74-84), on the fused path (pointer-rotated G buffers) and on the general one
     "ppp_weno_ab2_varying_dt": dict(size=(12, 10, 8), topo=(P, P, P), extent=(1, 1, 1), adv="WENO5", stepper="AB2", steps=5,
@@ -191,7 +196,7 @@ def build(mod, cfg, rng_seed=1234):
         init[n] = a
     for t in cfg.get("tracers", ()):
         init[t] = rng.random(m.tracers[t].interior().shape)
-    mod.set_model(m, **init)
+    mod.set_model(m, enforce_incompressibility=cfg.get("project_init", True), **init)
     return m
 
 
