@@ -517,6 +517,22 @@ static int fused_substep(ocn_model* m, double dt_full, double cn, double cm, int
   return OCN_OK;
 }
 
+// tendencies + time-stepper update of the general path.  With a Bounded z and an upwind scheme the momentum advection and
+// the update of u, v, w come from the tiled kernel (fused.hip, ZB): the general kernels deliver the other terms.
+static void tendencies_and_step(ocn_model* m, double dt, double cn, double cm, int use_m) {
+  if (!m->bz_fast) {
+    launch_tendencies(m);
+    launch_step(m, dt, cn, cm, use_m);
+    return;
+  }
+  launch_tendencies(m, true);                  // closure, Coriolis, pressure gradient, boundary fluxes; tracers complete
+  launch_fused_bz(m, dt, cn, cm, use_m);       // + advection -> G^n; stepped velocities -> us, vs, ws
+  std::swap(m->u.d, m->us.d);                  // halos are filled by the pressure-correction step that follows
+  std::swap(m->v.d, m->vs.d);
+  std::swap(m->w.d, m->ws.d);
+  launch_step(m, dt, cn, cm, use_m, true);
+}
+
 static int time_step_ab2(ocn_model* m, double dt, int force_euler) {
   // quasi_adams_bashforth_2.jl:70-104
   bool euler = force_euler || (dt != m->previous_dt);
@@ -535,8 +551,7 @@ static int time_step_ab2(ocn_model* m, double dt, int force_euler) {
     return OCN_OK;           // update_state!: halos were written by the projection; no pHY', no closure
   }
   if (m->gn_alias_gm) m->gn_alias_gm = false;   // G^n gets its own (recycled) buffer again
-  launch_tendencies(m);
-  launch_step(m, dt, 1.5 + chi, -(0.5 + chi), 1);
+  tendencies_and_step(m, dt, 1.5 + chi, -(0.5 + chi), 1);
   int rc = pressure_correction(m, dt);
   if (rc) return rc;
   launch_pcorrect(m, dt);
@@ -568,8 +583,7 @@ static int time_step_rk3(ocn_model* m, double dt) {
   }
   m->gn_alias_gm = false;
   for (int s = 0; s < 3; ++s) {
-    launch_tendencies(m);
-    launch_step(m, dt, gam[s], zet[s], s > 0);
+    tendencies_and_step(m, dt, gam[s], zet[s], s > 0);
     int rc = pressure_correction(m, sdt[s]);
     if (rc) return rc;
     launch_pcorrect(m, sdt[s]);
@@ -691,10 +705,12 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
   }
   m->fast_path = fused_available(m) ? 1 : 0;
   if (getenv("OCNHIP_DEBUG")) fprintf(stderr, "[ocnhip] model: fast_path=%d\n", m->fast_path);
-  if (m->fast_path) {
+  m->bz_fast = (!m->fast_path && fused_bz_available(m)) ? 1 : 0;
+  if (getenv("OCNHIP_DEBUG")) fprintf(stderr, "[ocnhip] model: bz_fast=%d\n", m->bz_fast);
+  if (m->fast_path || m->bz_fast) {
     int r2 = field_alloc(m, m->us, OCN_FACE, OCN_CENTER, OCN_CENTER) | field_alloc(m, m->vs, OCN_CENTER, OCN_FACE, OCN_CENTER) |
              field_alloc(m, m->ws, OCN_CENTER, OCN_CENTER, OCN_FACE);
-    for (int t = 0; t < m->nt; ++t) r2 |= field_alloc(m, m->trs[t], OCN_CENTER, OCN_CENTER, OCN_CENTER);
+    for (int t = 0; m->fast_path && t < m->nt; ++t) r2 |= field_alloc(m, m->trs[t], OCN_CENTER, OCN_CENTER, OCN_CENTER);
     if (r2) {
       ocn_model_destroy(m);
       return OCN_ENOMEM;

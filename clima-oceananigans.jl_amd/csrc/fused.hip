@@ -190,8 +190,12 @@ __global__ void __launch_bounds__(FUSED_MAX_THREADS) k_tend_step(GridDev g, Fuse
 // base address (workgroup shape is a template parameter, so row / field strides are immediates).
 //   LDS: slab 3*(BY+5)*(BX+6) + flux exchange 6*T + carry 6*T doubles  (BX = 256, BY = 4: 151.3 KB of 160)
 #define SLAB_MAXG 3
-template <int ADV, int BX, int BY, bool EARLY, bool FENCE3, bool VISC>
+template <int ADV, int BX, int BY, bool EARLY, bool FENCE3, bool VISC, bool ZB>
 __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
+  // ZB: Bounded z (regular or stretched).  The march is the same; what changes is uniform per level: the spacings,
+  // the 2nd-order fallback of every z stencil inside the boundary buffer (topologically_conditional_interpolation.jl:
+  // 46-79) and the tendency that is completed here -- G^n arrives holding everything but advection (closure,
+  // Coriolis, pressure gradient, boundary fluxes from the general kernels) and leaves as the full tendency.
   constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
   constexpr int NG = (NR + BY - 1) / BY;   // row groups of the cooperative slab load
   OCN_SHARED double slab[3 * NR * SX];     // [field][row][column]; element (f, r, s) <-> (j0 - 3 + r, s - 3)
@@ -202,6 +206,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
   const int i = tx;
   const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
   const double rdx = g.rdx, rdy = g.rdy, rdz = 1.0 / g.dz;
+  const int nbz = (ADV == ADV_C4) ? 1 : 2;   // boundary buffer of the scheme (only WENO5 / U5 reach this kernel)
   const bool col_ok = i < g.Nx;
   const bool ghost = (ty == BY - 1);
   const int txe = (tx + 1 == g.Nx) ? 0 : tx + 1;
@@ -289,6 +294,12 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
     if (!(a.dbg_nobar & 2)) __syncthreads();
     if (EARLY && !last) prefetch(k + 1);   // next level's slab in flight during the whole flux stage
     double gm0 = 0, gm1 = 0, gm2 = 0;      // G^- of the level finalized below, also fetched early
+    double rs0 = 0, rs1 = 0, rs2 = 0;      // ZB: the non-advective part of G^n waiting in the G^n arrays
+    if (ZB && full && k > k0) {
+      rs0 = ldo(a.gnu, c - szb);
+      rs1 = ldo(a.gnv, c - szb);
+      rs2 = ldo(a.gnw, c - szb);
+    }
     if (EARLY && a.use_m && full && k > k0) {
       gm0 = ldo(a.gmu, c - szb);
       gm1 = ldo(a.gmv, c - szb);
@@ -306,12 +317,23 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
       wxm = ldo(a.w, c + szb - sxb);
       wym = ldo(a.w, c + szb - syb);
     }
-    auto symz = [&](const double* z) { return sym4_v(z[1], z[2], z[3], z[4]); };
-    auto reconz = [&](const double* z, double ut) {
+    // idx: the reference's 1-based index of the evaluation point along z (face k+1 for the bottom face of level k,
+    // centre k for the w flux below face k); all conditions are uniform over the workgroup
+    auto symz_at = [&](const double* z, int idx) {
+      if (ZB && !(idx > nbz && idx < g.Nz + 1 - nbz)) return 0.5 * (z[2] + z[3]);
+      return sym4_v(z[1], z[2], z[3], z[4]);
+    };
+    auto symz = [&](const double* z) { return symz_at(z, k + 1); };
+    auto reconz_at = [&](const double* z, double ut, int idx) {
       bool pos = ut > 0.0;
+      if (ZB) {
+        const bool ok = pos ? (idx > nbz && idx < g.Nz + 1 - (nbz - 1)) : (idx > nbz - 1 && idx < g.Nz + 1 - nbz);
+        if (!ok) return 0.5 * (z[2] + z[3]);
+      }
       return recon5<ADV>(pos ? z[0] : z[5], pos ? z[1] : z[4], pos ? z[2] : z[3], pos ? z[3] : z[2],
                          pos ? z[4] : z[1], pos);
     };
+    auto reconz = [&](const double* z, double ut) { return reconz_at(z, ut, k + 1); };
     auto sym_v = [&](double m2, double m1, double c0, double c1) { return sym4_v(m2, m1, c0, c1); };  // midway m1|c0
     auto rec_v = [&](double m3, double m2, double m1, double c0, double c1, double c2, double ut) {
       bool pos = ut > 0.0;                                            // face between m1 and c0
@@ -365,8 +387,8 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
       double wtv = YSYM(2);
       Fwv = wtv * reconz(zv, wtv);
       if (FENCE3) OCN_SCHED_FENCE();
-      double wtw = symz(zw);
-      Fww = wtw * reconz(zw, wtw);
+      double wtw = symz_at(zw, k);                    // centre below face k
+      Fww = wtw * reconz_at(zw, wtw, k);
       if (visc) {
         Fwu -= a.nu * (zu[3] - zu[2]) * rdz;
         Fwv -= a.nu * (zv[3] - zv[2]) * rdz;
@@ -384,9 +406,10 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
     if (full) {
       if (k > k0) {
         const unsigned cm1 = c - szb;
-        double Gu = -(own[0 * T + tid] + (Fwu - own[3 * T + tid]) * rdz);
-        double Gv = -(own[1 * T + tid] + (Fwv - own[4 * T + tid]) * rdz);
-        double Gw = -(own[2 * T + tid] + (Fww - own[5 * T + tid]) * rdz);
+        const double rzc = ZB ? g_rdzc(g, k - 1) : rdz, rzf = ZB ? g_rdzf(g, k - 1) : rdz;
+        double Gu = rs0 - (own[0 * T + tid] + (Fwu - own[3 * T + tid]) * rzc);
+        double Gv = rs1 - (own[1 * T + tid] + (Fwv - own[4 * T + tid]) * rzc);
+        double Gw = rs2 - (own[2 * T + tid] + (Fww - own[5 * T + tid]) * rzf);
         sto(a.gnu, cm1, Gu);
         sto(a.gnv, cm1, Gv);
         sto(a.gnw, cm1, Gw);
@@ -889,15 +912,15 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
     dim3 blk(bx, by, 1), grd(nseg, 1, 1);
 #define V3_CASE(ADVV)                                                                               \
     if (a.nu != 0.0) {                                                                                \
-      if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, true>, grd, blk, s, m->gd, a);     \
-      else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, true>, grd, blk, s, m->gd, a); \
-      else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, true>, grd, blk, s, m->gd, a);                \
-    } else if (bx == 256 && by == 3) ocn_launch_sync(k_tend_step3<ADVV, 256, 3, true, false, false>, grd, blk, s, m->gd, a);   \
-    else if (bx == 256 && early && fence) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, true, false>, grd, blk, s, m->gd, a); \
-    else if (bx == 256 && early) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, false>, grd, blk, s, m->gd, a); \
-    else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, false, true, false>, grd, blk, s, m->gd, a);        \
-    else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, false>, grd, blk, s, m->gd, a);        \
-    else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, false>, grd, blk, s, m->gd, a);
+      if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, true, false>, grd, blk, s, m->gd, a);     \
+      else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, true, false>, grd, blk, s, m->gd, a); \
+      else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, true, false>, grd, blk, s, m->gd, a);                \
+    } else if (bx == 256 && by == 3) ocn_launch_sync(k_tend_step3<ADVV, 256, 3, true, false, false, false>, grd, blk, s, m->gd, a);   \
+    else if (bx == 256 && early && fence) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, true, false, false>, grd, blk, s, m->gd, a); \
+    else if (bx == 256 && early) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, false, false>, grd, blk, s, m->gd, a); \
+    else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, false, true, false, false>, grd, blk, s, m->gd, a);        \
+    else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, false, false>, grd, blk, s, m->gd, a);        \
+    else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, false, false>, grd, blk, s, m->gd, a);
     switch (m->d.advection) {
       case ADV_WENO_Z: V3_CASE(ADV_WENO_Z) break;
       case ADV_WENO_JS: V3_CASE(ADV_WENO_JS) break;
@@ -954,6 +977,66 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
     case ADV_WENO_JS: ocn_launch_sync(k_tend_step<ADV_WENO_JS, false>, grid, block, s, m->gd, a); break;
     default: ocn_launch_sync(k_tend_step<ADV_U5, false>, grid, block, s, m->gd, a); break;
   }
+}
+
+// ---- Bounded z: advection + time-stepper update of u, v, w on top of the general kernels' other terms ----------------
+bool fused_bz_available(const ocn_model* m) {
+  const ocn_grid* g = m->g;
+  if (g->topo[0] != OCN_PERIODIC || g->topo[1] != OCN_PERIODIC || g->topo[2] != OCN_BOUNDED) return false;
+  int adv = m->d.advection;
+  if (adv != ADV_WENO_Z && adv != ADV_WENO_JS && adv != ADV_U5) return false;
+  for (int d = 0; d < 3; ++d)
+    if (g->H[d] < 3 || g->N[d] < 2 * g->H[d]) return false;
+  if (g->N[0] > 256) return false;                             // complete x rows per workgroup (the x-tiled variant is periodic-z only)
+  if (m->u.n * sizeof(double) >= (1ull << 31) || m->w.n * sizeof(double) >= (1ull << 31)) return false;
+  if (getenv("OCNHIP_NO_FUSED") || getenv("OCNHIP_NO_FUSED_BZ")) return false;
+  return true;
+}
+
+// G^n(u, v, w) must hold the non-advective terms (k_tend_uvw<ADV_NONE> + boundary fluxes); on return it holds the full
+// tendencies and us / vs / ws the stepped velocities (interior cells; the caller swaps buffers and fills halos).
+void launch_fused_bz(ocn_model* m, double dt, double cn, double cm, int use_m) {
+  ProfScope ps(m->ctx, "fused_tendency_step");
+  FusedArgs a;
+  a.u = m->u.d; a.v = m->v.d; a.w = m->w.d;
+  a.gmu = m->Gm[0].d; a.gmv = m->Gm[1].d; a.gmw = m->Gm[2].d;
+  a.gnu = m->Gn[0].d; a.gnv = m->Gn[1].d; a.gnw = m->Gn[2].d;
+  a.us = m->us.d; a.vs = m->vs.d; a.ws = m->ws.d;
+  a.org = (unsigned)((m->u.Hx + m->u.Hy * m->u.sy + m->u.Hz * m->u.sz) * sizeof(double));
+  a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
+  a.dbg_nobar = 0;
+  a.nu = 0.0;
+  a.KZ = 0; a.ntx = 1; a.BXo = 0;
+  const GridDev& gd = m->gd;
+  const int bx = gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
+  const int by = bx == 256 ? 4 : 8;
+  a.BYo = by - 1;
+  a.ntiles = (gd.Ny + by - 2) / (by - 1);
+  static int ncu = 0;
+  if (!ncu) {
+#ifndef OCN_HOST_EMU
+    hipDeviceProp_t prop;
+    ncu = (hipGetDeviceProperties(&prop, m->ctx->device) == hipSuccess) ? prop.multiProcessorCount : 256;
+#else
+    ncu = 8;
+#endif
+  }
+  int nseg = ncu;
+  long total = (long)a.ntiles * gd.Nz;
+  if (nseg > total / 4) nseg = (int)(total / 4 > 8 ? total / 4 : 8);
+  nseg = ((nseg + 7) / 8) * 8;
+  dim3 blk(bx, by, 1), grd(nseg, 1, 1);
+  hipStream_t s = m->ctx->stream;
+#define BZ_CASE(ADVV)                                                                                          \
+  if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, false, true>, grd, blk, s, m->gd, a);     \
+  else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, false, true>, grd, blk, s, m->gd, a); \
+  else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, false, true>, grd, blk, s, m->gd, a);
+  switch (m->d.advection) {
+    case ADV_WENO_Z: BZ_CASE(ADV_WENO_Z) break;
+    case ADV_WENO_JS: BZ_CASE(ADV_WENO_JS) break;
+    default: BZ_CASE(ADV_U5) break;
+  }
+#undef BZ_CASE
 }
 
 void launch_rhs_wrap(ocn_model* m, double dt, double* rhs) {

@@ -104,6 +104,7 @@ struct ocn_model {
   int stage = 1;
   double* d_red = nullptr;  // reduction scratch
   int fast_path = 0;        // 1: fused periodic WENO kernels usable
+  int bz_fast = 0;          // 1: Bounded z: tiled advection + update kernel on top of the general kernels' other terms
   double* amd_tab = nullptr;     // per-level factors of the AMD predictors (kernels.hip amd_build_table)
   double* phi_below = nullptr;   // (Nx,Ny): top plane of the lower neighbour's pressure (slab runs)
   double *ypack_s = nullptr, *ypack_r = nullptr;   // y-slab halo exchange staging (send / receive)
@@ -122,8 +123,8 @@ struct FieldPtrs {
 void launch_fill_periodic(ocn_model* m, const FieldPtrs& f, int dim);
 void launch_fill_flat(ocn_model* m, const FieldPtrs& f, int dim);
 void launch_fill_bounded(ocn_model* m, Field& f, int dim);
-void launch_tendencies(ocn_model* m);
-void launch_step(ocn_model* m, double dt, double cn, double cm, int use_m);
+void launch_tendencies(ocn_model* m, bool skip_momentum_advection = false);
+void launch_step(ocn_model* m, double dt, double cn, double cm, int use_m, bool tracers_only = false);
 void launch_store(ocn_model* m);
 void launch_rhs(ocn_model* m, double dt, double* rhs, int mult_dz);
 void launch_pcorrect(ocn_model* m, double dt);
@@ -135,6 +136,8 @@ int amd_build_table(ocn_model* m);
 
 // ---- fused.hip -----------------------------------------------------------------------------------------
 bool fused_available(const ocn_model* m);
+bool fused_bz_available(const ocn_model* m);
+void launch_fused_bz(ocn_model* m, double dt, double cn, double cm, int use_m);
 void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m);
 void launch_rhs_wrap(ocn_model* m, double dt, double* rhs);
 void launch_project(ocn_model* m, double dt, const double* phi);

@@ -217,7 +217,7 @@ __global__ void k_apply_flux(GridDev g, double* __restrict__ G, int dim, int zlo
   }
 }
 
-void launch_tendencies(ocn_model* m) {
+void launch_tendencies(ocn_model* m, bool skip_momentum_advection) {
   ProfScope ps(m->ctx, "tendencies");
   const GridDev& g = m->gd;
   hipStream_t s = m->ctx->stream;
@@ -234,7 +234,8 @@ void launch_tendencies(ocn_model* m) {
   const double *u = m->u.interior(), *v = m->v.interior(), *w = m->w.interior();
   double *Gu = m->Gn[0].interior(), *Gv = m->Gn[1].interior(), *Gw = m->Gn[2].interior();
 #define TEND_LAUNCH(A, W)                                                       \
-  ocn_launch(k_tend_uvw<A, W>, gr, b, s, g, ph, u, v, w, Gu, Gv, Gw);           \
+  if (skip_momentum_advection) ocn_launch(k_tend_uvw<ADV_NONE, W>, gr, b, s, g, ph, u, v, w, Gu, Gv, Gw);   \
+  else ocn_launch(k_tend_uvw<A, W>, gr, b, s, g, ph, u, v, w, Gu, Gv, Gw);      \
   for (int t = 0; t < m->nt; ++t)                                               \
     ocn_launch(k_tend_c<A, W>, gr, b, s, g, u, v, w, (const double*)m->tr[t].interior(), m->d.kappa[t], \
                (const double*)(m->kappa_e[t].present ? m->kappa_e[t].interior() : nullptr), m->d.closure, \
@@ -298,17 +299,19 @@ __global__ void k_step(GridDev g, StepPtrs P, double dt, double cn, double cm, i
 }
 
 // U += dt * (cn * Gn + cm * Gm)   [AB2: cn = 1.5+chi, cm = -(0.5+chi);  RK3: cn = gamma, cm = zeta]
-void launch_step(ocn_model* m, double dt, double cn, double cm, int use_m) {
+void launch_step(ocn_model* m, double dt, double cn, double cm, int use_m, bool tracers_only) {
   ProfScope ps(m->ctx, "step");
   const GridDev& g = m->gd;
   StepPtrs P;
-  P.n = 3 + m->nt;
-  for (int f = 0; f < P.n; ++f) {
+  P.n = 0;
+  for (int f = tracers_only ? 3 : 0; f < 3 + m->nt; ++f) {
     Field* fld = f == 0 ? &m->u : f == 1 ? &m->v : f == 2 ? &m->w : &m->tr[f - 3];
-    P.U[f] = fld->interior();
-    P.Gn[f] = m->Gn[f].interior();
-    P.Gm[f] = m->Gm[f].interior();
+    P.U[P.n] = fld->interior();
+    P.Gn[P.n] = m->Gn[f].interior();
+    P.Gm[P.n] = m->Gm[f].interior();
+    ++P.n;
   }
+  if (P.n == 0) return;
   dim3 b(64, 4, 1);
   ocn_launch(k_step, grid3(g, b), b, m->ctx->stream, g, P, dt, cn, cm, use_m);
 }
