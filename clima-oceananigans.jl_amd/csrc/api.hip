@@ -419,7 +419,7 @@ static int fill_fields(ocn_model* m, Field** fs, int n) {
   for (int t = 0; t < 3; ++t) {
     const int d = order[t];
     if (m->g->topo[d] == OCN_BOUNDED) {
-      for (int i = 0; i < n; ++i) launch_fill_bounded(m, *fs[i], d);
+      launch_fill_bounded(m, fs, n, d);
     } else if (m->g->topo[d] == OCN_PERIODIC) {
       if (d == 2 && m->g->dist) rc = comm_halo_exchange_z(m, fs, n);
       else if (d == 1 && m->g->dist_y) rc = comm_halo_exchange_y(m, fs, n);

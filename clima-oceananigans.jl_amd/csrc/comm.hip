@@ -171,16 +171,25 @@ int comm_halo_exchange_z(ocn_model* m, Field** fs, int n) {
 // y-halo exchange for y-slabs (Bounded z): H rows of every (x, z) -- full parent extent in x and z, as the periodic
 // fill it replaces (fill_halo_regions_periodic.jl:37-65) -- are strided in memory, so they are packed into one
 // staging buffer per call, exchanged with both ring neighbours in one group, and unpacked.
-__global__ void k_pack_rows(double* __restrict__ p, long sy, long sz, int Tx, int Tz, int H, int row0,
-                            double* __restrict__ buf, int unpack) {
+struct RowPack {
+  double* p[OCN_NF + 2];
+  long off[OCN_NF + 2];      // start of the field's two blocks in the staging buffer
+  int Tx[OCN_NF + 2], Tz[OCN_NF + 2];
+  int n;
+};
+// blockIdx.z = 2 * field + side; blockIdx.y = h + H * k.  pack: rows [Ny, Ny+H) (side 0) and [H, 2H) (side 1) -> buffer;
+// unpack: buffer -> rows [0, H) (side 0: from the lower neighbour) and [Ny+H, Ny+2H) (side 1: from the upper one).
+__global__ void k_pack_rows(RowPack P, long sy, long sz, int H, int Ny, double* __restrict__ buf, int unpack) {
+  const int f = blockIdx.z >> 1, side = blockIdx.z & 1;
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int h = blockIdx.y;
-  const int k = blockIdx.z;
-  if (x >= Tx || h >= H || k >= Tz) return;
+  const int h = blockIdx.y % H, k = blockIdx.y / H;
+  const int Tx = P.Tx[f];
+  if (x >= Tx || k >= P.Tz[f]) return;
+  const int row0 = unpack ? (side == 0 ? 0 : Ny + H) : (side == 0 ? Ny : H);
   const long ip = x + (long)(row0 + h) * sy + (long)k * sz;
-  const long ib = x + (long)Tx * (h + (long)H * k);
-  if (unpack) p[ip] = buf[ib];
-  else buf[ib] = p[ip];
+  const long ib = P.off[f] + (long)side * H * Tx * P.Tz[f] + x + (long)Tx * (h + (long)H * k);
+  if (unpack) P.p[f][ip] = buf[ib];
+  else buf[ib] = P.p[f][ip];
 }
 
 int comm_halo_exchange_y(ocn_model* m, Field** fs, int n) {
@@ -189,7 +198,7 @@ int comm_halo_exchange_y(ocn_model* m, Field** fs, int n) {
   const int R = c->nranks, r = c->rank;
   const int up = (r + 1) % R, dn = (r + R - 1) % R;
   const int Ny = m->gd.Ny, H = m->gd.Hy;
-  if (H == 0) return OCN_OK;
+  if (H == 0 || n == 0) return OCN_OK;
   size_t need = 0;
   for (int i = 0; i < n; ++i) need += 2 * (size_t)H * fs[i]->P[0] * fs[i]->T[2];
   if (need > m->ypack_n) {
@@ -204,35 +213,32 @@ int comm_halo_exchange_y(ocn_model* m, Field** fs, int n) {
     }
     m->ypack_n = need;
   }
+  RowPack P;
+  P.n = n;
   std::vector<CommOp> sends, recvs;
-  std::vector<size_t> off(n);
   size_t o = 0;
-  const dim3 b(64, 1, 1);
+  int Txm = 0, Tzm = 0;
   for (int i = 0; i < n; ++i) {
     Field* f = fs[i];
-    const int Tx = f->P[0], Tz = f->T[2];
-    const size_t blk = (size_t)H * Tx * Tz;
-    off[i] = o;
-    const dim3 gr((Tx + 63) / 64, H, Tz);
-    // block 0: my top interior rows [Ny, Ny+H) -> upper neighbour's south halo; block 1: rows [H, 2H) -> lower's north halo
-    ocn_launch(k_pack_rows, gr, b, c->stream, f->d, f->sy, f->sz, Tx, Tz, H, Ny, m->ypack_s + o, 0);
-    ocn_launch(k_pack_rows, gr, b, c->stream, f->d, f->sy, f->sz, Tx, Tz, H, H, m->ypack_s + o + blk, 0);
+    const size_t blk = (size_t)H * f->P[0] * f->T[2];
+    P.p[i] = f->d;
+    P.off[i] = (long)o;
+    P.Tx[i] = f->P[0];
+    P.Tz[i] = f->T[2];
+    Txm = f->P[0] > Txm ? f->P[0] : Txm;
+    Tzm = f->T[2] > Tzm ? f->T[2] : Tzm;
+    // block 0: my top interior rows -> upper neighbour's south halo; block 1: my bottom interior rows -> lower's north halo
     sends.push_back({m->ypack_s + o, blk * sizeof(double), up, 2 * i});
     recvs.push_back({m->ypack_r + o, blk * sizeof(double), dn, 2 * i});
     sends.push_back({m->ypack_s + o + blk, blk * sizeof(double), dn, 2 * i + 1});
     recvs.push_back({m->ypack_r + o + blk, blk * sizeof(double), up, 2 * i + 1});
     o += 2 * blk;
   }
+  const dim3 b(64, 1, 1), gr((Txm + 63) / 64, H * Tzm, 2 * n);
+  ocn_launch(k_pack_rows, gr, b, c->stream, P, m->gd.sy, m->gd.sz, H, Ny, m->ypack_s, 0);     // all fields, both sides
   int rc = comm_exchange(c, sends, recvs);
   if (rc) return rc;
-  for (int i = 0; i < n; ++i) {
-    Field* f = fs[i];
-    const int Tx = f->P[0], Tz = f->T[2];
-    const size_t blk = (size_t)H * Tx * Tz;
-    const dim3 gr((Tx + 63) / 64, H, Tz);
-    ocn_launch(k_pack_rows, gr, b, c->stream, f->d, f->sy, f->sz, Tx, Tz, H, 0, m->ypack_r + off[i], 1);
-    ocn_launch(k_pack_rows, gr, b, c->stream, f->d, f->sy, f->sz, Tx, Tz, H, Ny + H, m->ypack_r + off[i] + blk, 1);
-  }
+  ocn_launch(k_pack_rows, gr, b, c->stream, P, m->gd.sy, m->gd.sz, H, Ny, m->ypack_r, 1);
   return OCN_OK;
 }
 

@@ -115,14 +115,14 @@ struct ocn_model {
 Field* model_field(ocn_model* m, int id);
 
 // ---- kernels.hip ------------------------------------------------------------------------------------
-struct FieldPtrs {
-  double* p[OCN_NF];
-  int Tx[OCN_NF], Ty[OCN_NF], Tz[OCN_NF];   // extents the fill sweeps (the field's own parent extents)
+struct FieldPtrs {   // up to velocities + both pressures + all tracers in one call (ocn_fill_halos)
+  double* p[OCN_NF + 2];
+  int Tx[OCN_NF + 2], Ty[OCN_NF + 2], Tz[OCN_NF + 2];   // extents the fill sweeps (the field's own parent extents)
   int n;
 };
 void launch_fill_periodic(ocn_model* m, const FieldPtrs& f, int dim);
 void launch_fill_flat(ocn_model* m, const FieldPtrs& f, int dim);
-void launch_fill_bounded(ocn_model* m, Field& f, int dim);
+void launch_fill_bounded(ocn_model* m, Field** fs, int n, int dim);
 void launch_tendencies(ocn_model* m, bool skip_momentum_advection = false);
 void launch_step(ocn_model* m, double dt, double cn, double cm, int use_m, bool tracers_only = false);
 void launch_store(ocn_model* m);

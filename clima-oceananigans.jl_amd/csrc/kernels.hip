@@ -427,9 +427,17 @@ void launch_fill_flat(ocn_model* m, const FieldPtrs& F, int dim) {
 
 // Bounded directions: one halo cell per side (fill_halo_regions_flux.jl:16-35, ..value_gradient.jl:7-99,
 // ..open.jl:34-39), launched over the two other directions' *centre* sizes (:yz / :xz / :xy).
-__global__ void k_fill_bounded(GridDev g, double* __restrict__ p, int dim, int face, BCdev lo, BCdev hi) {
+struct BoundedFill {          // one launch fills the same direction of several fields
+  double* p[OCN_NF + 2];
+  int face[OCN_NF + 2];
+  BCdev lo[OCN_NF + 2], hi[OCN_NF + 2];
+};
+__global__ void k_fill_bounded(GridDev g, BoundedFill F, int dim) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y * blockDim.y + threadIdx.y;
+  double* __restrict__ p = F.p[blockIdx.z];
+  const int face = F.face[blockIdx.z];
+  const BCdev lo = F.lo[blockIdx.z], hi = F.hi[blockIdx.z];
   const int Na = dim == 0 ? g.Ny : g.Nx, Nb = dim == 2 ? g.Ny : g.Nz;
   if (a >= Na || b >= Nb) return;
   long c, st;
@@ -467,11 +475,18 @@ __global__ void k_fill_bounded(GridDev g, double* __restrict__ p, int dim, int f
   }
 }
 
-void launch_fill_bounded(ocn_model* m, Field& f, int dim) {
+void launch_fill_bounded(ocn_model* m, Field** fs, int n, int dim) {
   const GridDev& g = m->gd;
   const int Na = dim == 0 ? g.Ny : g.Nx, Nb = dim == 2 ? g.Ny : g.Nz;
-  dim3 b(64, 4, 1), gr((Na + 63) / 64, (Nb + 3) / 4, 1);
-  ocn_launch(k_fill_bounded, gr, b, m->ctx->stream, g, f.interior(), dim, f.loc[dim], f.bc[2 * dim], f.bc[2 * dim + 1]);
+  BoundedFill F;
+  for (int i = 0; i < n; ++i) {
+    F.p[i] = fs[i]->interior();
+    F.face[i] = fs[i]->loc[dim];
+    F.lo[i] = fs[i]->bc[2 * dim];
+    F.hi[i] = fs[i]->bc[2 * dim + 1];
+  }
+  dim3 b(64, 4, 1), gr((Na + 63) / 64, (Nb + 3) / 4, n);
+  ocn_launch(k_fill_bounded, gr, b, m->ctx->stream, g, F, dim);
 }
 
 // ---- Poisson right-hand side (solve_for_pressure.jl:15-18,30-33) ------------------------------------------
