@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
 // produces the WEST-face fluxes that the last output column needs as its EAST fluxes (the same device as the ghost
 // row in y); x halos of the slab are read from the arrays' own halo columns (the projection keeps their periodic
 // images current) instead of being wrapped inside LDS.  Tiles are (x-tile, y-tile) pairs, x fastest.
-template <int ADV, int BX, int BY, bool VISC>
+template <int ADV, int BX, int BY, bool VISC, bool ZB>
 __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) {
   constexpr bool EARLY = true, FENCE3 = false;
   constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
@@ -474,6 +474,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
   const int tid = ty * BX + tx;
   const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
   const double rdx = g.rdx, rdy = g.rdy, rdz = 1.0 / g.dz;
+  const int nbz = (ADV == ADV_C4) ? 1 : 2;   // boundary buffer of the scheme (ZB, see k_tend_step3)
   const bool ghost = (ty == BY - 1);
   const int nid_e = ty * BX + (tx + 1 < BX ? tx + 1 : tx);   // the east neighbour is the next thread (output or ghost column)
   const int nid_n = (ty + 1 < BY ? ty + 1 : ty) * BX + tx;
@@ -558,6 +559,12 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
     if (!(a.dbg_nobar & 2)) __syncthreads();
     if (EARLY && !last) prefetch(k + 1);   // next level's slab in flight during the whole flux stage
     double gm0 = 0, gm1 = 0, gm2 = 0;      // G^- of the level finalized below, also fetched early
+    double rs0 = 0, rs1 = 0, rs2 = 0;      // ZB: the non-advective part of G^n waiting in the G^n arrays
+    if (ZB && full && k > k0) {
+      rs0 = ldo(a.gnu, c - szb);
+      rs1 = ldo(a.gnv, c - szb);
+      rs2 = ldo(a.gnw, c - szb);
+    }
     if (EARLY && a.use_m && full && k > k0) {
       gm0 = ldo(a.gmu, c - szb);
       gm1 = ldo(a.gmv, c - szb);
@@ -575,12 +582,21 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
       wxm = ldo(a.w, c + szb - sxb);
       wym = ldo(a.w, c + szb - syb);
     }
-    auto symz = [&](const double* z) { return sym4_v(z[1], z[2], z[3], z[4]); };
-    auto reconz = [&](const double* z, double ut) {
+    auto symz_at = [&](const double* z, int idx) {
+      if (ZB && !(idx > nbz && idx < g.Nz + 1 - nbz)) return 0.5 * (z[2] + z[3]);
+      return sym4_v(z[1], z[2], z[3], z[4]);
+    };
+    auto symz = [&](const double* z) { return symz_at(z, k + 1); };
+    auto reconz_at = [&](const double* z, double ut, int idx) {
       bool pos = ut > 0.0;
+      if (ZB) {
+        const bool ok = pos ? (idx > nbz && idx < g.Nz + 1 - (nbz - 1)) : (idx > nbz - 1 && idx < g.Nz + 1 - nbz);
+        if (!ok) return 0.5 * (z[2] + z[3]);
+      }
       return recon5<ADV>(pos ? z[0] : z[5], pos ? z[1] : z[4], pos ? z[2] : z[3], pos ? z[3] : z[2],
                          pos ? z[4] : z[1], pos);
     };
+    auto reconz = [&](const double* z, double ut) { return reconz_at(z, ut, k + 1); };
     auto sym_v = [&](double m2, double m1, double c0, double c1) { return sym4_v(m2, m1, c0, c1); };  // midway m1|c0
     auto rec_v = [&](double m3, double m2, double m1, double c0, double c1, double c2, double ut) {
       bool pos = ut > 0.0;                                            // face between m1 and c0
@@ -634,8 +650,8 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
       double wtv = YSYM(2);
       Fwv = wtv * reconz(zv, wtv);
       if (FENCE3) OCN_SCHED_FENCE();
-      double wtw = symz(zw);
-      Fww = wtw * reconz(zw, wtw);
+      double wtw = symz_at(zw, k);                    // centre below face k
+      Fww = wtw * reconz_at(zw, wtw, k);
       if (visc) {
         Fwu -= a.nu * (zu[3] - zu[2]) * rdz;
         Fwv -= a.nu * (zv[3] - zv[2]) * rdz;
@@ -653,9 +669,10 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
     if (full) {
       if (k > k0) {
         const unsigned cm1 = c - szb;
-        double Gu = -(own[0 * T + tid] + (Fwu - own[3 * T + tid]) * rdz);
-        double Gv = -(own[1 * T + tid] + (Fwv - own[4 * T + tid]) * rdz);
-        double Gw = -(own[2 * T + tid] + (Fww - own[5 * T + tid]) * rdz);
+        const double rzc = ZB ? g_rdzc(g, k - 1) : rdz, rzf = ZB ? g_rdzf(g, k - 1) : rdz;
+        double Gu = rs0 - (own[0 * T + tid] + (Fwu - own[3 * T + tid]) * rzc);
+        double Gv = rs1 - (own[1 * T + tid] + (Fwv - own[4 * T + tid]) * rzc);
+        double Gw = rs2 - (own[2 * T + tid] + (Fww - own[5 * T + tid]) * rzf);
         sto(a.gnu, cm1, Gu);
         sto(a.gnv, cm1, Gv);
         sto(a.gnw, cm1, Gw);
@@ -957,10 +974,10 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
     nseg = ((nseg + 7) / 8) * 8;
     dim3 blk(bx, by, 1), grd(nseg, 1, 1);
 #define V3X_CASE(ADVV)                                                                     \
-    if (small && a.nu != 0.0) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, true>, grd, blk, s, m->gd, a);   \
-    else if (small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, false>, grd, blk, s, m->gd, a);            \
-    else if (a.nu != 0.0) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, true>, grd, blk, s, m->gd, a);     \
-    else ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, false>, grd, blk, s, m->gd, a);
+    if (small && a.nu != 0.0) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, true, false>, grd, blk, s, m->gd, a);   \
+    else if (small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, false, false>, grd, blk, s, m->gd, a);            \
+    else if (a.nu != 0.0) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, true, false>, grd, blk, s, m->gd, a);     \
+    else ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, false, false>, grd, blk, s, m->gd, a);
     switch (m->d.advection) {
       case ADV_WENO_Z: V3X_CASE(ADV_WENO_Z) break;
       case ADV_WENO_JS: V3X_CASE(ADV_WENO_JS) break;
@@ -987,7 +1004,6 @@ bool fused_bz_available(const ocn_model* m) {
   if (adv != ADV_WENO_Z && adv != ADV_WENO_JS && adv != ADV_U5) return false;
   for (int d = 0; d < 3; ++d)
     if (g->H[d] < 3 || g->N[d] < 2 * g->H[d]) return false;
-  if (g->N[0] > 256) return false;                             // complete x rows per workgroup (the x-tiled variant is periodic-z only)
   if (m->u.n * sizeof(double) >= (1ull << 31) || m->w.n * sizeof(double) >= (1ull << 31)) return false;
   if (getenv("OCNHIP_NO_FUSED") || getenv("OCNHIP_NO_FUSED_BZ")) return false;
   return true;
@@ -1008,10 +1024,20 @@ void launch_fused_bz(ocn_model* m, double dt, double cn, double cm, int use_m) {
   a.nu = 0.0;
   a.KZ = 0; a.ntx = 1; a.BXo = 0;
   const GridDev& gd = m->gd;
-  const int bx = gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
-  const int by = bx == 256 ? 4 : 8;
+  const int xt_env = getenv("OCNHIP_FUSED_XT") ? atoi(getenv("OCNHIP_FUSED_XT")) : 0;     // 1: force the x-tiled kernel (tests)
+  const bool small = xt_env == 1 && gd.Nx <= 57 * 4;
+  const bool wide = gd.Nx > 256 || small;
+  const int bx = small ? 64 : wide ? 192 : gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
+  const int by = small ? 4 : wide ? 5 : bx == 256 ? 4 : 8;
   a.BYo = by - 1;
   a.ntiles = (gd.Ny + by - 2) / (by - 1);
+  if (wide) {
+    const int cap = bx - 7;
+    a.ntx = (gd.Nx + cap - 1) / cap;
+    if (small && a.ntx < 2) a.ntx = 2;
+    a.BXo = (gd.Nx + a.ntx - 1) / a.ntx;
+    a.ntiles *= a.ntx;
+  }
   static int ncu = 0;
   if (!ncu) {
 #ifndef OCN_HOST_EMU
@@ -1028,7 +1054,9 @@ void launch_fused_bz(ocn_model* m, double dt, double cn, double cm, int use_m) {
   dim3 blk(bx, by, 1), grd(nseg, 1, 1);
   hipStream_t s = m->ctx->stream;
 #define BZ_CASE(ADVV)                                                                                          \
-  if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, false, true>, grd, blk, s, m->gd, a);     \
+  if (small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, false, true>, grd, blk, s, m->gd, a);                      \
+  else if (wide) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, false, true>, grd, blk, s, m->gd, a);                 \
+  else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, false, true>, grd, blk, s, m->gd, a);     \
   else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, false, true>, grd, blk, s, m->gd, a); \
   else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, false, true>, grd, blk, s, m->gd, a);
   switch (m->d.advection) {

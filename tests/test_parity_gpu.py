@@ -81,6 +81,22 @@ def test_wide_rows_vs_oracle(ocn, N):
         assert np.abs(a.parent() - b.data).max() <= 2e-11 * np.abs(b.data).max()
 
 
+def test_wide_bounded_rows_vs_oracle(ocn):
+    """(Periodic, Periodic, Bounded) with rows wider than a workgroup: x-tiled tendency kernel in its bounded-z form, on top
+    of the general kernels' buoyancy / Coriolis / closure terms, stretched z, RK3 -- vs the oracle."""
+    import copy
+    import parity_cases as pc
+    cfg = copy.deepcopy(pc.CASES["ppb_stretched_bcs"])
+    cfg["size"] = (300, 10, 8)
+    om, dm = pc.build(pc.O, cfg), pc.build(ocn, cfg)
+    for _ in range(2):
+        pc.O.time_step(om, cfg["dt"])
+        ocn.time_step(dm, cfg["dt"])
+    a, b = pc.fields_of(om, True), pc.fields_of(dm, False)
+    for k in a:
+        assert np.abs(a[k] - b[k]).max() <= 2e-11 * max(np.abs(a[k]).max(), 1e-300), k
+
+
 def test_full_size_properties(ocn):
     """BASELINE config 2 (256^3, WENO5, AB2): projection leaves max|div U| ~ roundoff, halos are periodic
     images, and the Poisson solve satisfies lap(phi) = R to roundoff."""
