@@ -55,6 +55,11 @@ CASES = {
     "ppb_stretched_c2": dict(size=(6, 7, 8), topo=(P, P, B), xy=((0, 1), (0, 1)),
                              zfaces=[0, 1, 2, 4, 7, 11, 16, 22, 29], adv="C2", stepper="AB2", steps=2, dt=1e-2,
                              tracers=("b",), buoyancy="b", closure=(1e-2, 1e-2)),
+    # no-slip bottom, wind-stress top, regular z: the bounded-z tiled kernel next to value conditions
+    "ppb_weno_noslip": dict(size=(10, 9, 8), topo=(P, P, B), extent=(1, 1, 0.5), adv="WENO5", stepper="AB2", steps=3, dt=2e-3,
+                            tracers=("b",), buoyancy="b", closure=(1e-2, 1e-2), coriolis=1e-1,
+                            bcs={"u": {"bottom": ("value", 0.0), "top": ("flux", -1e-2)}, "v": {"bottom": ("value", 0.0)},
+                                 "b": {"top": ("value", 1.0), "bottom": ("gradient", 0.3)}}),
     # BASELINE config 3 in miniature: stretched bounded z, T/S, FPlane, linear EOS, AMD, flux/gradient BCs, WENO5, RK3
     "ppb_amd_config3": dict(size=(8, 8, 8), topo=(P, P, B), xy=((0, 2), (0, 2)),
                             zfaces=[-1.0, -0.8, -0.62, -0.46, -0.32, -0.2, -0.1, -0.04, 0.0],
