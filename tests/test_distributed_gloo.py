@@ -107,6 +107,43 @@ def _worker(rank, world, port, q):
         loc[:, :, :H], loc[:, :, nzl + H:] = rb.numpy(), rt.numpy()
         idx = (np.arange(-H, nzl + H) + rank * nzl) % N[2]
         assert np.array_equal(loc, glob[:, :, idx])
+        # (c) y-slab algorithm for a Bounded z (csrc/poisson.hip run_yslab): local x transform, all-to-all to kx bands with
+        #     every y, local y transform + Thomas sweeps down z, and back; padded band when Nxh is not divisible by R
+        Nb = (10, 8, 7)
+        faces = np.array([0.0, 1, 2, 4, 7, 11, 16, 22])
+        kwb = dict(x=(0, 1), y=(0, 2), z=faces, topology=("Periodic", "Periodic", "Bounded"))
+        ogb = O.RectilinearGrid(size=Nb, **kwb)
+        srcb = rng.random(Nb)
+        dzc = np.diff(faces).reshape(1, 1, -1)
+        srcb -= (srcb * dzc).sum() / (dzc.sum() * Nb[0] * Nb[1])
+        fts = poisson.FourierTridiagonalPoissonSolver(ogb)
+        ref_b = fts.solve_source(srcb)
+        nyl_b = Nb[1] // R
+        mine_b = (srcb * dzc)[:, rank * nyl_b:(rank + 1) * nyl_b, :]
+        sx = np.fft.rfft(mine_b, axis=0)                                   # (Nxh, nyl, Nz)
+        nxh_b = sx.shape[0]
+        w = -(-nxh_b // R)                                                # kx columns per rank, padded
+        pad = np.zeros((w * R, nyl_b, Nb[2]), dtype=complex)
+        pad[:nxh_b] = sx
+        send = [torch.from_numpy(np.ascontiguousarray(pad[q * w:(q + 1) * w])) for q in range(R)]
+        recv = [torch.empty_like(send[0]) for _ in range(R)]
+        all_to_all(recv, send)
+        band = np.concatenate([t.numpy() for t in recv], axis=1)          # (w, Ny, Nz): my kx band, all y
+        bh = np.fft.fft(band, axis=1)
+        kx = np.minimum(np.arange(rank * w, (rank + 1) * w), nxh_b - 1)   # padding columns: any non-singular eigenvalue
+        Dband = fts.D[kx]                                                  # diagonal of my kx rows (lx + ly inside)
+        sol = poisson.thomas_batched(fts.lower, Dband, fts.lower, bh, Nb[2])
+        band2 = np.fft.ifft(sol, axis=1)
+        send = [torch.from_numpy(np.ascontiguousarray(band2[:, q * nyl_b:(q + 1) * nyl_b])) for q in range(R)]
+        recv = [torch.empty_like(send[0]) for _ in range(R)]
+        all_to_all(recv, send)
+        spec_b = np.concatenate([t.numpy() for t in recv], axis=0)[:nxh_b]  # (Nxh, nyl, Nz)
+        phi_b = np.fft.irfft(spec_b, n=Nb[0], axis=0)
+        tot = torch.tensor([phi_b.sum()], dtype=torch.float64)
+        dist.all_reduce(tot)
+        phi_b -= float(tot[0]) / np.prod(Nb)                                # phi .-= mean(phi) over the global domain
+        err = np.abs(phi_b - ref_b[:, rank * nyl_b:(rank + 1) * nyl_b]).max() / np.abs(ref_b).max()
+        assert err < 1e-11, err
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
