@@ -418,6 +418,12 @@ static int fill_fields(ocn_model* m, Field** fs, int n) {
   fill_order(m->g, order);
   for (int t = 0; t < 3; ++t) {
     const int d = order[t];
+    // y directly followed by x, both Periodic and local: one pass over the whole halo frame
+    if (d == 1 && t < 2 && order[t + 1] == 0 && m->g->topo[0] == OCN_PERIODIC && m->g->topo[1] == OCN_PERIODIC &&
+        !m->g->dist_y && launch_fill_periodic_xy(m, F)) {
+      ++t;
+      continue;
+    }
     if (m->g->topo[d] == OCN_BOUNDED) {
       launch_fill_bounded(m, fs, n, d);
     } else if (m->g->topo[d] == OCN_PERIODIC) {

@@ -122,6 +122,7 @@ struct FieldPtrs {   // up to velocities + both pressures + all tracers in one c
 };
 void launch_fill_periodic(ocn_model* m, const FieldPtrs& f, int dim);
 void launch_fill_flat(ocn_model* m, const FieldPtrs& f, int dim);
+bool launch_fill_periodic_xy(ocn_model* m, const FieldPtrs& f);   // false: not applicable, use the two passes
 void launch_fill_bounded(ocn_model* m, Field** fs, int n, int dim);
 void launch_tendencies(ocn_model* m, bool skip_momentum_advection = false);
 void launch_step(ocn_model* m, double dt, double cn, double cm, int use_m, bool tracers_only = false);

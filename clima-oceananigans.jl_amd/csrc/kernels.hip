@@ -394,6 +394,45 @@ void launch_fill_periodic(ocn_model* m, const FieldPtrs& F, int dim) {
   ocn_launch(k_fill_periodic, gr, b, m->ctx->stream, F, dim, N, H, g.sy, g.sz);
 }
 
+// Periodic x AND y in one pass: every halo cell of the frame (rows, columns, corners) takes its periodic image straight
+// from the interior -- identical to the y pass followed by the x pass (fill_halo_regions.jl order) whenever N >= H.
+__global__ void k_fill_periodic_xy(FieldPtrs F, int Nx, int Ny, int H, long sy, long sz) {
+  const int f = blockIdx.z;
+  const int Tx = Nx + 2 * H;
+  const int nrow = 2 * H * Tx, ncol = 2 * H * Ny;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;      // index inside the frame of one plane
+  const int k = blockIdx.y;
+  if (q >= nrow + ncol || k >= F.Tz[f]) return;
+  int a, b;
+  if (q < nrow) {                                           // the 2H halo rows, full width
+    const int r = q / Tx;
+    a = q - r * Tx;
+    b = r < H ? r : Ny + r;                                 // r in [H, 2H) -> rows Ny+H .. Ny+2H-1
+  } else {                                                  // the 2H halo columns of the interior rows
+    const int t = q - nrow, r = t / (2 * H), cidx = t - r * (2 * H);
+    b = H + r;
+    a = cidx < H ? cidx : Nx + cidx;
+  }
+  int as = a - H, bs = b - H;                               // interior image
+  as = as < 0 ? as + Nx : (as >= Nx ? as - Nx : as);
+  bs = bs < 0 ? bs + Ny : (bs >= Ny ? bs - Ny : bs);
+  double* p = F.p[f] + (long)k * sz;
+  p[a + (long)b * sy] = p[(as + H) + (long)(bs + H) * sy];
+}
+
+bool launch_fill_periodic_xy(ocn_model* m, const FieldPtrs& F) {
+  const GridDev& g = m->gd;
+  if (g.Hx != g.Hy || g.Hx == 0 || g.Nx < g.Hx || g.Ny < g.Hy || g.xb || g.yb) return false;
+  for (int f = 0; f < F.n; ++f)
+    if (F.Tx[f] != g.Nx + 2 * g.Hx || F.Ty[f] != g.Ny + 2 * g.Hy) return false;
+  int Tz = 0;
+  for (int f = 0; f < F.n; ++f) Tz = F.Tz[f] > Tz ? F.Tz[f] : Tz;
+  const int frame = 2 * g.Hx * (g.Nx + 2 * g.Hx) + 2 * g.Hx * g.Ny;
+  dim3 b(256, 1, 1), gr((frame + 255) / 256, Tz, F.n);
+  ocn_launch(k_fill_periodic_xy, gr, b, m->ctx->stream, F, g.Nx, g.Ny, g.Hx, g.sy, g.sz);
+  return true;
+}
+
 // Flat x / y: every physical slot along the direction holds the single logical value
 __global__ void k_fill_flat(FieldPtrs F, int dim, int H, long sy, long sz) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
