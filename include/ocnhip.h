@@ -166,7 +166,8 @@ int ocn_fill_halos(ocn_model* m, uint32_t field_mask);
 int ocn_update_state(ocn_model* m);
 /* calculate_tendencies!(model)  .../calculate_nonhydrostatic_tendencies.jl:12-36 (interior + boundary) */
 int ocn_compute_tendencies(ocn_model* m);
-/* ab2_step!(model, dt, chi)     TimeSteppers/quasi_adams_bashforth_2.jl:116-150 */
+/* ab2_step!(model, dt, chi)     TimeSteppers/quasi_adams_bashforth_2.jl:116-150.  The caller of the phase-level entry
+ * points owns the clock (ocn_set_clock): previous_dt decides between Euler and AB2 inside ocn_time_step only. */
 int ocn_ab2_step(ocn_model* m, double dt, double chi);
 /* rk3_substep!(model, dt, gamma, zeta)  TimeSteppers/runge_kutta_3.jl:161-218 ; has_zeta = 0 for stage 1 */
 int ocn_rk3_substep(ocn_model* m, double dt, double gamma, double zeta, int has_zeta);
@@ -192,8 +193,10 @@ int ocn_set_clock(ocn_model* m, double time, int64_t iteration, double previous_
 /* max |div U| over the interior (test helper `divergence!`, test/utils_for_runtests.jl:60-67) */
 int ocn_max_abs_divergence(ocn_model* m, double* out);
 
-/* ---- multi-GPU: one process per GPU, z-slabs, RCCL (Distributed/multi_architectures.jl:20-137,
- * halo_communication.jl:68-183, distributed_fft_based_poisson_solver.jl:95-196) ------------------- */
+/* ---- multi-GPU: one process per GPU, RCCL (Distributed/multi_architectures.jl:20-137, halo_communication.jl:68-183,
+ * distributed_fft_based_poisson_solver.jl:95-196).  Call ocn_comm_init BEFORE ocn_grid_create: grids created afterwards
+ * are cut into z-slabs (triply Periodic) or y-slabs ((Periodic, Periodic, Bounded)); every compute call is then
+ * collective and must be issued by all ranks in the same order. ---------------------------------------- */
 int ocn_comm_unique_id(void* out128);                                      /* ncclGetUniqueId (128 bytes) */
 int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* unique_id128);
 int ocn_comm_rank(const ocn_ctx* ctx, int* rank, int* nranks);
