@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(FUSED_MAX_THREADS) k_tend_step(GridDev g, Fuse
 // base address (workgroup shape is a template parameter, so row / field strides are immediates).
 //   LDS: slab 3*(BY+5)*(BX+6) + flux exchange 6*T + carry 6*T doubles  (BX = 256, BY = 4: 151.3 KB of 160)
 #define SLAB_MAXG 3
-template <int ADV, int BX, int BY, bool EARLY, bool FENCE3, bool VISC, bool ZB>
+template <int ADV, int BX, int BY, bool EARLY, bool FENCE3, bool VISC, bool ZB, bool REST>
 __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
   // ZB: Bounded z (regular or stretched).  The march is the same; what changes is uniform per level: the spacings,
   // the 2nd-order fallback of every z stencil inside the boundary buffer (topologically_conditional_interpolation.jl:
@@ -294,8 +294,8 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
     if (!(a.dbg_nobar & 2)) __syncthreads();
     if (EARLY && !last) prefetch(k + 1);   // next level's slab in flight during the whole flux stage
     double gm0 = 0, gm1 = 0, gm2 = 0;      // G^- of the level finalized below, also fetched early
-    double rs0 = 0, rs1 = 0, rs2 = 0;      // ZB: the non-advective part of G^n waiting in the G^n arrays
-    if (ZB && full && k > k0) {
+    double rs0 = 0, rs1 = 0, rs2 = 0;      // REST: the non-advective part of G^n waiting in the G^n arrays
+    if (REST && full && k > k0) {
       rs0 = ldo(a.gnu, c - szb);
       rs1 = ldo(a.gnv, c - szb);
       rs2 = ldo(a.gnw, c - szb);
@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
 // produces the WEST-face fluxes that the last output column needs as its EAST fluxes (the same device as the ghost
 // row in y); x halos of the slab are read from the arrays' own halo columns (the projection keeps their periodic
 // images current) instead of being wrapped inside LDS.  Tiles are (x-tile, y-tile) pairs, x fastest.
-template <int ADV, int BX, int BY, bool VISC, bool ZB>
+template <int ADV, int BX, int BY, bool VISC, bool ZB, bool REST>
 __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) {
   constexpr bool EARLY = true, FENCE3 = false;
   constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
@@ -559,8 +559,8 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
     if (!(a.dbg_nobar & 2)) __syncthreads();
     if (EARLY && !last) prefetch(k + 1);   // next level's slab in flight during the whole flux stage
     double gm0 = 0, gm1 = 0, gm2 = 0;      // G^- of the level finalized below, also fetched early
-    double rs0 = 0, rs1 = 0, rs2 = 0;      // ZB: the non-advective part of G^n waiting in the G^n arrays
-    if (ZB && full && k > k0) {
+    double rs0 = 0, rs1 = 0, rs2 = 0;      // REST: the non-advective part of G^n waiting in the G^n arrays
+    if (REST && full && k > k0) {
       rs0 = ldo(a.gnu, c - szb);
       rs1 = ldo(a.gnv, c - szb);
       rs2 = ldo(a.gnw, c - szb);
@@ -929,15 +929,15 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
     dim3 blk(bx, by, 1), grd(nseg, 1, 1);
 #define V3_CASE(ADVV)                                                                               \
     if (a.nu != 0.0) {                                                                                \
-      if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, true, false>, grd, blk, s, m->gd, a);     \
-      else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, true, false>, grd, blk, s, m->gd, a); \
-      else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, true, false>, grd, blk, s, m->gd, a);                \
-    } else if (bx == 256 && by == 3) ocn_launch_sync(k_tend_step3<ADVV, 256, 3, true, false, false, false>, grd, blk, s, m->gd, a);   \
-    else if (bx == 256 && early && fence) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, true, false, false>, grd, blk, s, m->gd, a); \
-    else if (bx == 256 && early) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, false, false>, grd, blk, s, m->gd, a); \
-    else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, false, true, false, false>, grd, blk, s, m->gd, a);        \
-    else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, false, false>, grd, blk, s, m->gd, a);        \
-    else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, false, false>, grd, blk, s, m->gd, a);
+      if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, true, false, false>, grd, blk, s, m->gd, a);     \
+      else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, true, false, false>, grd, blk, s, m->gd, a); \
+      else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, true, false, false>, grd, blk, s, m->gd, a);                \
+    } else if (bx == 256 && by == 3) ocn_launch_sync(k_tend_step3<ADVV, 256, 3, true, false, false, false, false>, grd, blk, s, m->gd, a);   \
+    else if (bx == 256 && early && fence) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, true, false, false, false>, grd, blk, s, m->gd, a); \
+    else if (bx == 256 && early) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, false, false, false>, grd, blk, s, m->gd, a); \
+    else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, false, true, false, false, false>, grd, blk, s, m->gd, a);        \
+    else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, false, false, false>, grd, blk, s, m->gd, a);        \
+    else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, false, false, false>, grd, blk, s, m->gd, a);
     switch (m->d.advection) {
       case ADV_WENO_Z: V3_CASE(ADV_WENO_Z) break;
       case ADV_WENO_JS: V3_CASE(ADV_WENO_JS) break;
@@ -974,10 +974,10 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
     nseg = ((nseg + 7) / 8) * 8;
     dim3 blk(bx, by, 1), grd(nseg, 1, 1);
 #define V3X_CASE(ADVV)                                                                     \
-    if (small && a.nu != 0.0) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, true, false>, grd, blk, s, m->gd, a);   \
-    else if (small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, false, false>, grd, blk, s, m->gd, a);            \
-    else if (a.nu != 0.0) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, true, false>, grd, blk, s, m->gd, a);     \
-    else ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, false, false>, grd, blk, s, m->gd, a);
+    if (small && a.nu != 0.0) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, true, false, false>, grd, blk, s, m->gd, a);   \
+    else if (small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, false, false, false>, grd, blk, s, m->gd, a);            \
+    else if (a.nu != 0.0) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, true, false, false>, grd, blk, s, m->gd, a);     \
+    else ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, false, false, false>, grd, blk, s, m->gd, a);
     switch (m->d.advection) {
       case ADV_WENO_Z: V3X_CASE(ADV_WENO_Z) break;
       case ADV_WENO_JS: V3X_CASE(ADV_WENO_JS) break;
@@ -999,7 +999,8 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
 // ---- Bounded z: advection + time-stepper update of u, v, w on top of the general kernels' other terms ----------------
 bool fused_bz_available(const ocn_model* m) {
   const ocn_grid* g = m->g;
-  if (g->topo[0] != OCN_PERIODIC || g->topo[1] != OCN_PERIODIC || g->topo[2] != OCN_BOUNDED) return false;
+  if (g->topo[0] != OCN_PERIODIC || g->topo[1] != OCN_PERIODIC) return false;
+  if (g->topo[2] == OCN_FLAT || (g->topo[2] == OCN_PERIODIC && (!g->z_regular || g->dist))) return false;
   int adv = m->d.advection;
   if (adv != ADV_WENO_Z && adv != ADV_WENO_JS && adv != ADV_U5) return false;
   for (int d = 0; d < 3; ++d)
@@ -1053,17 +1054,24 @@ void launch_fused_bz(ocn_model* m, double dt, double cn, double cm, int use_m) {
   nseg = ((nseg + 7) / 8) * 8;
   dim3 blk(bx, by, 1), grd(nseg, 1, 1);
   hipStream_t s = m->ctx->stream;
-#define BZ_CASE(ADVV)                                                                                          \
-  if (small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, false, true>, grd, blk, s, m->gd, a);                      \
-  else if (wide) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, false, true>, grd, blk, s, m->gd, a);                 \
-  else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, false, true>, grd, blk, s, m->gd, a);     \
-  else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, false, true>, grd, blk, s, m->gd, a); \
-  else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, false, true>, grd, blk, s, m->gd, a);
+#define BZ_CASE1(ADVV, ZBV)                                                                                    \
+  if (small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, false, ZBV, true>, grd, blk, s, m->gd, a);                 \
+  else if (wide) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, false, ZBV, true>, grd, blk, s, m->gd, a);            \
+  else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, false, ZBV, true>, grd, blk, s, m->gd, a);     \
+  else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, false, ZBV, true>, grd, blk, s, m->gd, a); \
+  else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, false, ZBV, true>, grd, blk, s, m->gd, a);
+#define BZ_CASE(ADVV)                       \
+  if (m->g->topo[2] == OCN_BOUNDED) {       \
+    BZ_CASE1(ADVV, true)                    \
+  } else {                                  \
+    BZ_CASE1(ADVV, false)                   \
+  }
   switch (m->d.advection) {
     case ADV_WENO_Z: BZ_CASE(ADV_WENO_Z) break;
     case ADV_WENO_JS: BZ_CASE(ADV_WENO_JS) break;
     default: BZ_CASE(ADV_U5) break;
   }
+#undef BZ_CASE1
 #undef BZ_CASE
 }
 

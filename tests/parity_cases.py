@@ -34,6 +34,12 @@ CASES = {
                               dt=2e-3, tracers=("c",), closure=(2e-2, 3e-2)),
     "ppp_weno_visc_rk3_noproj": dict(size=(10, 12, 8), topo=(P, P, P), extent=(1, 1, 1), adv="WENO5", stepper="RK3", steps=2,
                                      dt=2e-3, tracers=("a", "b2"), closure=(5e-2, 1e-2), project_init=False),
+    # triply periodic with terms the all-in-one fused path does not carry (AMD, Coriolis): the tiled kernel then adds
+    # advection on top of the general kernels' other terms, as on bounded-z grids
+    "ppp_weno_amd_coriolis": dict(size=(10, 8, 9), topo=(P, P, P), extent=(1, 1, 1), adv="WENO5", stepper="RK3", steps=2,
+                                  dt=2e-3, tracers=("c",), closure="amd", coriolis=2e-1),
+    "ppp_u5_coriolis_ab2": dict(size=(8, 10, 8), topo=(P, P, P), extent=(1, 1, 1), adv="U5", stepper="AB2", steps=3, dt=2e-3,
+                                coriolis=1e-1),
     # adaptive time stepping (TimeStepWizard): every change of dt is an Euler step with G^- zeroed
     # (quasi_adams_bashforth_2.jl:74-84), on the fused path (pointer-rotated G buffers) and on the general one
     "ppp_weno_ab2_varying_dt": dict(size=(12, 10, 8), topo=(P, P, P), extent=(1, 1, 1), adv="WENO5", stepper="AB2", steps=5,
