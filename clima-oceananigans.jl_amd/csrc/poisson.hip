@@ -38,7 +38,9 @@ struct PoissonSolver {
   void* tw = nullptr;                      // twiddle holder for the custom passes
   double* rhs = nullptr;      // real (Nx,Ny,Nz)
   double2_* spec = nullptr;   // complex (Nxh,Ny,Nz)
-  double* tscr = nullptr;     // Thomas scratch (Nxh*Ny, Nz)
+  double* tscr = nullptr;     // Thomas factors: t (ncol, Nz) then 1/beta (ncol, Nz), built once (k_tridiag_setup)
+  int* tri_kbr = nullptr;     // per column: level of the reference's early break (Nz: none)
+  bool tri_ready = false;
   double *lx = nullptr, *ly = nullptr, *lz = nullptr;  // eigenvalues on the device
   // kind 4 (a Bounded or Flat x / y direction), see run_walls
   bool tr = false;                 // solved on the x <-> y transposed array (x Bounded / Flat with y Periodic)
@@ -147,7 +149,8 @@ PoissonSolver* poisson_create(ocn_model* m) {
     return nullptr;
   }
   if (g->topo[2] == OCN_BOUNDED) {
-    if (hipMalloc((void**)&s->tscr, (size_t)s->Nxh * s->Ny * s->Nz * sizeof(double)) != hipSuccess) {
+    if (hipMalloc((void**)&s->tscr, 2 * (size_t)s->Nxh * s->Ny * s->Nz * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&s->tri_kbr, (size_t)s->Nxh * s->Ny * sizeof(int)) != hipSuccess) {
       poisson_destroy(s);
       return nullptr;
     }
@@ -279,6 +282,7 @@ void poisson_destroy(PoissonSolver* s) {
   hipFree(s->rhs);
   hipFree(s->spec);
   hipFree(s->tscr);
+  hipFree(s->tri_kbr);
   hipFree(s->lx);
   hipFree(s->ly);
   hipFree(s->lz);
@@ -419,9 +423,13 @@ __global__ void k_scale_spectrum(int Nxh, int Ny, int Nz, const double* __restri
 
 // Thomas algorithm down z for each (i,j) of the half spectrum (batched_tridiagonal_solver.jl:91-122) with
 // the diagonal of fourier_tridiagonal_poisson_solver.jl:16-28 computed on the fly; in place on `a`.
-__global__ void k_tridiag(GridDev g, int Nxh, int Ny, int Nz, const double* __restrict__ lx,
-                          const double* __restrict__ ly, double norm, double2_* __restrict__ a,
-                          double* __restrict__ t, int owns_mean) {
+// The elimination factors of the Thomas algorithm (batched_tridiagonal_solver.jl:91-122 with the diagonal of
+// fourier_tridiagonal_poisson_solver.jl:16-28) depend on the grid and the eigenvalues only -- not on the right-hand side.
+// They are computed ONCE per solver: t_k = c_{k-1} / beta_{k-1}, 1 / beta_k, and the level at which the reference's
+// early `break` (:113-114) stops a singular column.  A solve is then two sweeps whose dependent chain per level is one
+// fused multiply-add and one multiply instead of two divisions -- the sweeps are latency bound (only Nxh*Ny threads).
+__global__ void k_tridiag_setup(GridDev g, int Nxh, int Ny, int Nz, const double* __restrict__ lx, const double* __restrict__ ly,
+                                double* __restrict__ t, double* __restrict__ rb, int* __restrict__ kbr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= Nxh || j >= Ny) return;
@@ -432,40 +440,61 @@ __global__ void k_tridiag(GridDev g, int Nxh, int Ny, int Nz, const double* __re
     double lo = (k > 0) ? g_rdzf(g, k) : 0.0;
     return -(up + lo) - g_dzc(g, k) * lam;
   };
-  // Only Nxh*Ny threads exist (a few waves per CU) and every level depends on the one before, so the sweep is
-  // load-latency bound: right-hand sides are fetched PF levels ahead of the recurrence that consumes them.
-  // (Splitting real and imaginary parts over two threads was measured slower: the second copy of the
-  // elimination factors costs more traffic than the extra parallelism returns.)
-  constexpr int PF = 8;
   double beta = diag(0);
-  double2_ f = a[col];
-  double2_ prev = {f.x * norm / beta, f.y * norm / beta};
-  a[col] = prev;
+  rb[col] = 1.0 / beta;
+  t[col] = 0.0;
   int kbreak = Nz;
-  for (int k0 = 1; k0 < Nz && kbreak == Nz; k0 += PF) {
+  for (int k = 1; k < Nz; ++k) {
+    double off = g_rdzf(g, k);  // a^{k-1} = c^{k-1} = 1/dzf(k) (1-based face k+1 -> 0-based face k)
+    double tk = off / beta;
+    t[col + ncol * k] = tk;
+    beta = diag(k) - off * tk;
+    if (!(fabs(beta) > 10.0 * 2.220446049250313e-16)) {  // reference `break`
+      kbreak = k;
+      break;
+    }
+    rb[col + ncol * k] = 1.0 / beta;
+  }
+  for (int k = kbreak; k < Nz; ++k) rb[col + ncol * k] = 0.0;       // levels past the break stay at the stand-in value 0
+  for (int k = kbreak + 1; k < Nz; ++k) t[col + ncol * k] = 0.0;
+  kbr[col] = kbreak;
+}
+
+// Thomas sweeps down z for each (i,j) column of the spectrum with the precomputed factors; in place on `a`.
+__global__ void k_tridiag(GridDev g, int Nxh, int Ny, int Nz, double norm, double2_* __restrict__ a,
+                          const double* __restrict__ t, const double* __restrict__ rb, const int* __restrict__ kbr,
+                          int owns_mean) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= Nxh || j >= Ny) return;
+  const size_t ncol = (size_t)Nxh * Ny, col = i + (size_t)Nxh * j;
+  constexpr int PF = 8;               // loads run PF levels ahead of the recurrence that consumes them
+  const int kbreak = kbr[col];
+  double2_ f = a[col];
+  double r0 = rb[col];
+  double2_ prev = {f.x * norm * r0, f.y * norm * r0};
+  a[col] = prev;
+  for (int k0 = 1; k0 < Nz; k0 += PF) {
     double2_ fb[PF];
+    double rbb[PF];
 #pragma unroll
     for (int q = 0; q < PF; ++q)
-      if (k0 + q < Nz) fb[q] = a[col + ncol * (k0 + q)];
+      if (k0 + q < Nz) {
+        fb[q] = a[col + ncol * (k0 + q)];
+        rbb[q] = rb[col + ncol * (k0 + q)];
+      }
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
       const int k = k0 + q;
-      if (k >= Nz || kbreak != Nz) break;
-      double off = g_rdzf(g, k);  // a^{k-1} = c^{k-1} = 1/dzf(k) (1-based face k+1 -> 0-based face k)
-      double tk = off / beta;
-      t[col + ncol * k] = tk;
-      beta = diag(k) - off * tk;
-      if (!(fabs(beta) > 10.0 * 2.220446049250313e-16)) {  // reference `break` (:113-114)
-        kbreak = k;
-        break;
-      }
-      double2_ cur = {(fb[q].x * norm - off * prev.x) / beta, (fb[q].y * norm - off * prev.y) / beta};
+      if (k >= Nz) break;
+      const double off = g_rdzf(g, k);
+      // rb is 0 from the break level on: those levels hold the deterministic stand-in 0, like the stale storage they replace
+      double2_ cur = {(fb[q].x * norm - off * prev.x) * rbb[q], (fb[q].y * norm - off * prev.y) * rbb[q]};
       a[col + ncol * k] = cur;
       prev = cur;
     }
   }
-  for (int k = kbreak; k < Nz; ++k) a[col + ncol * k] = {0.0, 0.0};  // deterministic stand-in for the stale storage
-  for (int k = kbreak + 1; k < Nz; ++k) t[col + ncol * k] = 0.0;
+  (void)kbreak;
   double2_ nxt = a[col + ncol * (Nz - 1)];
   double sx = nxt.x, sy_ = nxt.y;
   for (int k0 = Nz - 2; k0 >= 0; k0 -= PF) {
@@ -500,6 +529,22 @@ __global__ void k_tridiag(GridDev g, int Nxh, int Ny, int Nz, const double* __re
       a[col + ncol * k] = cur;
     }
   }
+}
+
+// launch: factors are built on first use (the model's GridDev -- halo, spacings -- is final by then)
+static void tridiag_run(ocn_model* m, PoissonSolver* s, int Nc0, int Nc1, const double* l0, const double* l1, double norm,
+                        double2_* data, int owns_mean) {
+  hipStream_t st = m->ctx->stream;
+  const size_t nc = (size_t)Nc0 * Nc1 * s->Nz;
+  // one wave per workgroup: only Nc0*Nc1/64 waves exist, so they are spread over as many CUs as possible
+  static const int by = getenv("OCNHIP_TRI_BY") ? atoi(getenv("OCNHIP_TRI_BY")) : 1;
+  const dim3 b(64, by, 1), gr((Nc0 + 63) / 64, (Nc1 + by - 1) / by, 1);
+  if (!s->tri_ready) {
+    ocn_launch(k_tridiag_setup, gr, b, st, m->gd, Nc0, Nc1, s->Nz, l0, l1, s->tscr, s->tscr + nc, s->tri_kbr);
+    s->tri_ready = true;
+  }
+  ocn_launch(k_tridiag, gr, b, st, m->gd, Nc0, Nc1, s->Nz, norm, data, (const double*)s->tscr, (const double*)(s->tscr + nc),
+             (const int*)s->tri_kbr, owns_mean);
 }
 
 // ---- a Bounded or Flat x / y direction (kind 4) ----------------------------------------------------------------
@@ -606,7 +651,9 @@ static int walls_create(ocn_model* m, PoissonSolver* s) {
       hipMalloc((void**)&s->rb, nr * sizeof(double)) != hipSuccess || hipMalloc((void**)&s->ga, nc * sizeof(double2_)) != hipSuccess ||
       hipMalloc((void**)&s->gb, nc * sizeof(double2_)) != hipSuccess)
     return OCN_ENOMEM;
-  if (g->topo[2] == OCN_BOUNDED && hipMalloc((void**)&s->tscr, nc * sizeof(double)) != hipSuccess) return OCN_ENOMEM;
+  if (g->topo[2] == OCN_BOUNDED && (hipMalloc((void**)&s->tscr, 2 * nc * sizeof(double)) != hipSuccess ||
+                                    hipMalloc((void**)&s->tri_kbr, (size_t)s->gR * s->gNy * sizeof(int)) != hipSuccess))
+    return OCN_ENOMEM;
   for (int d = 0; d < 2; ++d) {
     const int N = d == 0 ? s->gNx : s->gNy;
     if (s->gtopo[d] != OCN_BOUNDED || N == 1) continue;
@@ -700,8 +747,7 @@ static int run_walls(ocn_model* m) {
     const dim3 b(64, 4, 1);
     const double norm = 1.0 / ((xper ? (double)Nx : 1.0) * (zper ? (double)Nz : 1.0));
     if (m->g->topo[2] == OCN_BOUNDED) {
-      ocn_launch(k_tridiag, dim3((R + 63) / 64, (Ny + 3) / 4, 1), b, st, m->gd, R, Ny, Nz, (const double*)s->lx,
-                 (const double*)s->ly, norm, cur, s->tscr, 1);
+      tridiag_run(m, s, R, Ny, s->lx, s->ly, norm, cur, 1);
     } else {
       if (zper) {
 #ifndef OCN_HOST_EMU
@@ -816,7 +862,8 @@ static int yslab_create(ocn_model* m, PoissonSolver* s) {
   const size_t nt = (size_t)s->Nyg * s->yw * s->Nz;
   if (hipMalloc((void**)&s->rhs, nr * sizeof(double)) != hipSuccess || hipMalloc((void**)&s->spec, nc * sizeof(double2_)) != hipSuccess ||
       hipMalloc((void**)&s->ysend, nt * sizeof(double2_)) != hipSuccess || hipMalloc((void**)&s->yrecv, nt * sizeof(double2_)) != hipSuccess ||
-      hipMalloc((void**)&s->yT, nt * sizeof(double2_)) != hipSuccess || hipMalloc((void**)&s->tscr, nt * sizeof(double)) != hipSuccess)
+      hipMalloc((void**)&s->yT, nt * sizeof(double2_)) != hipSuccess || hipMalloc((void**)&s->tscr, 2 * nt * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&s->tri_kbr, (size_t)s->Nyg * s->yw * sizeof(int)) != hipSuccess)
     return OCN_ENOMEM;
   std::vector<double> lxg = eigenvalues_periodic(s->Nx, g->L[0]), lxl(s->yw);
   for (int i = 0; i < s->yw; ++i) {
@@ -886,8 +933,7 @@ static int run_yslab(ocn_model* m) {
   {
     ProfScope ps(m->ctx, "spectral_solve");
     // columns are (ky, kx_local): ky runs fastest, so the roles of lx / ly in the kernel are swapped
-    ocn_launch(k_tridiag, dim3((Nyg + 63) / 64, (w + 3) / 4, 1), b, st, m->gd, Nyg, w, Nz, (const double*)s->ly, (const double*)s->lx,
-               1.0 / ((double)Nx * Nyg), s->yT, s->tscr, s->rank == 0 ? 1 : 0);
+    tridiag_run(m, s, Nyg, w, s->ly, s->lx, 1.0 / ((double)Nx * Nyg), s->yT, s->rank == 0 ? 1 : 0);
   }
   {
     ProfScope ps(m->ctx, "fft_backward");
@@ -982,8 +1028,7 @@ static int run_solver(ocn_model* m) {
     if (m->g->topo[2] == OCN_BOUNDED) {
       dim3 gr((s->Nxh + 63) / 64, (s->Ny + 3) / 4, 1);
       double norm = 1.0 / ((double)s->Nx * s->Ny);
-      ocn_launch(k_tridiag, gr, b, st, m->gd, s->Nxh, s->Ny, s->Nz, (const double*)s->lx, (const double*)s->ly, norm,
-                 s->spec, s->tscr, 1);
+      tridiag_run(m, s, s->Nxh, s->Ny, s->lx, s->ly, norm, s->spec, 1);
     } else {
       dim3 gr((s->Nxh + 63) / 64, (s->Ny + 3) / 4, s->Nz);
       double norm = 1.0 / ((double)s->Nx * s->Ny * (s->kind == 0 ? s->Nz : 1));
