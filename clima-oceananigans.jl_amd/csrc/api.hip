@@ -281,8 +281,10 @@ int ocn_grid_create(ocn_ctx* ctx, const ocn_grid_desc* desc, ocn_grid** out) {
   g->dist = want && zslab_ok;
   g->dist_y = want && !zslab_ok && yslab_ok;
   if (g->dist) {
-    if (g->N[2] % ctx->nranks != 0 || g->N[1] % ctx->nranks != 0) {
-      ocn_set_error(ctx, "Nz and Ny must be divisible by the number of ranks (%d)", ctx->nranks);
+    const char* dsolver = getenv("OCNHIP_DIST_SOLVER");
+    const bool transposed = dsolver && strcmp(dsolver, "transpose") == 0;   // the all-to-all variant also cuts ky into R bands
+    if (g->N[2] % ctx->nranks != 0 || (transposed && g->N[1] % ctx->nranks != 0)) {
+      ocn_set_error(ctx, "Nz%s must be divisible by the number of ranks (%d)", transposed ? " and Ny" : "", ctx->nranks);
       delete g;
       return OCN_EINVAL;
     }

@@ -201,3 +201,36 @@ def test_yslab_poisson_matches_oracle(ocn, backend):
         return m.poisson_solve(np.ascontiguousarray(src[:, r * nyl:(r + 1) * nyl]))
     phi = np.concatenate(run_ranks(ocn, R, rank_fn), axis=1)
     assert np.abs(phi - ref).max() < 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_slab_viscous_tracer_matches_single_domain_oracle(ocn, backend, R):
+    """z-slabs with ScalarDiffusivity on the fused path: the viscous face fluxes reach one level into the neighbour's slab
+    (div U below the first level, w one level up in the west / south column)."""
+    if backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    N = (8, 9, 6 * R)
+    rng = np.random.default_rng(15)
+    init = {n: rng.random(N) - 0.5 for n in "uvw"}
+    init["c"] = rng.random(N)
+    kw = dict(size=N, extent=(1, 1.1, 0.7 * R), topology=(P,) * 3)
+    om = O.NonhydrostaticModel(O.RectilinearGrid(**kw), advection=O.WENO5(), tracers=("c",), closure=O.ScalarDiffusivity(nu=3e-2, kappa=2e-2))
+    O.set_model(om, enforce_incompressibility=False, **init)      # non-solenoidal start: the grad-div term is alive
+    dt = 2e-3
+    for _ in range(3):
+        O.time_step(om, dt)
+    nz = N[2] // R
+
+    def rank_fn(ctx, r):
+        g = ocn.RectilinearGrid(ctx, **kw)
+        m = ocn.NonhydrostaticModel(g, advection=ocn.WENO5(), tracers=("c",), closure=ocn.ScalarDiffusivity(nu=3e-2, kappa=2e-2))
+        ocn.set_model(m, enforce_incompressibility=False, **{n: a[:, :, r * nz:(r + 1) * nz] for n, a in init.items()})
+        for _ in range(3):
+            ocn.time_step(m, dt)
+        return {n: f.interior() for n, f in (("u", m.u), ("v", m.v), ("w", m.w), ("p", m.pNHS), ("c", m.tracers["c"]))}
+    res = run_ranks(ocn, R, rank_fn)
+    refs = {"u": om.u.interior(), "v": om.v.interior(), "w": om.w.interior(), "p": om.pNHS.interior(), "c": om.tracers["c"].interior()}
+    for r, flds in enumerate(res):
+        for n, ref in refs.items():
+            err = np.abs(flds[n] - ref[:, :, r * nz:(r + 1) * nz]).max() / np.abs(ref).max()
+            assert err < 1e-11, (r, n, err)
