@@ -1,9 +1,11 @@
-// fused.hip -- MI355X fast path for the headline configuration: (Periodic, Periodic, Periodic-or-slab),
-// regular spacing, upwind-biased 5th-order advection (WENO5 Z / JS, U5), no closure / Coriolis / buoyancy.
+// fused.hip -- the tiled kernels of the time_step! hot path (upwind-biased 5th-order advection: WENO5 Z / JS, U5).
 //
-//   k_tend_step : calculate_G{u,v,w}! + ab2_step_field! / rk3_substep_field! in ONE pass.
+//   k_tend_step3 / k_tend_step3x : calculate_G{u,v,w}! + ab2_step_field! / rk3_substep_field! in ONE pass
 //                 (calculate_nonhydrostatic_tendencies.jl:155-170, quasi_adams_bashforth_2.jl:158-166,
-//                  runge_kutta_3.jl:204-218).  G^- <- G^n becomes a pointer swap (store_tendencies.jl).
+//                  runge_kutta_3.jl:204-218).  G^- <- G^n becomes a pointer rotation (store_tendencies.jl).
+//                 Template flags: VISC (ScalarDiffusivity as face fluxes), ZB (Bounded z), REST (G^n arrives holding
+//                 the non-advective terms computed by the general kernels).  3x: rows wider than a workgroup.
+//   k_tracer_step: calculate_Gc! + update for passive tracers (periodic path)
 //   k_rhs_wrap  : calculate_pressure_source_term_fft_based_solver! reading the predictor with periodic
 //                 wrap indexing (no halo fill of U* needed)           (solve_for_pressure.jl:15-18)
 //   k_project   : copy_real_component! + _pressure_correct_velocities! + the periodic halo fills of
@@ -11,17 +13,16 @@
 //                 interior value and its periodic images             (pressure_correction.jl:34-40,
 //                 fill_halo_regions_periodic.jl:37-65)
 //
-// Design of k_tend_step (why it looks the way it does):
-//   * the kernel is FP64-VALU bound, not HBM bound: one WENO reconstruction is ~75 DP operations and the
-//     reference evaluates 36 per cell.  Here every face flux is evaluated once (9 per cell + 1/BY ghost
-//     overhead) and only on the upwind side (bitwise equal to upwind_biased_product for finite input).
+// Design of the tendency kernel (why it looks the way it does):
+//   * it is FP64-VALU bound, not HBM bound: one WENO reconstruction is ~60 DP operations and the reference
+//     evaluates 36 per cell.  Here every face flux is evaluated once (9 per cell + ghost-row overhead) and only
+//     on the upwind side (bitwise equal to upwind_biased_product for finite input).
 //   * a workgroup owns complete x rows (x wrap stays inside the workgroup) of BY-1 output rows plus one
-//     "ghost" row of threads that only produces the y-fluxes of the next row; waves of the ghost row
-//     retire early so the SIMDs stay balanced.
-//   * each thread computes the fluxes through the WEST / SOUTH / BOTTOM faces of its three velocity
-//     cells.  EAST and NORTH fluxes come from the neighbouring threads through LDS (6 doubles per thread,
-//     double buffered, one barrier per level); TOP fluxes are the next level's BOTTOM fluxes, carried in
-//     registers while the workgroup marches up a z-chunk.  z-stencils live in a 6-deep register window.
+//     "ghost" row of threads that only produces the y-fluxes of the next row.
+//   * each thread computes the fluxes through the WEST / SOUTH / BOTTOM faces of its three velocity cells.
+//     EAST and NORTH fluxes come from the neighbouring threads through LDS; TOP fluxes are the next level's
+//     BOTTOM fluxes, carried while the workgroup marches up its share of levels; z stencils live in a 6-deep
+//     register window, x / y stencils in an LDS slab of the level.
 #include "internal.h"
 
 #define FUSED_MAX_THREADS 1024
@@ -34,7 +35,6 @@ struct FusedArgs {
   unsigned org;                   // byte offset of the first interior cell inside a parent array
   double dt, cn, cm;
   int use_m;
-  int KZ;                         // levels per z-chunk
   int BYo;                        // output rows per workgroup (= blockDim.y - 1)
   int ntiles;                     // y-tiles (v3: segment decomposition); x-tiled variant: ntx * nty
   int ntx, BXo;                   // x-tiled variant: tiles along x, output columns per tile
@@ -44,148 +44,9 @@ struct FusedArgs {
 
 OCN_DEVFN void sto(double* base, unsigned boff, double v) { *(double*)((char*)base + boff) = v; }
 
-template <int ADV, bool FENCE>
-__global__ void __launch_bounds__(FUSED_MAX_THREADS) k_tend_step(GridDev g, FusedArgs a) {
-  // 96 KB flux exchange (double buffered) + 48 KB per-thread carry = 144 KB of the CU's 160 KB
-  OCN_SHARED double lds[2][6][FUSED_MAX_THREADS];
-  OCN_SHARED double own[6][FUSED_MAX_THREADS];
-  const int tx = threadIdx.x, ty = threadIdx.y;
-  const int BX = blockDim.x;
-  const int tid = ty * BX + tx;
-  const int i = tx;
-  // XCD-aware mapping: workgroups b and b+8 share an XCD (round-robin dispatch), so hand every XCD a
-  // contiguous band of y-tiles of one z-chunk: neighbouring tiles then hit the same L2 for their halo rows.
-  // gridDim.x is padded to a multiple of 8; tiles past the domain fail the row tests below.
-  const int per = gridDim.x / 8;
-  const int ytile = (blockIdx.x % 8) * per + blockIdx.x / 8;
-  const int j = ytile * a.BYo + ty;
-  const bool ghost = (ty == a.BYo);
-  const bool col_ok = i < g.Nx;
-  const bool row_ok = j < g.Ny;            // output row inside the domain
-  const bool do_y = col_ok && j <= g.Ny;   // south fluxes are needed up to row Ny (the north face of row Ny-1)
-  const bool full = col_ok && row_ok && !ghost;
-  const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
-  const int k0 = blockIdx.y * a.KZ;
-  const int k1 = (k0 + a.KZ < g.Nz) ? k0 + a.KZ : g.Nz;   // outputs for levels k0 .. k1-1
-  const double rdx = g.rdx, rdy = g.rdy, rdz = 1.0 / g.dz;
-  const unsigned cxy = a.org + (unsigned)(col_ok ? i : 0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
-
-  // right neighbour in x with periodic wrap inside the workgroup; upper neighbour in y
-  const int txe = (tx + 1 == g.Nx) ? 0 : tx + 1;
-  const int nid_e = ty * BX + (txe < BX ? txe : tx);
-  const int nid_n = (ty + 1 < (int)blockDim.y ? ty + 1 : ty) * BX + tx;
-
-  // z windows: values at levels k-3 .. k+2
-  double zu[6], zv[6], zw[6];
-  {
-    const unsigned c = cxy + (unsigned)k0 * szb;
-    for (int q = 0; q < 6; ++q) {
-      zu[q] = ldo(a.u, c + (unsigned)(q - 3) * szb);
-      zv[q] = ldo(a.v, c + (unsigned)(q - 3) * szb);
-      zw[q] = ldo(a.w, c + (unsigned)(q - 3) * szb);
-    }
-  }
-  for (int k = k0; k <= k1; ++k) {
-    const unsigned c = cxy + (unsigned)k * szb;
-    const int buf = (k - k0) & 1;
-    const bool last = (k == k1);           // only bottom fluxes are needed at the level above the chunk
-    // 4th-order interpolation from the z window: midway between levels k-1 and k
-    auto symz = [&](const double* z) { return sym4_v(z[1], z[2], z[3], z[4]); };
-    auto reconz = [&](const double* z, double ut) {
-      bool pos = ut > 0.0;
-      return recon5<ADV>(pos ? z[0] : z[5], pos ? z[1] : z[4], pos ? z[2] : z[3], pos ? z[3] : z[2],
-                         pos ? z[4] : z[1], pos);
-    };
-    if (!last) {
-      if (full) {
-        // ---- fluxes through the WEST faces of the u, v, w cells ----
-        double utu = sym4_o(a.u, c - sxb, sxb);       // centre i-1: between u[i-1], u[i]
-        lds[buf][0][tid] = utu * recon_o<ADV>(a.u, c, sxb, utu);
-        if (FENCE) OCN_SCHED_FENCE();
-        double utv = sym4_o(a.u, c - syb, syb);       // u interpolated in y to the v row (x-face i)
-        lds[buf][1][tid] = utv * recon_o<ADV>(a.v, c, sxb, utv);
-        if (FENCE) OCN_SCHED_FENCE();
-        double utw = symz(zu);                        // u interpolated in z to the w level
-        lds[buf][2][tid] = utw * recon_o<ADV>(a.w, c, sxb, utw);
-        if (FENCE) OCN_SCHED_FENCE();
-      }
-      if (do_y) {
-        // ---- fluxes through the SOUTH faces (also on the ghost row) ----
-        double vtu = sym4_o(a.v, c - sxb, sxb);       // v interpolated in x to the u column (y-face j)
-        lds[buf][3][tid] = vtu * recon_o<ADV>(a.u, c, syb, vtu);
-        if (FENCE) OCN_SCHED_FENCE();
-        double vtv = sym4_o(a.v, c - syb, syb);       // centre j-1
-        lds[buf][4][tid] = vtv * recon_o<ADV>(a.v, c, syb, vtv);
-        if (FENCE) OCN_SCHED_FENCE();
-        double vtw = symz(zv);
-        lds[buf][5][tid] = vtw * recon_o<ADV>(a.w, c, syb, vtw);
-        if (FENCE) OCN_SCHED_FENCE();
-      }
-    }
-    double Fwu = 0, Fwv = 0, Fww = 0;
-    if (full) {
-      // ---- fluxes through the BOTTOM faces at level k ----
-      double wtu = sym4_o(a.w, c - sxb, sxb);         // w interpolated in x to the u column (between i-1, i)
-      Fwu = wtu * reconz(zu, wtu);
-      if (FENCE) OCN_SCHED_FENCE();
-      double wtv = sym4_o(a.w, c - syb, syb);         // w interpolated in y to the v row
-      Fwv = wtv * reconz(zv, wtv);
-      if (FENCE) OCN_SCHED_FENCE();
-      double wtw = symz(zw);
-      Fww = wtw * reconz(zw, wtw);
-    }
-    __syncthreads();
-    if (full) {
-      if (k > k0) {
-        // finalize level k-1: G = -(horizontal + (top - bottom)/dz), then the time-stepper update
-        const unsigned cm1 = c - szb;
-        double Gu = -(own[0][tid] + (Fwu - own[3][tid]) * rdz);
-        double Gv = -(own[1][tid] + (Fwv - own[4][tid]) * rdz);
-        double Gw = -(own[2][tid] + (Fww - own[5][tid]) * rdz);
-        sto(a.gnu, cm1, Gu);
-        sto(a.gnv, cm1, Gv);
-        sto(a.gnw, cm1, Gw);
-        double iu, iv, iw;
-        if (a.use_m) {
-          iu = a.dt * (a.cn * Gu + a.cm * ldo(a.gmu, cm1));
-          iv = a.dt * (a.cn * Gv + a.cm * ldo(a.gmv, cm1));
-          iw = a.dt * (a.cn * Gw + a.cm * ldo(a.gmw, cm1));
-        } else {
-          iu = a.dt * a.cn * Gu;
-          iv = a.dt * a.cn * Gv;
-          iw = a.dt * a.cn * Gw;
-        }
-        sto(a.us, cm1, zu[2] + iu);
-        sto(a.vs, cm1, zv[2] + iv);
-        sto(a.ws, cm1, zw[2] + iw);
-      }
-      if (!last) {
-        own[0][tid] = (lds[buf][0][nid_e] - lds[buf][0][tid]) * rdx + (lds[buf][3][nid_n] - lds[buf][3][tid]) * rdy;
-        own[1][tid] = (lds[buf][1][nid_e] - lds[buf][1][tid]) * rdx + (lds[buf][4][nid_n] - lds[buf][4][tid]) * rdy;
-        own[2][tid] = (lds[buf][2][nid_e] - lds[buf][2][tid]) * rdx + (lds[buf][5][nid_n] - lds[buf][5][tid]) * rdy;
-        own[3][tid] = Fwu;
-        own[4][tid] = Fwv;
-        own[5][tid] = Fww;
-      }
-    }
-    if (!last) {
-      // advance the z windows to level k+1
-      for (int q = 0; q < 5; ++q) {
-        zu[q] = zu[q + 1];
-        zv[q] = zv[q + 1];
-        zw[q] = zw[q + 1];
-      }
-      zu[5] = ldo(a.u, c + 3 * szb);
-      zv[5] = ldo(a.v, c + 3 * szb);
-      zw[5] = ldo(a.w, c + 3 * szb);
-    }
-  }
-}
-
-// ---- v3: the same algorithm with the level's x/y neighbourhood staged through LDS -------------------------
-// k_tend_step issues ~50 vector-memory instructions per thread and level and all 16 waves of the workgroup
-// stall on them together (measured: VALU busy 50 %, 59 % of wave time in s_waitcnt/barrier).  Here the
-// workgroup loads the level's slab -- (BY+5) rows x (Nx+6) columns of u, v, w -- once (9 loads per thread,
+// ---- the level's x/y neighbourhood is staged through LDS --------------------------------------------------------
+// (A first version read every stencil from global memory: ~50 vector-memory instructions per thread and level, all
+// 16 waves stalling on them together -- VALU busy 50 %.)  The workgroup loads the level's slab -- (BY+5) rows x (Nx+6) columns of u, v, w -- once (9 loads per thread,
 // issued one level ahead), and every x / y stencil is read from LDS with compile-time offsets from ONE
 // base address (workgroup shape is a template parameter, so row / field strides are immediates).
 //   LDS: slab 3*(BY+5)*(BX+6) + flux exchange 6*T + carry 6*T doubles  (BX = 256, BY = 4: 151.3 KB of 160)
@@ -865,134 +726,91 @@ bool fused_available(const ocn_model* m) {
   return true;
 }
 
-void fused_geometry(const ocn_model* m, dim3& block, dim3& grid, int& KZ, int& BYo) {
-  const GridDev& g = m->gd;
-  int BX = ((g.Nx + 63) / 64) * 64;
-  int BY = FUSED_MAX_THREADS / BX;
-  if (BY > 8) BY = 8;
-  if (BY > g.Ny + 1) BY = g.Ny + 1;
-  if (BY < 2) BY = 2;
-  BYo = BY - 1;
-  const char* e = getenv("OCNHIP_FUSED_KZ");
-  KZ = e ? atoi(e) : 32;
-  if (KZ < 1) KZ = 1;
-  if (KZ > g.Nz) KZ = g.Nz;
-  block = dim3(BX, BY, 1);
-  int nty = (g.Ny + BYo - 1) / BYo;
-  nty = ((nty + 7) / 8) * 8;               // padded so that the XCD-aware remap covers every tile
-  grid = dim3(nty, (g.Nz + KZ - 1) / KZ, 1);
+static int fused_cu_count(const ocn_model* m) {
+  static int ncu = 0;
+  if (!ncu) {
+#ifndef OCN_HOST_EMU
+    hipDeviceProp_t prop;
+    ncu = (hipGetDeviceProperties(&prop, m->ctx->device) == hipSuccess) ? prop.multiProcessorCount : 256;
+#else
+    ncu = 8;
+#endif
+  }
+  return ncu;
 }
 
-void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m) {
-  ProfScope ps(m->ctx, "fused_tendency_step");
-  FusedArgs a;
+// Workgroup shape and work decomposition shared by all variants: complete rows up to 256 columns (64 x 8, 128 x 8,
+// 256 x 4 threads), x-tiles of 192 x 5 threads beyond that; one equal segment of the (tile, level) space per CU.
+struct FusedShape {
+  int bx, by;
+  bool wide, small;
+  dim3 blk, grd;
+};
+static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
+  const GridDev& gd = m->gd;
+  FusedShape f;
+  const int xt_env = getenv("OCNHIP_FUSED_XT") ? atoi(getenv("OCNHIP_FUSED_XT")) : 0;   // 1: force the x-tiled kernel (tests)
+  f.small = xt_env == 1 && gd.Nx <= 57 * 4;       // test shape: 64 x 4 threads, up to 57 output columns, >= 2 tiles
+  f.wide = gd.Nx > 256 || f.small;
+  f.bx = f.small ? 64 : f.wide ? 192 : gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
+  f.by = f.small ? 4 : f.wide ? 5 : f.bx == 256 ? 4 : 8;
+  a.BYo = f.by - 1;
+  a.ntiles = (gd.Ny + f.by - 2) / (f.by - 1);
+  a.ntx = 1;
+  a.BXo = 0;
+  if (f.wide) {
+    const int cap = f.bx - 7;                     // the slab of a tile is loaded by one thread per column: outputs + 7
+    a.ntx = (gd.Nx + cap - 1) / cap;
+    if (f.small && a.ntx < 2) a.ntx = 2;
+    a.BXo = (gd.Nx + a.ntx - 1) / a.ntx;
+    a.ntiles *= a.ntx;
+  }
+  int nseg = fused_cu_count(m);                   // one workgroup is resident per CU
+  const long total = (long)a.ntiles * gd.Nz;
+  if (nseg > total / 4) nseg = (int)(total / 4 > 8 ? total / 4 : 8);
+  nseg = ((nseg + 7) / 8) * 8;                    // XCD-aware remap inside the kernel wants a multiple of 8
+  f.blk = dim3(f.bx, f.by, 1);
+  f.grd = dim3(nseg, 1, 1);
+  return f;
+}
+
+// launch one of the instantiations: VISCV / ZBV / RESTV are compile-time constants at the call site
+#define FUSED_LAUNCH(ADVV, VISCV, ZBV, RESTV)                                                                              \
+  if (f.small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);                  \
+  else if (f.wide) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);             \
+  else if (f.bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); \
+  else if (f.bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); \
+  else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);
+#define FUSED_BY_SCHEME(VISCV, ZBV, RESTV)                            \
+  switch (m->d.advection) {                                           \
+    case ADV_WENO_Z: { FUSED_LAUNCH(ADV_WENO_Z, VISCV, ZBV, RESTV) } break;   \
+    case ADV_WENO_JS: { FUSED_LAUNCH(ADV_WENO_JS, VISCV, ZBV, RESTV) } break; \
+    default: { FUSED_LAUNCH(ADV_U5, VISCV, ZBV, RESTV) } break;               \
+  }
+
+static void fused_fill_args(ocn_model* m, FusedArgs& a, double dt, double cn, double cm, int use_m) {
   a.u = m->u.d; a.v = m->v.d; a.w = m->w.d;
   a.gmu = m->Gm[0].d; a.gmv = m->Gm[1].d; a.gmw = m->Gm[2].d;
   a.gnu = m->Gn[0].d; a.gnv = m->Gn[1].d; a.gnw = m->Gn[2].d;
   a.us = m->us.d; a.vs = m->vs.d; a.ws = m->ws.d;
   a.org = (unsigned)((m->u.Hx + m->u.Hy * m->u.sy + m->u.Hz * m->u.sz) * sizeof(double));
   a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
-  a.dbg_nobar = 0;
+  a.dbg_nobar = getenv("OCNHIP_DBG_NOBAR") ? atoi(getenv("OCNHIP_DBG_NOBAR")) : 0;
+  a.nu = 0.0;
+}
+
+// all-in-one path: triply periodic, no closure or ScalarDiffusivity
+void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m) {
+  ProfScope ps(m->ctx, "fused_tendency_step");
+  FusedArgs a;
+  fused_fill_args(m, a, dt, cn, cm, use_m);
   a.nu = m->d.closure == OCN_CLOSURE_SCALAR ? m->d.nu : 0.0;
-  dim3 block, grid;
-  fused_geometry(m, block, grid, a.KZ, a.BYo);
+  const FusedShape f = fused_shape(m, a);
   hipStream_t s = m->ctx->stream;
-  static const bool fence = getenv("OCNHIP_FENCE") && atoi(getenv("OCNHIP_FENCE")) != 0;
-  static const int variant = getenv("OCNHIP_FUSED_VARIANT") ? atoi(getenv("OCNHIP_FUSED_VARIANT")) : 3;
-  const int xt_env0 = getenv("OCNHIP_FUSED_XT") ? atoi(getenv("OCNHIP_FUSED_XT")) : 0;   // read per launch: tests toggle it
-  if ((variant == 3 || a.nu != 0.0) && m->gd.Nx <= 256 && xt_env0 != 1) {
-    // v3 is compiled for three workgroup shapes (complete x rows of up to 64 / 128 / 256 cells)
-    const GridDev& gd = m->gd;
-    int bx = gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
-    int by = bx == 256 ? 4 : 8;
-    static const int by_env = getenv("OCNHIP_FUSED_BY") ? atoi(getenv("OCNHIP_FUSED_BY")) : 0;
-    if (bx == 256 && by_env == 3) by = 3;
-    static const bool early = !(getenv("OCNHIP_FUSED_EARLY") && atoi(getenv("OCNHIP_FUSED_EARLY")) == 0);
-    a.BYo = by - 1;
-    a.ntiles = (gd.Ny + by - 2) / (by - 1);
-    static const int nobar = getenv("OCNHIP_DBG_NOBAR") ? atoi(getenv("OCNHIP_DBG_NOBAR")) : 0;
-    a.dbg_nobar = nobar;
-    static const int segs_env = getenv("OCNHIP_FUSED_SEGS") ? atoi(getenv("OCNHIP_FUSED_SEGS")) : 0;
-    static int ncu = 0;
-    if (!ncu) {
-#ifndef OCN_HOST_EMU
-      hipDeviceProp_t prop;
-      ncu = (hipGetDeviceProperties(&prop, m->ctx->device) == hipSuccess) ? prop.multiProcessorCount : 256;
-#else
-      ncu = 8;
-#endif
-    }
-    int nseg = segs_env > 0 ? segs_env : ncu;           // one equal march per CU (one workgroup is resident per CU)
-    long total = (long)a.ntiles * gd.Nz;
-    if (nseg > total / 4) nseg = (int)(total / 4 > 8 ? total / 4 : 8);
-    nseg = ((nseg + 7) / 8) * 8;
-    dim3 blk(bx, by, 1), grd(nseg, 1, 1);
-#define V3_CASE(ADVV)                                                                               \
-    if (a.nu != 0.0) {                                                                                \
-      if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, true, false, false>, grd, blk, s, m->gd, a);     \
-      else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, true, false, false>, grd, blk, s, m->gd, a); \
-      else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, true, false, false>, grd, blk, s, m->gd, a);                \
-    } else if (bx == 256 && by == 3) ocn_launch_sync(k_tend_step3<ADVV, 256, 3, true, false, false, false, false>, grd, blk, s, m->gd, a);   \
-    else if (bx == 256 && early && fence) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, true, false, false, false>, grd, blk, s, m->gd, a); \
-    else if (bx == 256 && early) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, false, false, false>, grd, blk, s, m->gd, a); \
-    else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, false, true, false, false, false>, grd, blk, s, m->gd, a);        \
-    else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, false, false, false>, grd, blk, s, m->gd, a);        \
-    else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, false, false, false>, grd, blk, s, m->gd, a);
-    switch (m->d.advection) {
-      case ADV_WENO_Z: V3_CASE(ADV_WENO_Z) break;
-      case ADV_WENO_JS: V3_CASE(ADV_WENO_JS) break;
-      default: V3_CASE(ADV_U5) break;
-    }
-#undef V3_CASE
-    return;
-  }
-  const int xt_env = xt_env0;   // 1: force the x-tiled kernel (tests)
-  if (variant == 3 || m->gd.Nx > FUSED_MAX_THREADS / 2 || a.nu != 0.0) {   // (v2 has no viscous terms)
-    // rows wider than a workgroup: x-tiled kernel, 192 x 5 threads (up to 185 output columns x 4 output rows per tile)
-    const GridDev& gd = m->gd;
-    const bool small = xt_env == 1 && gd.Nx <= 57 * 4;          // test shape: 64 x 4 threads, up to 57 output columns
-    const int bx = small ? 64 : 192, by = small ? 4 : 5;
-    const int cap = bx - 7;
-    a.ntx = (gd.Nx + cap - 1) / cap;
-    if (small && a.ntx < 2) a.ntx = 2;                           // make the test exercise an interior tile boundary
-    a.BXo = (gd.Nx + a.ntx - 1) / a.ntx;
-    a.BYo = by - 1;
-    const int nty = (gd.Ny + by - 2) / (by - 1);
-    a.ntiles = a.ntx * nty;
-    static int ncu2 = 0;
-    if (!ncu2) {
-#ifndef OCN_HOST_EMU
-      hipDeviceProp_t prop;
-      ncu2 = (hipGetDeviceProperties(&prop, m->ctx->device) == hipSuccess) ? prop.multiProcessorCount : 256;
-#else
-      ncu2 = 8;
-#endif
-    }
-    int nseg = ncu2;
-    long total = (long)a.ntiles * gd.Nz;
-    if (nseg > total / 4) nseg = (int)(total / 4 > 8 ? total / 4 : 8);
-    nseg = ((nseg + 7) / 8) * 8;
-    dim3 blk(bx, by, 1), grd(nseg, 1, 1);
-#define V3X_CASE(ADVV)                                                                     \
-    if (small && a.nu != 0.0) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, true, false, false>, grd, blk, s, m->gd, a);   \
-    else if (small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, false, false, false>, grd, blk, s, m->gd, a);            \
-    else if (a.nu != 0.0) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, true, false, false>, grd, blk, s, m->gd, a);     \
-    else ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, false, false, false>, grd, blk, s, m->gd, a);
-    switch (m->d.advection) {
-      case ADV_WENO_Z: V3X_CASE(ADV_WENO_Z) break;
-      case ADV_WENO_JS: V3X_CASE(ADV_WENO_JS) break;
-      default: V3X_CASE(ADV_U5) break;
-    }
-#undef V3X_CASE
-    return;
-  }
-  switch (m->d.advection) {
-    case ADV_WENO_Z:
-      if (fence) ocn_launch_sync(k_tend_step<ADV_WENO_Z, true>, grid, block, s, m->gd, a);
-      else ocn_launch_sync(k_tend_step<ADV_WENO_Z, false>, grid, block, s, m->gd, a);
-      break;
-    case ADV_WENO_JS: ocn_launch_sync(k_tend_step<ADV_WENO_JS, false>, grid, block, s, m->gd, a); break;
-    default: ocn_launch_sync(k_tend_step<ADV_U5, false>, grid, block, s, m->gd, a); break;
+  if (a.nu != 0.0) {
+    FUSED_BY_SCHEME(true, false, false)
+  } else {
+    FUSED_BY_SCHEME(false, false, false)
   }
 }
 
@@ -1015,65 +833,17 @@ bool fused_bz_available(const ocn_model* m) {
 void launch_fused_bz(ocn_model* m, double dt, double cn, double cm, int use_m) {
   ProfScope ps(m->ctx, "fused_tendency_step");
   FusedArgs a;
-  a.u = m->u.d; a.v = m->v.d; a.w = m->w.d;
-  a.gmu = m->Gm[0].d; a.gmv = m->Gm[1].d; a.gmw = m->Gm[2].d;
-  a.gnu = m->Gn[0].d; a.gnv = m->Gn[1].d; a.gnw = m->Gn[2].d;
-  a.us = m->us.d; a.vs = m->vs.d; a.ws = m->ws.d;
-  a.org = (unsigned)((m->u.Hx + m->u.Hy * m->u.sy + m->u.Hz * m->u.sz) * sizeof(double));
-  a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
-  a.dbg_nobar = 0;
-  a.nu = 0.0;
-  a.KZ = 0; a.ntx = 1; a.BXo = 0;
-  const GridDev& gd = m->gd;
-  const int xt_env = getenv("OCNHIP_FUSED_XT") ? atoi(getenv("OCNHIP_FUSED_XT")) : 0;     // 1: force the x-tiled kernel (tests)
-  const bool small = xt_env == 1 && gd.Nx <= 57 * 4;
-  const bool wide = gd.Nx > 256 || small;
-  const int bx = small ? 64 : wide ? 192 : gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
-  const int by = small ? 4 : wide ? 5 : bx == 256 ? 4 : 8;
-  a.BYo = by - 1;
-  a.ntiles = (gd.Ny + by - 2) / (by - 1);
-  if (wide) {
-    const int cap = bx - 7;
-    a.ntx = (gd.Nx + cap - 1) / cap;
-    if (small && a.ntx < 2) a.ntx = 2;
-    a.BXo = (gd.Nx + a.ntx - 1) / a.ntx;
-    a.ntiles *= a.ntx;
-  }
-  static int ncu = 0;
-  if (!ncu) {
-#ifndef OCN_HOST_EMU
-    hipDeviceProp_t prop;
-    ncu = (hipGetDeviceProperties(&prop, m->ctx->device) == hipSuccess) ? prop.multiProcessorCount : 256;
-#else
-    ncu = 8;
-#endif
-  }
-  int nseg = ncu;
-  long total = (long)a.ntiles * gd.Nz;
-  if (nseg > total / 4) nseg = (int)(total / 4 > 8 ? total / 4 : 8);
-  nseg = ((nseg + 7) / 8) * 8;
-  dim3 blk(bx, by, 1), grd(nseg, 1, 1);
+  fused_fill_args(m, a, dt, cn, cm, use_m);
+  const FusedShape f = fused_shape(m, a);
   hipStream_t s = m->ctx->stream;
-#define BZ_CASE1(ADVV, ZBV)                                                                                    \
-  if (small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, false, ZBV, true>, grd, blk, s, m->gd, a);                 \
-  else if (wide) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, false, ZBV, true>, grd, blk, s, m->gd, a);            \
-  else if (bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, false, ZBV, true>, grd, blk, s, m->gd, a);     \
-  else if (bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, false, ZBV, true>, grd, blk, s, m->gd, a); \
-  else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, false, ZBV, true>, grd, blk, s, m->gd, a);
-#define BZ_CASE(ADVV)                       \
-  if (m->g->topo[2] == OCN_BOUNDED) {       \
-    BZ_CASE1(ADVV, true)                    \
-  } else {                                  \
-    BZ_CASE1(ADVV, false)                   \
+  if (m->g->topo[2] == OCN_BOUNDED) {
+    FUSED_BY_SCHEME(false, true, true)
+  } else {
+    FUSED_BY_SCHEME(false, false, true)
   }
-  switch (m->d.advection) {
-    case ADV_WENO_Z: BZ_CASE(ADV_WENO_Z) break;
-    case ADV_WENO_JS: BZ_CASE(ADV_WENO_JS) break;
-    default: BZ_CASE(ADV_U5) break;
-  }
-#undef BZ_CASE1
-#undef BZ_CASE
 }
+#undef FUSED_BY_SCHEME
+#undef FUSED_LAUNCH
 
 void launch_rhs_wrap(ocn_model* m, double dt, double* rhs) {
   ProfScope ps(m->ctx, "rhs");
