@@ -200,14 +200,26 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
       bool pos = ut > 0.0;                                            // face between m1 and c0
       return recon5<ADV>(pos ? m3 : c2, pos ? m2 : c1, pos ? m1 : c0, pos ? c0 : m1, pos ? c1 : m2, pos);
     };
-#define XSYM(f) sym_v(SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4))
-#define YSYM(f) sym_v(SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3))
-#define XREC(f, ut) rec_v(SLB(f, 3, 0), SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4), SLB(f, 3, 5), ut)
-#define YREC(f, ut) rec_v(SLB(f, 0, 3), SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3), SLB(f, 5, 3), ut)
+    // Walls in x / y (REST variants only; g.xb / g.yb are runtime flags): inside the boundary buffer every stencil falls
+    // back to 2nd order, exactly as adv_flux_b / sym_b of the general kernels (idx: 1-based index along the stencil).
+    auto in_sym = [&](int idx, int N) { return idx > nbz && idx < N + 1 - nbz; };
+    auto in_rec = [&](bool pos, int idx, int N) {
+      return pos ? (idx > nbz && idx < N + 1 - (nbz - 1)) : (idx > nbz - 1 && idx < N + 1 - nbz);
+    };
+    const bool wx = REST && g.xb != 0, wy = REST && g.yb != 0;
+    const int ix = i + 1, jy = j + 1;                 // 1-based face indices of this thread's u / v cells
+#define XSYM(f, idx) ((wx && !in_sym(idx, g.Nx)) ? 0.5 * (SLB(f, 3, 2) + SLB(f, 3, 3)) \
+                                               : sym_v(SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4)))
+#define YSYM(f, idx) ((wy && !in_sym(idx, g.Ny)) ? 0.5 * (SLB(f, 2, 3) + SLB(f, 3, 3)) \
+                                               : sym_v(SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3)))
+#define XREC(f, ut, idx) ((wx && !in_rec((ut) > 0.0, idx, g.Nx)) ? 0.5 * (SLB(f, 3, 2) + SLB(f, 3, 3)) \
+                              : rec_v(SLB(f, 3, 0), SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4), SLB(f, 3, 5), ut))
+#define YREC(f, ut, idx) ((wy && !in_rec((ut) > 0.0, idx, g.Ny)) ? 0.5 * (SLB(f, 2, 3) + SLB(f, 3, 3)) \
+                              : rec_v(SLB(f, 0, 3), SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3), SLB(f, 5, 3), ut))
     if (!last) {
       if (full) {
-        double utu = XSYM(0);                          // centre i-1
-        double f0 = utu * XREC(0, utu);
+        double utu = XSYM(0, ix - 1);                  // centre i-1
+        double f0 = utu * XREC(0, utu, ix - 1);
         if (visc) {
           const double dux = (SLB(0, 3, 3) - SLB(0, 3, 2)) * rdx;
           const double divw = dux + (SLB(1, 4, 2) - SLB(1, 3, 2)) * rdy + (wxm - SLB(2, 3, 2)) * rdz;   // div U at (i-1, j, k)
@@ -215,19 +227,19 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
         }
         fx[0 * T + tid] = f0;
         if (FENCE3) OCN_SCHED_FENCE();
-        double utv = YSYM(0);                          // u interpolated in y to the v row
-        fx[1 * T + tid] = utv * XREC(1, utv) - (visc ? a.nu * (SLB(1, 3, 3) - SLB(1, 3, 2)) * rdx : 0.0);
+        double utv = YSYM(0, jy);                      // u interpolated in y to the v row
+        fx[1 * T + tid] = utv * XREC(1, utv, ix) - (visc ? a.nu * (SLB(1, 3, 3) - SLB(1, 3, 2)) * rdx : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
         double utw = symz(zu);                         // u interpolated in z to the w level
-        fx[2 * T + tid] = utw * XREC(2, utw) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 3, 2)) * rdx : 0.0);
+        fx[2 * T + tid] = utw * XREC(2, utw, ix) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 3, 2)) * rdx : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
       }
       if (do_y) {
-        double vtu = XSYM(1);                          // v interpolated in x to the u column
-        fx[3 * T + tid] = vtu * YREC(0, vtu) - (visc ? a.nu * (SLB(0, 3, 3) - SLB(0, 2, 3)) * rdy : 0.0);
+        double vtu = XSYM(1, ix);                      // v interpolated in x to the u column
+        fx[3 * T + tid] = vtu * YREC(0, vtu, jy) - (visc ? a.nu * (SLB(0, 3, 3) - SLB(0, 2, 3)) * rdy : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
-        double vtv = YSYM(1);                          // centre j-1
-        double f4 = vtv * YREC(1, vtv);
+        double vtv = YSYM(1, jy - 1);                  // centre j-1
+        double f4 = vtv * YREC(1, vtv, jy - 1);
         if (visc) {
           const double dvy = (SLB(1, 3, 3) - SLB(1, 2, 3)) * rdy;
           const double divs = (SLB(0, 2, 4) - SLB(0, 2, 3)) * rdx + dvy + (wym - SLB(2, 2, 3)) * rdz;   // div U at (i, j-1, k)
@@ -236,16 +248,16 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
         fx[4 * T + tid] = f4;
         if (FENCE3) OCN_SCHED_FENCE();
         double vtw = symz(zv);
-        fx[5 * T + tid] = vtw * YREC(2, vtw) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 2, 3)) * rdy : 0.0);
+        fx[5 * T + tid] = vtw * YREC(2, vtw, jy) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 2, 3)) * rdy : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
       }
     }
     double Fwu = 0, Fwv = 0, Fww = 0;
     if (full) {
-      double wtu = XSYM(2);
+      double wtu = XSYM(2, ix);
       Fwu = wtu * reconz(zu, wtu);
       if (FENCE3) OCN_SCHED_FENCE();
-      double wtv = YSYM(2);
+      double wtv = YSYM(2, jy);
       Fwv = wtv * reconz(zv, wtv);
       if (FENCE3) OCN_SCHED_FENCE();
       double wtw = symz_at(zw, k);                    // centre below face k
@@ -463,14 +475,26 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
       bool pos = ut > 0.0;                                            // face between m1 and c0
       return recon5<ADV>(pos ? m3 : c2, pos ? m2 : c1, pos ? m1 : c0, pos ? c0 : m1, pos ? c1 : m2, pos);
     };
-#define XSYM(f) sym_v(SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4))
-#define YSYM(f) sym_v(SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3))
-#define XREC(f, ut) rec_v(SLB(f, 3, 0), SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4), SLB(f, 3, 5), ut)
-#define YREC(f, ut) rec_v(SLB(f, 0, 3), SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3), SLB(f, 5, 3), ut)
+    // Walls in x / y (REST variants only; g.xb / g.yb are runtime flags): inside the boundary buffer every stencil falls
+    // back to 2nd order, exactly as adv_flux_b / sym_b of the general kernels (idx: 1-based index along the stencil).
+    auto in_sym = [&](int idx, int N) { return idx > nbz && idx < N + 1 - nbz; };
+    auto in_rec = [&](bool pos, int idx, int N) {
+      return pos ? (idx > nbz && idx < N + 1 - (nbz - 1)) : (idx > nbz - 1 && idx < N + 1 - nbz);
+    };
+    const bool wx = REST && g.xb != 0, wy = REST && g.yb != 0;
+    const int ix = i + 1, jy = j + 1;                 // 1-based face indices of this thread's u / v cells
+#define XSYM(f, idx) ((wx && !in_sym(idx, g.Nx)) ? 0.5 * (SLB(f, 3, 2) + SLB(f, 3, 3)) \
+                                               : sym_v(SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4)))
+#define YSYM(f, idx) ((wy && !in_sym(idx, g.Ny)) ? 0.5 * (SLB(f, 2, 3) + SLB(f, 3, 3)) \
+                                               : sym_v(SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3)))
+#define XREC(f, ut, idx) ((wx && !in_rec((ut) > 0.0, idx, g.Nx)) ? 0.5 * (SLB(f, 3, 2) + SLB(f, 3, 3)) \
+                              : rec_v(SLB(f, 3, 0), SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4), SLB(f, 3, 5), ut))
+#define YREC(f, ut, idx) ((wy && !in_rec((ut) > 0.0, idx, g.Ny)) ? 0.5 * (SLB(f, 2, 3) + SLB(f, 3, 3)) \
+                              : rec_v(SLB(f, 0, 3), SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3), SLB(f, 5, 3), ut))
     if (!last) {
       if (do_x) {
-        double utu = XSYM(0);                          // centre i-1
-        double f0 = utu * XREC(0, utu);
+        double utu = XSYM(0, ix - 1);                  // centre i-1
+        double f0 = utu * XREC(0, utu, ix - 1);
         if (visc) {
           const double dux = (SLB(0, 3, 3) - SLB(0, 3, 2)) * rdx;
           const double divw = dux + (SLB(1, 4, 2) - SLB(1, 3, 2)) * rdy + (wxm - SLB(2, 3, 2)) * rdz;   // div U at (i-1, j, k)
@@ -478,19 +502,19 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
         }
         fx[0 * T + tid] = f0;
         if (FENCE3) OCN_SCHED_FENCE();
-        double utv = YSYM(0);                          // u interpolated in y to the v row
-        fx[1 * T + tid] = utv * XREC(1, utv) - (visc ? a.nu * (SLB(1, 3, 3) - SLB(1, 3, 2)) * rdx : 0.0);
+        double utv = YSYM(0, jy);                      // u interpolated in y to the v row
+        fx[1 * T + tid] = utv * XREC(1, utv, ix) - (visc ? a.nu * (SLB(1, 3, 3) - SLB(1, 3, 2)) * rdx : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
         double utw = symz(zu);                         // u interpolated in z to the w level
-        fx[2 * T + tid] = utw * XREC(2, utw) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 3, 2)) * rdx : 0.0);
+        fx[2 * T + tid] = utw * XREC(2, utw, ix) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 3, 2)) * rdx : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
       }
       if (do_y) {
-        double vtu = XSYM(1);                          // v interpolated in x to the u column
-        fx[3 * T + tid] = vtu * YREC(0, vtu) - (visc ? a.nu * (SLB(0, 3, 3) - SLB(0, 2, 3)) * rdy : 0.0);
+        double vtu = XSYM(1, ix);                      // v interpolated in x to the u column
+        fx[3 * T + tid] = vtu * YREC(0, vtu, jy) - (visc ? a.nu * (SLB(0, 3, 3) - SLB(0, 2, 3)) * rdy : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
-        double vtv = YSYM(1);                          // centre j-1
-        double f4 = vtv * YREC(1, vtv);
+        double vtv = YSYM(1, jy - 1);                  // centre j-1
+        double f4 = vtv * YREC(1, vtv, jy - 1);
         if (visc) {
           const double dvy = (SLB(1, 3, 3) - SLB(1, 2, 3)) * rdy;
           const double divs = (SLB(0, 2, 4) - SLB(0, 2, 3)) * rdx + dvy + (wym - SLB(2, 2, 3)) * rdz;   // div U at (i, j-1, k)
@@ -499,16 +523,16 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
         fx[4 * T + tid] = f4;
         if (FENCE3) OCN_SCHED_FENCE();
         double vtw = symz(zv);
-        fx[5 * T + tid] = vtw * YREC(2, vtw) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 2, 3)) * rdy : 0.0);
+        fx[5 * T + tid] = vtw * YREC(2, vtw, jy) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 2, 3)) * rdy : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
       }
     }
     double Fwu = 0, Fwv = 0, Fww = 0;
     if (full) {
-      double wtu = XSYM(2);
+      double wtu = XSYM(2, ix);
       Fwu = wtu * reconz(zu, wtu);
       if (FENCE3) OCN_SCHED_FENCE();
-      double wtv = YSYM(2);
+      double wtv = YSYM(2, jy);
       Fwv = wtv * reconz(zv, wtv);
       if (FENCE3) OCN_SCHED_FENCE();
       double wtw = symz_at(zw, k);                    // centre below face k
@@ -751,7 +775,10 @@ static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
   FusedShape f;
   const int xt_env = getenv("OCNHIP_FUSED_XT") ? atoi(getenv("OCNHIP_FUSED_XT")) : 0;   // 1: force the x-tiled kernel (tests)
   f.small = xt_env == 1 && gd.Nx <= 57 * 4;       // test shape: 64 x 4 threads, up to 57 output columns, >= 2 tiles
-  f.wide = gd.Nx > 256 || f.small;
+#ifdef OCN_HOST_EMU
+  if (gd.xb && gd.Nx <= 57 * 4) f.small = true;   // the emulation spawns one OS thread per GPU thread: keep workgroups small
+#endif
+  f.wide = gd.Nx > 256 || f.small || gd.xb;          // walls in x: no periodic wrap inside LDS -> the x-tiled kernel
   f.bx = f.small ? 64 : f.wide ? 192 : gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
   f.by = f.small ? 4 : f.wide ? 5 : f.bx == 256 ? 4 : 8;
   a.BYo = f.by - 1;
@@ -817,7 +844,8 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
 // ---- Bounded z: advection + time-stepper update of u, v, w on top of the general kernels' other terms ----------------
 bool fused_bz_available(const ocn_model* m) {
   const ocn_grid* g = m->g;
-  if (g->topo[0] != OCN_PERIODIC || g->topo[1] != OCN_PERIODIC) return false;
+  if (g->topo[0] == OCN_FLAT || g->topo[1] == OCN_FLAT) return false;      // walls in x / y are fine (runtime flags of the REST variants)
+  if (g->dist_y && (g->topo[0] != OCN_PERIODIC || g->topo[1] != OCN_PERIODIC)) return false;
   if (g->topo[2] == OCN_FLAT || (g->topo[2] == OCN_PERIODIC && (!g->z_regular || g->dist))) return false;
   int adv = m->d.advection;
   if (adv != ADV_WENO_Z && adv != ADV_WENO_JS && adv != ADV_U5) return false;
