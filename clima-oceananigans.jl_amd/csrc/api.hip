@@ -533,12 +533,14 @@ static void tendencies_and_step(ocn_model* m, double dt, double cn, double cm, i
     launch_step(m, dt, cn, cm, use_m);
     return;
   }
-  launch_tendencies(m, true);                  // closure, Coriolis, pressure gradient, boundary fluxes; tracers complete
+  const bool tr3 = m->nt > 0 && fused_tracer3_ok(m);
+  launch_tendencies(m, true, tr3);             // closure, Coriolis, pressure gradient, boundary fluxes (+ tracer advection unless tiled)
   launch_fused_bz(m, dt, cn, cm, use_m);       // + advection -> G^n; stepped velocities -> us, vs, ws
+  if (tr3) launch_tracer3(m, dt, cn, cm, use_m, true);   // reads the old velocities: before the swap
+  else launch_step(m, dt, cn, cm, use_m, true);
   std::swap(m->u.d, m->us.d);                  // halos are filled by the pressure-correction step that follows
   std::swap(m->v.d, m->vs.d);
   std::swap(m->w.d, m->ws.d);
-  launch_step(m, dt, cn, cm, use_m, true);
 }
 
 static int time_step_ab2(ocn_model* m, double dt, int force_euler) {
@@ -718,7 +720,7 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
   if (m->fast_path || m->bz_fast) {
     int r2 = field_alloc(m, m->us, OCN_FACE, OCN_CENTER, OCN_CENTER) | field_alloc(m, m->vs, OCN_CENTER, OCN_FACE, OCN_CENTER) |
              field_alloc(m, m->ws, OCN_CENTER, OCN_CENTER, OCN_FACE);
-    for (int t = 0; m->fast_path && t < m->nt; ++t) r2 |= field_alloc(m, m->trs[t], OCN_CENTER, OCN_CENTER, OCN_CENTER);
+    for (int t = 0; t < m->nt; ++t) r2 |= field_alloc(m, m->trs[t], OCN_CENTER, OCN_CENTER, OCN_CENTER);
     if (r2) {
       ocn_model_destroy(m);
       return OCN_ENOMEM;

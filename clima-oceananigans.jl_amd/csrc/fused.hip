@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
   // (tile-major), so every workgroup marches the same number of levels whatever Ny/(BY-1) is -- no partial
   // last round.  XCD-aware: workgroups b and b+8 share an L2, so each XCD gets a contiguous band of segments.
   const int nseg = gridDim.x, per = nseg / 8;
-  const long seg = (long)(blockIdx.x % 8) * per + blockIdx.x / 8;
+  const long seg = (nseg % 8 == 0) ? (long)(blockIdx.x % 8) * per + blockIdx.x / 8 : (long)blockIdx.x;
   const long total = (long)a.ntiles * g.Nz;
   long lo = seg * total / nseg;
   const long hi = (seg + 1) * total / nseg;
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) 
   // (tile-major), so every workgroup marches the same number of levels whatever Ny/(BY-1) is -- no partial
   // last round.  XCD-aware: workgroups b and b+8 share an L2, so each XCD gets a contiguous band of segments.
   const int nseg = gridDim.x, per = nseg / 8;
-  const long seg = (long)(blockIdx.x % 8) * per + blockIdx.x / 8;
+  const long seg = (nseg % 8 == 0) ? (long)(blockIdx.x % 8) * per + blockIdx.x / 8 : (long)blockIdx.x;
   const long total = (long)a.ntiles * g.Nz;
   long lo = seg * total / nseg;
   const long hi = (seg + 1) * total / nseg;
@@ -733,6 +733,172 @@ __global__ void __launch_bounds__(256) k_tracer_step(GridDev g, TracerArgs a) {
   }
 }
 
+// ---- tiled tracer kernel: three reconstructions per cell instead of five / six --------------------------------------
+// Same scheme as k_tend_step3 for one Center field: a workgroup owns complete x rows of BY-1 output rows (+ ghost row),
+// stages the level's slab of c in LDS, every thread forms the WEST / SOUTH / BOTTOM face fluxes of its cell (advecting
+// velocity un-interpolated, upwind_biased_advective_fluxes.jl:103-128), EAST / NORTH come from the neighbours through LDS,
+// TOP is the next level's BOTTOM.  kappa != 0: ScalarDiffusivity as -kappa dc/dn in every face flux.  REST: G^n arrives
+// with the non-advective terms (variable diffusivity, boundary fluxes) from the general kernels.  ZB and the runtime
+// wall flags g.yb (REST only) select the 2nd-order fallbacks of the boundary buffer.  IMG: write the periodic images of
+// the updated tracer (all-in-one periodic path); otherwise the caller fills halos.
+struct Tracer3Args {
+  const double *u, *v, *w, *c, *gm;   // PARENT base pointers
+  double *gn, *cnew;
+  unsigned org;
+  double dt, cn, cm, kappa;
+  int use_m, ntiles, zwrap;
+};
+
+template <int ADV, int BX, int BY, bool ZB, bool REST, bool IMG>
+__global__ void __launch_bounds__(BX* BY) k_tracer_step3(GridDev g, Tracer3Args a) {
+  constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
+  constexpr int NG = (NR + BY - 1) / BY;
+  OCN_SHARED double slab2[2 * NR * SX];    // slab and flux exchange are both double buffered by level parity:
+  OCN_SHARED double fx[2 * 2 * T];         // ONE barrier per level (a level is only three reconstructions of work)
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tid = ty * BX + tx;
+  const int i = tx;
+  const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
+  const double rdx = g.rdx, rdy = g.rdy;
+  const int nbz = 2;
+  const bool col_ok = i < g.Nx;
+  const bool ghost = (ty == BY - 1);
+  const int txe = (tx + 1 == g.Nx) ? 0 : tx + 1;
+  const int nid_e = ty * BX + (txe < BX ? txe : tx);
+  const int nid_n = (ty + 1 < BY ? ty + 1 : ty) * BX + tx;
+  const bool wy = REST && g.yb != 0;
+  const int nseg = gridDim.x, per = nseg / 8;
+  const long seg = (nseg % 8 == 0) ? (long)(blockIdx.x % 8) * per + blockIdx.x / 8 : (long)blockIdx.x;
+  const long total = (long)a.ntiles * g.Nz;
+  long lo = seg * total / nseg;
+  const long hi = (seg + 1) * total / nseg;
+  auto in_rec = [&](bool pos, int idx, int N) {
+    return pos ? (idx > nbz && idx < N + 1 - (nbz - 1)) : (idx > nbz - 1 && idx < N + 1 - nbz);
+  };
+  while (lo < hi) {
+    const int ytile = (int)(lo / g.Nz);
+    const int k0 = (int)(lo - (long)ytile * g.Nz);
+    const int k1 = (k0 + (hi - lo) < g.Nz) ? (int)(k0 + (hi - lo)) : g.Nz;
+    lo += k1 - k0;
+    const int j0 = ytile * (BY - 1);
+    const int j = j0 + ty;
+    const bool row_ok = j < g.Ny;
+    const bool do_y = col_ok && j <= g.Ny;
+    const bool full = col_ok && row_ok && !ghost;
+    const unsigned cxy = a.org + (unsigned)(col_ok ? i : 0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
+    const unsigned grow = a.org + (unsigned)(col_ok ? i : 0) * sxb;
+    double pf[NG];
+    auto prefetch = [&](int k) {
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        int r = ty + BY * gq;
+        if (r < NR) {
+          int jg = j0 - 3 + r;
+          if (jg > g.Ny + 2) jg = g.Ny + 2;
+          pf[gq] = ldo(a.c, grow + (unsigned)(jg + 3) * syb - 3u * syb + (unsigned)k * szb);
+        }
+      }
+    };
+    const bool img_e = tx < 3, img_w = tx >= g.Nx - 3;
+    auto commit = [&](int k) {
+      double* slab = slab2 + (k & 1) * NR * SX;
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        int r = ty + BY * gq;
+        if (r < NR && col_ok) {
+          double* row = slab + r * SX;
+          row[tx + 3] = pf[gq];
+          if (img_e) row[tx + 3 + g.Nx] = pf[gq];
+          if (img_w) row[tx + 3 - g.Nx] = pf[gq];
+        }
+      }
+    };
+#define CS(d, e) S[(d) * SX + (e)]
+    double zc[6];
+    {
+      const unsigned c = cxy + (unsigned)k0 * szb;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) zc[q] = ldo(a.c, c + (unsigned)(q - 3) * szb);
+    }
+    double un = ldo(a.u, cxy + (unsigned)k0 * szb), vn = ldo(a.v, cxy + (unsigned)k0 * szb), wn = ldo(a.w, cxy + (unsigned)k0 * szb);
+    double own_h = 0, own_b = 0;
+    prefetch(k0);
+    commit(k0);
+    __syncthreads();
+    for (int k = k0; k <= k1; ++k) {
+      const unsigned c = cxy + (unsigned)k * szb;
+      const bool last = (k == k1);
+      double* fxx = fx + (k & 1) * 2 * T;
+      double* fxy = fxx + T;
+      const double* S = slab2 + (k & 1) * NR * SX + ty * SX + tx;      // own cell at S[3 * SX + 3]
+      if (!last) prefetch(k + 1);                                     // lands while the fluxes are formed
+      const double uw = un, vs_ = vn, wb = wn;          // advecting velocities at the west / south / bottom faces
+      if (!last) {
+        un = ldo(a.u, c + szb);
+        vn = ldo(a.v, c + szb);
+        wn = ldo(a.w, c + szb);
+      }
+      double gmv = 0, rest = 0;
+      if (full && k > k0) {
+        if (a.use_m) gmv = ldo(a.gm, c - szb);
+        if (REST) rest = ldo(a.gn, c - szb);
+      }
+      auto rec = [&](double m3, double m2, double m1, double c0, double c1, double c2, double ut) {
+        bool pos = ut > 0.0;
+        return recon5<ADV>(pos ? m3 : c2, pos ? m2 : c1, pos ? m1 : c0, pos ? c0 : m1, pos ? c1 : m2, pos);
+      };
+      if (!last) {
+        if (full) {
+          double f = uw * rec(CS(3, 0), CS(3, 1), CS(3, 2), CS(3, 3), CS(3, 4), CS(3, 5), uw);
+          if (a.kappa != 0.0) f -= a.kappa * (CS(3, 3) - CS(3, 2)) * rdx;
+          fxx[tid] = f;
+        }
+        if (do_y) {
+          double r;
+          if (wy && !in_rec(vs_ > 0.0, j + 1, g.Ny)) r = 0.5 * (CS(2, 3) + CS(3, 3));
+          else r = rec(CS(0, 3), CS(1, 3), CS(2, 3), CS(3, 3), CS(4, 3), CS(5, 3), vs_);
+          double f = vs_ * r;
+          if (a.kappa != 0.0) f -= a.kappa * (CS(3, 3) - CS(2, 3)) * rdy;
+          fxy[tid] = f;
+        }
+      }
+      double fb = 0;
+      if (full) {
+        const bool pos = wb > 0.0;
+        double r;
+        if (ZB && !in_rec(pos, k + 1, g.Nz)) r = 0.5 * (zc[2] + zc[3]);
+        else r = recon5<ADV>(pos ? zc[0] : zc[5], pos ? zc[1] : zc[4], pos ? zc[2] : zc[3], pos ? zc[3] : zc[2], pos ? zc[4] : zc[1], pos);
+        fb = wb * r;
+        if (a.kappa != 0.0) fb -= a.kappa * (zc[3] - zc[2]) * (ZB ? g_rdzf(g, k) : g.rdz);
+      }
+      if (!last) commit(k + 1);            // the other slab buffer: last read in the previous level's flux stage
+      __syncthreads();
+      if (full) {
+        if (k > k0) {
+          const unsigned cm1 = c - szb;
+          const double rzc = ZB ? g_rdzc(g, k - 1) : g.rdz;
+          const double G = rest - (own_h + (fb - own_b) * rzc);
+          sto(a.gn, cm1, G);
+          const double inc = a.use_m ? a.dt * (a.cn * G + a.cm * gmv) : a.dt * a.cn * G;
+          const double val = zc[2] + inc;
+          if (IMG) store_images(g, (double*)((char*)a.cnew + a.org), i, j, k - 1, val, a.zwrap);
+          else sto(a.cnew, cm1, val);
+        }
+        if (!last) {
+          own_h = (fxx[nid_e] - fxx[tid]) * rdx + (fxy[nid_n] - fxy[tid]) * rdy;
+          own_b = fb;
+        }
+      }
+      if (!last) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) zc[q] = zc[q + 1];
+        zc[5] = ldo(a.c, c + 3 * szb);
+      }
+    }
+  }
+#undef CS
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------
 bool fused_available(const ocn_model* m) {
   const ocn_grid* g = m->g;
@@ -781,6 +947,14 @@ static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
   f.wide = gd.Nx > 256 || f.small || gd.xb;          // walls in x: no periodic wrap inside LDS -> the x-tiled kernel
   f.bx = f.small ? 64 : f.wide ? 192 : gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
   f.by = f.small ? 4 : f.wide ? 5 : f.bx == 256 ? 4 : 8;
+#ifdef OCN_HOST_EMU
+  // the emulation runs one OS thread per GPU thread and every barrier wakes all of them: 16 x 4 workgroups for the tiny
+  // test grids (same kernel source, another template shape)
+  if ((f.small && gd.Nx <= 36) || (!f.wide && gd.Nx <= 16)) {
+    f.bx = 16;
+    f.by = 4;
+  }
+#endif
   a.BYo = f.by - 1;
   a.ntiles = (gd.Ny + f.by - 2) / (f.by - 1);
   a.ntx = 1;
@@ -796,13 +970,25 @@ static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
   const long total = (long)a.ntiles * gd.Nz;
   if (nseg > total / 4) nseg = (int)(total / 4 > 8 ? total / 4 : 8);
   nseg = ((nseg + 7) / 8) * 8;                    // XCD-aware remap inside the kernel wants a multiple of 8
+#ifdef OCN_HOST_EMU
+  nseg = total >= 3 ? 3 : 1;                      // one OS thread per emulated GPU thread: few workgroups, still several segments
+#endif
   f.blk = dim3(f.bx, f.by, 1);
   f.grd = dim3(nseg, 1, 1);
   return f;
 }
 
 // launch one of the instantiations: VISCV / ZBV / RESTV are compile-time constants at the call site
+#ifdef OCN_HOST_EMU
+#define FUSED_EMU16(ADVV, VISCV, ZBV, RESTV)                                                                               \
+  if (f.bx == 16 && f.small) ocn_launch_sync(k_tend_step3x<ADVV, 16, 4, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);     \
+  else if (f.bx == 16) ocn_launch_sync(k_tend_step3<ADVV, 16, 4, true, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); \
+  else
+#else
+#define FUSED_EMU16(ADVV, VISCV, ZBV, RESTV)
+#endif
 #define FUSED_LAUNCH(ADVV, VISCV, ZBV, RESTV)                                                                              \
+  FUSED_EMU16(ADVV, VISCV, ZBV, RESTV)                                                                                     \
   if (f.small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);                  \
   else if (f.wide) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);             \
   else if (f.bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); \
@@ -921,8 +1107,76 @@ int fused_exchange_phi(ocn_model* m, const double* phi) {
   return comm_exchange(c, s, q);
 }
 
+bool fused_tracer3_ok(const ocn_model* m) {
+  return m->gd.Nx <= 256 && !m->gd.xb && !getenv("OCNHIP_NO_TRACER3");
+}
+
+// tiled tracer kernel for every tracer; rest: G^n(tracers) holds the non-advective terms and halos are filled by the caller
+void launch_tracer3(ocn_model* m, double dt, double cn, double cm, int use_m, bool rest) {
+  ProfScope ps(m->ctx, "fused_tracer_step");
+  const GridDev& gd = m->gd;
+  int bx = gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
+  int by = bx == 256 ? 4 : 8;
+#ifdef OCN_HOST_EMU
+  if (gd.Nx <= 16) {
+    bx = 16;
+    by = 4;
+  }
+#endif
+  Tracer3Args a;
+  a.u = m->u.d; a.v = m->v.d; a.w = m->w.d;
+  a.org = (unsigned)((m->u.Hx + m->u.Hy * m->u.sy + m->u.Hz * m->u.sz) * sizeof(double));
+  a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
+  a.ntiles = (gd.Ny + by - 2) / (by - 1);
+  a.zwrap = (m->g->dist || m->g->topo[2] != OCN_PERIODIC) ? 0 : 1;
+  int nseg = fused_cu_count(m);
+  const long total = (long)a.ntiles * gd.Nz;
+  if (nseg > total / 4) nseg = (int)(total / 4 > 8 ? total / 4 : 8);
+  nseg = ((nseg + 7) / 8) * 8;
+#ifdef OCN_HOST_EMU
+  nseg = total >= 3 ? 3 : 1;
+#endif
+  const dim3 blk(bx, by, 1), grd(nseg, 1, 1);
+  hipStream_t s = m->ctx->stream;
+  const bool zb = m->g->topo[2] == OCN_BOUNDED;
+  for (int t = 0; t < m->nt; ++t) {
+    a.c = m->tr[t].d;
+    a.gm = m->Gm[3 + t].d;
+    a.gn = m->Gn[3 + t].d;
+    a.cnew = m->trs[t].d;
+    a.kappa = (!rest && m->d.closure == OCN_CLOSURE_SCALAR) ? m->d.kappa[t] : 0.0;
+#ifdef OCN_HOST_EMU
+#define TR3_EMU16(ADVV, ZBV, RESTV, IMGV) \
+    if (bx == 16) ocn_launch_sync(k_tracer_step3<ADVV, 16, 4, ZBV, RESTV, IMGV>, grd, blk, s, m->gd, a); else
+#else
+#define TR3_EMU16(ADVV, ZBV, RESTV, IMGV)
+#endif
+#define TR3_SHAPES(ADVV, ZBV, RESTV, IMGV)                                                                 \
+    TR3_EMU16(ADVV, ZBV, RESTV, IMGV)                                                                      \
+    if (bx == 256) ocn_launch_sync(k_tracer_step3<ADVV, 256, 4, ZBV, RESTV, IMGV>, grd, blk, s, m->gd, a);     \
+    else if (bx == 128) ocn_launch_sync(k_tracer_step3<ADVV, 128, 8, ZBV, RESTV, IMGV>, grd, blk, s, m->gd, a); \
+    else ocn_launch_sync(k_tracer_step3<ADVV, 64, 8, ZBV, RESTV, IMGV>, grd, blk, s, m->gd, a);
+#define TR3_MODE(ADVV)                                 \
+    if (!rest) { TR3_SHAPES(ADVV, false, false, true) } \
+    else if (zb) { TR3_SHAPES(ADVV, true, true, false) } \
+    else { TR3_SHAPES(ADVV, false, true, false) }
+    switch (m->d.advection) {
+      case ADV_WENO_Z: TR3_MODE(ADV_WENO_Z) break;
+      case ADV_WENO_JS: TR3_MODE(ADV_WENO_JS) break;
+      default: TR3_MODE(ADV_U5) break;
+    }
+#undef TR3_MODE
+#undef TR3_SHAPES
+  }
+  for (int t = 0; t < m->nt; ++t) std::swap(m->tr[t].d, m->trs[t].d);
+}
+
 void launch_tracer_steps(ocn_model* m, double dt, double cn, double cm, int use_m) {
   if (m->nt == 0) return;
+  if (fused_tracer3_ok(m)) {
+    launch_tracer3(m, dt, cn, cm, use_m, false);
+    return;
+  }
   ProfScope ps(m->ctx, "fused_tracer_step");
   const GridDev& g = m->gd;
   for (int t = 0; t < m->nt; ++t) {

@@ -124,7 +124,7 @@ void launch_fill_periodic(ocn_model* m, const FieldPtrs& f, int dim);
 void launch_fill_flat(ocn_model* m, const FieldPtrs& f, int dim);
 bool launch_fill_periodic_xy(ocn_model* m, const FieldPtrs& f);   // false: not applicable, use the two passes
 void launch_fill_bounded(ocn_model* m, Field** fs, int n, int dim);
-void launch_tendencies(ocn_model* m, bool skip_momentum_advection = false);
+void launch_tendencies(ocn_model* m, bool skip_momentum_advection = false, bool skip_tracer_advection = false);
 void launch_step(ocn_model* m, double dt, double cn, double cm, int use_m, bool tracers_only = false);
 void launch_store(ocn_model* m);
 void launch_rhs(ocn_model* m, double dt, double* rhs, int mult_dz);
@@ -139,6 +139,8 @@ int amd_build_table(ocn_model* m);
 bool fused_available(const ocn_model* m);
 bool fused_bz_available(const ocn_model* m);
 void launch_fused_bz(ocn_model* m, double dt, double cn, double cm, int use_m);
+bool fused_tracer3_ok(const ocn_model* m);
+void launch_tracer3(ocn_model* m, double dt, double cn, double cm, int use_m, bool rest);
 void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m);
 void launch_rhs_wrap(ocn_model* m, double dt, double* rhs);
 void launch_project(ocn_model* m, double dt, const double* phi);

@@ -217,7 +217,7 @@ __global__ void k_apply_flux(GridDev g, double* __restrict__ G, int dim, int zlo
   }
 }
 
-void launch_tendencies(ocn_model* m, bool skip_momentum_advection) {
+void launch_tendencies(ocn_model* m, bool skip_momentum_advection, bool skip_tracer_advection) {
   ProfScope ps(m->ctx, "tendencies");
   const GridDev& g = m->gd;
   hipStream_t s = m->ctx->stream;
@@ -233,13 +233,17 @@ void launch_tendencies(ocn_model* m, bool skip_momentum_advection) {
   const dim3 gr = grid3(g, b);
   const double *u = m->u.interior(), *v = m->v.interior(), *w = m->w.interior();
   double *Gu = m->Gn[0].interior(), *Gv = m->Gn[1].interior(), *Gw = m->Gn[2].interior();
+#define TEND_TRACER(A, W, t)                                                                               \
+  ocn_launch(k_tend_c<A, W>, gr, b, s, g, u, v, w, (const double*)m->tr[t].interior(), m->d.kappa[t],     \
+             (const double*)(m->kappa_e[t].present ? m->kappa_e[t].interior() : nullptr), m->d.closure, \
+             m->Gn[3 + t].interior());
 #define TEND_LAUNCH(A, W)                                                       \
   if (skip_momentum_advection) ocn_launch(k_tend_uvw<ADV_NONE, W>, gr, b, s, g, ph, u, v, w, Gu, Gv, Gw);   \
   else ocn_launch(k_tend_uvw<A, W>, gr, b, s, g, ph, u, v, w, Gu, Gv, Gw);      \
-  for (int t = 0; t < m->nt; ++t)                                               \
-    ocn_launch(k_tend_c<A, W>, gr, b, s, g, u, v, w, (const double*)m->tr[t].interior(), m->d.kappa[t], \
-               (const double*)(m->kappa_e[t].present ? m->kappa_e[t].interior() : nullptr), m->d.closure, \
-               m->Gn[3 + t].interior());
+  for (int t = 0; t < m->nt; ++t) {                                             \
+    if (skip_tracer_advection) { TEND_TRACER(ADV_NONE, W, t) }                  \
+    else { TEND_TRACER(A, W, t) }                                               \
+  }
 #define TEND_CASE(A)                \
   case A:                           \
     if (g.xb || g.yb) {             \
@@ -258,6 +262,7 @@ void launch_tendencies(ocn_model* m, bool skip_momentum_advection) {
   }
 #undef TEND_CASE
 #undef TEND_LAUNCH
+#undef TEND_TRACER
   // boundary contributions in every Bounded direction
   for (int dim = 0; dim < 3; ++dim) {
     if (m->g->topo[dim] != OCN_BOUNDED) continue;

@@ -15,8 +15,7 @@ def test_case_matches_oracle(ocn, backend, name):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("name", ["ppp_weno_ab2", "ppp_weno_rk3_2tracers", "ppp_wenojs_tracer", "ppp_weno_visc_ab2",
-                                  "ppb_weno_full", "ppb_amd_config3"])
+@pytest.mark.parametrize("name", ["ppp_weno_ab2", "ppp_weno_visc_ab2", "ppb_weno_full", "ppb_amd_config3"])
 def test_x_tiled_tendency_kernel(ocn, backend, name, monkeypatch):
     """The kernel for rows wider than a workgroup (Nx > 256), forced onto small grids with two x-tiles per row."""
     if backend != "hostemu":
