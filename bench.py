@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--nu", type=float, default=0.0, help="config 2 with ScalarDiffusivity(nu = kappa = NU) (DNS-style; 0: inviscid headline)")
     ap.add_argument("--topology", default="PPP", help="config 2 with other x/y/z topologies, e.g. PBB (debug / widening rows)")
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (headline, default), 1 (2-D turbulence) or 3 (ocean LES)")
+    ap.add_argument("--lib", default=None, help="another build of libocnhip.so (kernel experiments; never the host emulation)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,6 +119,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     os.environ.pop("OCNHIP_LIB", None)      # the product library only
+    if args.lib:
+        if "hostemu" in args.lib:
+            raise SystemExit("--lib is for GPU builds of the library only")
+        os.environ["OCNHIP_LIB"] = os.path.abspath(args.lib)
     import __graft_entry__ as ge
     ocn = ge.load_package()                 # loads libocnhip.so before anything touches torch
     ocn._lib.load()

@@ -244,7 +244,11 @@ int ocn_grid_create(ocn_ctx* ctx, const ocn_grid_desc* desc, ocn_grid** out) {
     }
   g->z_regular = desc->z_faces == nullptr;
   if (!g->z_regular) {
-    if (g->topo[2] == OCN_FLAT) return OCN_EINVAL;
+    if (g->topo[2] == OCN_FLAT) {
+      ocn_set_error(ctx, "z_faces given for a Flat z direction");
+      delete g;
+      return OCN_EINVAL;
+    }
     g->zF_int.assign(desc->z_faces, desc->z_faces + g->N[2] + 1);
     for (int k = 0; k < g->N[2]; ++k)
       if (!(g->zF_int[k + 1] > g->zF_int[k])) {
@@ -441,44 +445,44 @@ static int fill_fields(ocn_model* m, Field** fs, int n) {
   return OCN_OK;
 }
 
-static void fill_velocities_tracers(ocn_model* m, bool tracers) {
+static int fill_velocities_tracers(ocn_model* m, bool tracers) {
   Field* fs[OCN_NF];
   int n = 0;
-  fs[n++] = &m->u;
-  fs[n++] = &m->v;
-  fs[n++] = &m->w;
+  fs[n++] = &pred_u(m);   // the predictor between time-stepper update and projection, else u, v, w themselves
+  fs[n++] = &pred_v(m);
+  fs[n++] = &pred_w(m);
   if (tracers)
     for (int t = 0; t < m->nt; ++t) fs[n++] = &m->tr[t];
-  fill_fields(m, fs, n);
+  return fill_fields(m, fs, n);
 }
 
 static int update_state(ocn_model* m) {
   // update_nonhydrostatic_model_state.jl:14-37
-  fill_velocities_tracers(m, true);
+  int rc = fill_velocities_tracers(m, true);
+  if (rc) return rc;
   if (m->d.closure == OCN_CLOSURE_AMD) {
     launch_amd(m);
     Field* fs[OCN_NF];
     int n = 0;
     fs[n++] = &m->nu_e;
     for (int t = 0; t < m->nt; ++t) fs[n++] = &m->kappa_e[t];
-    fill_fields(m, fs, n);
+    if ((rc = fill_fields(m, fs, n))) return rc;
   }
   launch_hydrostatic(m);
   if (m->pHY.present && m->d.buoyancy != OCN_BUOYANCY_NONE) {
     Field* fs[1] = {&m->pHY};
-    fill_fields(m, fs, 1);
+    if ((rc = fill_fields(m, fs, 1))) return rc;
   }
   return OCN_OK;
 }
 
 static int pressure_correction(ocn_model* m, double dt) {
   // pressure_correction.jl:10-23
-  fill_velocities_tracers(m, false);
-  int rc = poisson_solve(m, dt);
+  int rc = fill_velocities_tracers(m, false);
   if (rc) return rc;
+  if ((rc = poisson_solve(m, dt))) return rc;
   Field* fs[1] = {&m->pNHS};
-  fill_fields(m, fs, 1);
-  return OCN_OK;
+  return fill_fields(m, fs, 1);
 }
 
 // store_tendencies! (store_tendencies.jl:14-36) without the copy: G^- takes over G^n's buffers, and G^n gets
@@ -488,15 +492,18 @@ static void store_by_swap(ocn_model* m) {
 }
 
 // Phase-level callers expect two distinct arrays: make G^n a real copy of G^- again when they are aliased.
-static void materialize_gn(ocn_model* m) {
-  if (!m->gn_alias_gm) return;
+static int materialize_gn(ocn_model* m) {
+  if (!m->gn_alias_gm) return OCN_OK;
   for (int f = 0; f < 3 + m->nt; ++f)
-    hipMemcpyAsync(m->Gn[f].d, m->Gm[f].d, m->Gm[f].n * sizeof(double), hipMemcpyDeviceToDevice, m->ctx->stream);
+    OCN_HIP_CHECK(m->ctx, hipMemcpyAsync(m->Gn[f].d, m->Gm[f].d, m->Gm[f].n * sizeof(double), hipMemcpyDeviceToDevice, m->ctx->stream));
   m->gn_alias_gm = false;
+  return OCN_OK;
 }
 
-static void zero_Gm(ocn_model* m) {
-  for (int f = 0; f < 3 + m->nt; ++f) hipMemsetAsync(m->Gm[f].d, 0, m->Gm[f].n * sizeof(double), m->ctx->stream);
+static int zero_Gm(ocn_model* m) {
+  for (int f = 0; f < 3 + m->nt; ++f)
+    OCN_HIP_CHECK(m->ctx, hipMemsetAsync(m->Gm[f].d, 0, m->Gm[f].n * sizeof(double), m->ctx->stream));
+  return OCN_OK;
 }
 
 // one fused (sub)step of the fast path: tendencies + update, rhs, solve, projection + halo images
@@ -538,18 +545,17 @@ static void tendencies_and_step(ocn_model* m, double dt, double cn, double cm, i
   launch_fused_bz(m, dt, cn, cm, use_m);       // + advection -> G^n; stepped velocities -> us, vs, ws
   if (tr3) launch_tracer3(m, dt, cn, cm, use_m, true);   // reads the old velocities: before the swap
   else launch_step(m, dt, cn, cm, use_m, true);
-  std::swap(m->u.d, m->us.d);                  // halos are filled by the pressure-correction step that follows
-  std::swap(m->v.d, m->vs.d);
-  std::swap(m->w.d, m->ws.d);
-}
+  m->pred_active = true;                       // U* stays in us / vs / ws (halos filled by the pressure-correction step that
+}                                              // follows); launch_pcorrect writes u = U* - dt grad p and clears the flag
 
 static int time_step_ab2(ocn_model* m, double dt, int force_euler) {
   // quasi_adams_bashforth_2.jl:70-104
   bool euler = force_euler || (dt != m->previous_dt);
   double chi = euler ? -0.5 : m->d.chi;
-  if (euler) zero_Gm(m);
+  int rc0 = euler ? zero_Gm(m) : OCN_OK;
+  if (rc0) return rc0;
   m->previous_dt = dt;
-  if (m->iteration == 0) update_state(m);
+  if (m->iteration == 0 && (rc0 = update_state(m))) return rc0;
   if (m->fast_path) {
     m->gn_alias_gm = false;
     int rc = fused_substep(m, dt, 1.5 + chi, -(0.5 + chi), 1, dt, true);
@@ -575,7 +581,8 @@ static int time_step_ab2(ocn_model* m, double dt, int force_euler) {
 
 static int time_step_rk3(ocn_model* m, double dt) {
   // runge_kutta_3.jl:57-62,81-152
-  if (m->iteration == 0) update_state(m);
+  int rc0 = m->iteration == 0 ? update_state(m) : OCN_OK;
+  if (rc0) return rc0;
   const double g1 = 8.0 / 15.0, g2 = 5.0 / 12.0, g3 = 3.0 / 4.0, z2 = -17.0 / 60.0, z3 = -5.0 / 12.0;
   const double gam[3] = {g1, g2, g3}, zet[3] = {0.0, z2, z3};
   const double sdt[3] = {g1 * dt, (g2 + z2) * dt, (g3 + z3) * dt};
@@ -605,7 +612,7 @@ static int time_step_rk3(ocn_model* m, double dt) {
       m->iteration += 1;
       m->stage = 1;
     }
-    update_state(m);
+    if ((rc = update_state(m))) return rc;
   }
   return OCN_OK;
 }
@@ -623,18 +630,27 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
   }
   // halo inflation (nonhydrostatic_model.jl:140-148; Advection.jl:40)
   static const int buffer[6] = {0, 0, 1, 2, 2, 2};
+  // The reference builds a NEW grid with the wider halo (with_halo); so does this: the caller's grid, and any
+  // model already living on it, keep their halos, spacing tables and layouts.
   int need = buffer[desc->advection] + 1;
   bool changed = false;
   for (int d = 0; d < 3; ++d)
-    if (g->topo[d] != OCN_FLAT && g->H[d] < need) {
-      g->H[d] = need;
-      changed = true;
-    }
+    if (g->topo[d] != OCN_FLAT && g->H[d] < need) changed = true;
+  ocn_grid* own = nullptr;
   if (changed) {
-    int rc = grid_build_dev(g);
-    if (rc) return rc;
+    own = new ocn_grid(*g);
+    own->d_dzc = own->d_dzf = own->d_rdzc = own->d_rdzf = nullptr;   // grid_build_dev allocates the copy's own tables
+    for (int d = 0; d < 3; ++d)
+      if (own->topo[d] != OCN_FLAT && own->H[d] < need) own->H[d] = need;
+    int rc = grid_build_dev(own);
+    if (rc) {
+      ocn_grid_destroy(own);
+      return rc;
+    }
+    g = own;
   }
   ocn_model* m = new ocn_model;
+  m->own_grid = own;
   m->g = g;
   m->ctx = ctx;
   m->d = *desc;
@@ -725,6 +741,11 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
       ocn_model_destroy(m);
       return OCN_ENOMEM;
     }
+    for (int s = 0; s < 6; ++s) {   // the predictor is filled with the velocities' boundary conditions
+      m->us.bc[s] = m->u.bc[s];
+      m->vs.bc[s] = m->v.bc[s];
+      m->ws.bc[s] = m->w.bc[s];
+    }
   }
   m->solver = poisson_create(m);
   if (!m->solver) {
@@ -757,6 +778,7 @@ void ocn_model_destroy(ocn_model* m) {
   hipFree(m->ypack_s);
   hipFree(m->ypack_r);
   poisson_destroy(m->solver);
+  ocn_grid_destroy(m->own_grid);
   delete m;
 }
 
@@ -818,7 +840,7 @@ int ocn_field_layout(const ocn_model* m, int field_id, int64_t strides[3], int64
 }
 
 int ocn_field_upload(ocn_model* m, int field_id, const double* host) {
-  if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF) materialize_gn(m);
+  if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF && materialize_gn(m)) return OCN_EHIP;
   Field* f = model_field(m, field_id);
   if (!f || !host) return OCN_EINVAL;
   OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));
@@ -850,7 +872,7 @@ int ocn_field_download(const ocn_model* m, int field_id, double* host) {
 }
 
 int ocn_field_set_interior(ocn_model* m, int field_id, const double* host) {
-  if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF) materialize_gn(m);
+  if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF && materialize_gn(m)) return OCN_EHIP;
   Field* f = model_field(m, field_id);
   if (!f || !host) return OCN_EINVAL;
   int32_t it[3];
@@ -890,8 +912,7 @@ int ocn_fill_halos(ocn_model* m, uint32_t mask) {
   for (int t = 0; t < m->nt; ++t)
     if (mask & (1u << (8 + t))) fs[n++] = &m->tr[t];
   // fields of one call share one batched launch; aux fields (pressures) use their own z conditions
-  fill_fields(m, fs, n);
-  return OCN_OK;
+  return fill_fields(m, fs, n);
 }
 
 int ocn_update_state(ocn_model* m) { return m ? update_state(m) : OCN_EINVAL; }
@@ -905,21 +926,21 @@ int ocn_compute_tendencies(ocn_model* m) {
 
 int ocn_ab2_step(ocn_model* m, double dt, double chi) {
   if (!m) return OCN_EINVAL;
-  materialize_gn(m);
+  if (materialize_gn(m)) return OCN_EHIP;
   launch_step(m, dt, 1.5 + chi, -(0.5 + chi), 1);
   return OCN_OK;
 }
 
 int ocn_rk3_substep(ocn_model* m, double dt, double gamma, double zeta, int has_zeta) {
   if (!m) return OCN_EINVAL;
-  materialize_gn(m);
+  if (materialize_gn(m)) return OCN_EHIP;
   launch_step(m, dt, gamma, zeta, has_zeta);
   return OCN_OK;
 }
 
 int ocn_store_tendencies(ocn_model* m) {
   if (!m) return OCN_EINVAL;
-  materialize_gn(m);
+  if (materialize_gn(m)) return OCN_EHIP;
   launch_store(m);
   return OCN_OK;
 }
@@ -950,12 +971,12 @@ int ocn_poisson_solve_host(ocn_model* m, const double* rhs, double* phi) {
 int ocn_set_epilogue(ocn_model* m, int enforce_incompressibility) {
   // set_nonhydrostatic_model.jl:45-58
   if (!m) return OCN_EINVAL;
-  update_state(m);
+  int rc = update_state(m);
+  if (rc) return rc;
   if (enforce_incompressibility) {
-    int rc = pressure_correction(m, 1.0);
-    if (rc) return rc;
+    if ((rc = pressure_correction(m, 1.0))) return rc;
     launch_pcorrect(m, 1.0);
-    update_state(m);
+    if ((rc = update_state(m))) return rc;
   }
   return OCN_OK;
 }

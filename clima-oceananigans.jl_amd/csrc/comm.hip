@@ -7,11 +7,24 @@
 // and the Poisson transpose is a single grouped send/recv to the 7 peers so every link carries 1/8 of the
 // slab concurrently (per-link bound, no ring).
 //
-// Two back ends behind the same three calls (comm_exchange / comm_alltoall / comm_barrier):
-//   * RCCL (the product)                      -- built when OCN_WITH_RCCL is defined
-//   * in-process mailbox (OCN_HOST_EMU only)  -- several contexts of ONE process act as ranks, so the
-//     decomposition logic (pack order, neighbour ranks, transposes) is testable without GPUs.
+// Three transports behind the same calls (comm_exchange / comm_alltoall):
+//   * RCCL (the product)                      -- grouped ncclSend / ncclRecv on the context's stream
+//   * host shared memory (both builds)        -- one process per rank, POSIX shm mailboxes; selected when the id
+//     handed to ocn_comm_init starts with "SHM:" (ocn_comm_unique_id produces such an id in the host-emulation
+//     build and, in the GPU build, when OCNHIP_TRANSPORT=shm).  Test / rehearsal transport: it lets world_size-2
+//     gloo tests drive the LIBRARY on the CPU box and lets two ranks share the ONE GPU of a test box (device
+//     buffers are staged through the mailbox with blocking copies).  Same pairing rule as RCCL: the k-th send of
+//     rank a to rank b meets the k-th receive b posts from a; tag and size are checked.
+//   * in-process mailbox (OCN_HOST_EMU only)  -- several contexts of ONE process act as ranks (threads).
 #include "internal.h"
+
+#include <atomic>
+#include <chrono>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #ifndef OCN_HOST_EMU
 #include <rccl/rccl.h>
@@ -42,10 +55,194 @@ struct EmuWorld {
 static EmuWorld g_world;
 #endif
 
+// ---- host shared-memory transport ---------------------------------------------------------------------------------
+#define SHM_MAXR 16
+#define SHM_MAXMSG 256
+struct ShmCtl {                        // "<name>.ctl": zero-filled by the kernel on creation
+  std::atomic<int> arrived, gen;
+  std::atomic<uint64_t> box_bytes[SHM_MAXR];   // current size of every rank's outbox segment
+};
+struct ShmMsg { int peer, tag; uint64_t bytes, off; };
+struct ShmBox {                        // "<name>.<rank>": what the rank sends in the current exchange
+  uint32_t nmsg;
+  ShmMsg msg[SHM_MAXMSG];
+};
+struct ShmWorld {
+  std::string name;
+  ShmCtl* ctl = nullptr;
+  void* box[SHM_MAXR] = {nullptr};     // mappings of every rank's outbox (own one writable)
+  uint64_t mapped[SHM_MAXR] = {0};
+  int rank = 0, nranks = 0;
+};
+
+static void* shm_map(const std::string& nm, uint64_t bytes, bool create) {
+  int fd = shm_open(nm.c_str(), create ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+  if (fd < 0) return nullptr;
+  if (create && ftruncate(fd, (off_t)bytes) != 0) { close(fd); return nullptr; }
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  return p == MAP_FAILED ? nullptr : p;
+}
+
+static int shm_barrier(ocn_ctx* c, ShmWorld* w) {
+  const int g = w->ctl->gen.load(std::memory_order_acquire);
+  if (w->ctl->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == w->nranks) {
+    w->ctl->arrived.store(0, std::memory_order_relaxed);
+    w->ctl->gen.store(g + 1, std::memory_order_release);
+    return OCN_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  long spins = 0;
+  while (w->ctl->gen.load(std::memory_order_acquire) == g) {
+    if (++spins > 2000) usleep(50); else sched_yield();
+    if ((spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) {
+      ocn_set_error(c, "shm transport: rank %d waited 300 s at a barrier (a peer died or the ranks' call sequences differ)", w->rank);
+      return OCN_ESTATE;
+    }
+  }
+  return OCN_OK;
+}
+
+static int shm_grow_own(ocn_ctx* c, ShmWorld* w, uint64_t need) {
+  if (need <= w->mapped[w->rank]) return OCN_OK;
+  uint64_t cap = w->mapped[w->rank] ? w->mapped[w->rank] : (1u << 20);
+  while (cap < need) cap *= 2;
+  if (w->box[w->rank]) munmap(w->box[w->rank], w->mapped[w->rank]);
+  w->box[w->rank] = shm_map(w->name + "." + std::to_string(w->rank), cap, true);
+  if (!w->box[w->rank]) {
+    ocn_set_error(c, "shm transport: cannot size the outbox to %llu bytes", (unsigned long long)cap);
+    return OCN_ENOMEM;
+  }
+  w->mapped[w->rank] = cap;
+  w->ctl->box_bytes[w->rank].store(cap, std::memory_order_release);
+  return OCN_OK;
+}
+
+static int shm_init(ocn_ctx* c, const char* name, int rank, int nranks) {
+  if (nranks > SHM_MAXR) {
+    ocn_set_error(c, "shm transport supports up to %d ranks", SHM_MAXR);
+    return OCN_EUNSUPPORTED;
+  }
+  ShmWorld* w = new ShmWorld;
+  w->name = name;
+  w->rank = rank;
+  w->nranks = nranks;
+  w->ctl = (ShmCtl*)shm_map(w->name + ".ctl", sizeof(ShmCtl), true);
+  if (!w->ctl) {
+    ocn_set_error(c, "shm transport: cannot open %s.ctl", name);
+    delete w;
+    return OCN_ESTATE;
+  }
+  c->shm = w;
+  int rc = shm_grow_own(c, w, sizeof(ShmBox) + (1u << 20));
+  if (rc) return rc;
+  return shm_barrier(c, w);            // every outbox exists before anyone opens a peer's
+}
+
+static void* shm_peer_box(ocn_ctx* c, ShmWorld* w, int p) {
+  const uint64_t cur = w->ctl->box_bytes[p].load(std::memory_order_acquire);
+  if (cur != w->mapped[p]) {
+    if (w->box[p]) munmap(w->box[p], w->mapped[p]);
+    w->box[p] = shm_map(w->name + "." + std::to_string(p), cur, false);
+    w->mapped[p] = w->box[p] ? cur : 0;
+    if (!w->box[p]) ocn_set_error(c, "shm transport: cannot map the outbox of rank %d", p);
+  }
+  return w->box[p];
+}
+
+static int shm_copy(ocn_ctx* c, void* dst, const void* src, size_t n, int to_host) {
+#ifndef OCN_HOST_EMU
+  OCN_HIP_CHECK(c, hipMemcpy(dst, src, n, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice));
+#else
+  memcpy(dst, src, n);
+#endif
+  return OCN_OK;
+}
+
+static int shm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs) {
+  ShmWorld* w = (ShmWorld*)c->shm;
+  int rc;
+  uint64_t need = sizeof(ShmBox);
+  int nmsg = 0;
+  for (const CommOp& s : sends)
+    if (s.peer != c->rank) { need += (s.bytes + 63) & ~(uint64_t)63; ++nmsg; }
+  if (nmsg > SHM_MAXMSG) {
+    ocn_set_error(c, "shm transport: %d messages in one exchange (max %d)", nmsg, SHM_MAXMSG);
+    return OCN_EUNSUPPORTED;
+  }
+  if ((rc = shm_grow_own(c, w, need))) return rc;
+#ifndef OCN_HOST_EMU
+  OCN_HIP_CHECK(c, hipStreamSynchronize(c->stream));   // the kernels that produced the send buffers
+#endif
+  ShmBox* mine = (ShmBox*)w->box[c->rank];
+  uint64_t off = sizeof(ShmBox);
+  mine->nmsg = 0;
+  for (const CommOp& s : sends) {
+    if (s.peer == c->rank) continue;
+    mine->msg[mine->nmsg++] = ShmMsg{s.peer, s.tag, (uint64_t)s.bytes, off};
+    if ((rc = shm_copy(c, (char*)mine + off, s.buf, s.bytes, 1))) return rc;
+    off += (s.bytes + 63) & ~(uint64_t)63;
+  }
+  if ((rc = shm_barrier(c, w))) return rc;
+  std::vector<int> taken(c->nranks, 0);
+  for (const CommOp& r : recvs) {
+    if (r.peer == c->rank) continue;
+    const ShmBox* from = (const ShmBox*)shm_peer_box(c, w, r.peer);
+    if (!from) return OCN_ESTATE;
+    int seen = 0;
+    const ShmMsg* match = nullptr;
+    for (uint32_t q = 0; q < from->nmsg; ++q)
+      if (from->msg[q].peer == c->rank && seen++ == taken[r.peer]) { match = &from->msg[q]; break; }
+    ++taken[r.peer];
+    if (!match || match->tag != r.tag || match->bytes != r.bytes) {
+      ocn_set_error(c, "shm comm: receive #%d from rank %d (tag %d, %zu B) pairs with %s (tag %d, %zu B)",
+                    taken[r.peer] - 1, r.peer, r.tag, r.bytes, match ? "send" : "nothing",
+                    match ? match->tag : -1, match ? (size_t)match->bytes : (size_t)0);
+      return OCN_ESTATE;
+    }
+    if ((rc = shm_copy(c, r.buf, (const char*)from + match->off, r.bytes, 0))) return rc;
+  }
+  for (int p = 0; p < c->nranks; ++p) {
+    if (p == c->rank) continue;
+    const ShmBox* from = (const ShmBox*)shm_peer_box(c, w, p);
+    if (!from) return OCN_ESTATE;
+    int posted = 0;
+    for (uint32_t q = 0; q < from->nmsg; ++q) posted += (from->msg[q].peer == c->rank);
+    if (posted != taken[p]) {
+      ocn_set_error(c, "shm comm: rank %d posted %d sends to rank %d, which receives %d", p, posted, c->rank, taken[p]);
+      return OCN_ESTATE;
+    }
+  }
+  return shm_barrier(c, w);            // nobody overwrites an outbox that is still being read
+}
+
+static void shm_destroy(ocn_ctx* c) {
+  ShmWorld* w = (ShmWorld*)c->shm;
+  if (!w) return;
+  for (int p = 0; p < SHM_MAXR; ++p)
+    if (w->box[p]) munmap(w->box[p], w->mapped[p]);
+  shm_unlink((w->name + "." + std::to_string(w->rank)).c_str());
+  if (w->ctl) munmap(w->ctl, sizeof(ShmCtl));
+  if (w->rank == 0) shm_unlink((w->name + ".ctl").c_str());
+  delete w;
+  c->shm = nullptr;
+}
+
 extern "C" {
 
 int ocn_comm_unique_id(void* out128) {
   if (!out128) return OCN_EINVAL;
+  const char* tr = getenv("OCNHIP_TRANSPORT");
+  bool shm = tr && strcmp(tr, "shm") == 0;
+#ifdef OCN_HOST_EMU
+  shm = true;
+#endif
+  if (shm) {   // the name of the mailbox segments; unique per job
+    memset(out128, 0, 128);
+    const auto now = std::chrono::steady_clock::now().time_since_epoch().count();
+    snprintf((char*)out128, 128, "SHM:/ocnhip_%d_%llx", (int)getpid(), (unsigned long long)now);
+    return OCN_OK;
+  }
 #ifndef OCN_HOST_EMU
   ncclUniqueId id;
   if (ncclGetUniqueId(&id) != ncclSuccess) {
@@ -54,8 +251,6 @@ int ocn_comm_unique_id(void* out128) {
   }
   static_assert(sizeof(id) == 128, "unexpected ncclUniqueId size");
   memcpy(out128, &id, 128);
-#else
-  memset(out128, 0, 128);
 #endif
   return OCN_OK;
 }
@@ -66,6 +261,12 @@ int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* id128) {
   ctx->nranks = nranks;
   if (nranks == 1) return OCN_OK;
   if (!id128) return OCN_EINVAL;
+  if (strncmp((const char*)id128, "SHM:", 4) == 0) {
+    char nm[128];
+    memcpy(nm, (const char*)id128 + 4, 124);
+    nm[123] = 0;
+    return shm_init(ctx, nm, rank, nranks);
+  }
 #ifndef OCN_HOST_EMU
   ncclUniqueId id;
   memcpy(&id, id128, 128);
@@ -96,8 +297,13 @@ int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vecto
         if (s.peer == c->rank && s.tag == r.tag)
           OCN_HIP_CHECK(c, hipMemcpyAsync(r.buf, s.buf, r.bytes, hipMemcpyDeviceToDevice, st));
   if (c->nranks == 1) return OCN_OK;
+  if (c->shm) return shm_exchange(c, sends, recvs);
 #ifndef OCN_HOST_EMU
   ncclComm_t comm = (ncclComm_t)c->comm;
+  if (!comm) {
+    ocn_set_error(c, "comm_exchange on %d ranks without a communicator (ocn_comm_init failed or was not called)", c->nranks);
+    return OCN_ESTATE;
+  }
   NCCL_OK(c, ncclGroupStart());
   for (const CommOp& s : sends)
     if (s.peer != c->rank) NCCL_OK(c, ncclSend(s.buf, s.bytes, ncclChar, s.peer, comm, st));
@@ -206,6 +412,7 @@ int comm_halo_exchange_y(ocn_model* m, Field** fs, int n) {
     hipFree(m->ypack_s);
     hipFree(m->ypack_r);
     m->ypack_s = m->ypack_r = nullptr;
+    m->ypack_n = 0;
     if (hipMalloc((void**)&m->ypack_s, need * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&m->ypack_r, need * sizeof(double)) != hipSuccess) {
       ocn_set_error(c, "y-slab halo staging allocation failed");
@@ -254,6 +461,7 @@ int comm_alltoall(ocn_ctx* c, const void* send, void* recv, size_t block_bytes) 
 }
 
 void comm_destroy(ocn_ctx* c) {
+  shm_destroy(c);
 #ifndef OCN_HOST_EMU
   if (c->comm) ncclCommDestroy((ncclComm_t)c->comm);
 #endif

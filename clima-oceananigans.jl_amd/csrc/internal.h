@@ -26,6 +26,7 @@ struct ocn_ctx {
   // multi-GPU
   int rank = 0, nranks = 1;
   void* comm = nullptr;  // ncclComm_t
+  void* shm = nullptr;   // ShmWorld: host shared-memory transport (tests / rehearsals on one GPU or none), comm.hip
 };
 
 void ocn_set_error(ocn_ctx* ctx, const char* fmt, ...);
@@ -110,7 +111,14 @@ struct ocn_model {
   double *ypack_s = nullptr, *ypack_r = nullptr;   // y-slab halo exchange staging (send / receive)
   size_t ypack_n = 0;
   bool gn_alias_gm = false; // after a fused AB2 step G^n and G^- are the same buffer (pointer swap instead of a copy)
+  // Bounded-z tiled path: between the time-stepper update and the projection the predictor U* lives in us / vs / ws;
+  // the projection writes u = U* - dt grad p back into u, v, w, so their device pointers never change.
+  bool pred_active = false;
+  ocn_grid* own_grid = nullptr;   // private copy of the caller's grid when the advection scheme needs wider halos
 };
+inline Field& pred_u(ocn_model* m) { return m->pred_active ? m->us : m->u; }
+inline Field& pred_v(ocn_model* m) { return m->pred_active ? m->vs : m->v; }
+inline Field& pred_w(ocn_model* m) { return m->pred_active ? m->ws : m->w; }
 
 Field* model_field(ocn_model* m, int id);
 

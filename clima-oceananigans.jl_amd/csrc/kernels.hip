@@ -552,29 +552,32 @@ __global__ void k_rhs(GridDev g, const double* __restrict__ u, const double* __r
 void launch_rhs(ocn_model* m, double dt, double* rhs, int mult_dz) {
   ProfScope ps(m->ctx, "rhs");
   dim3 b(64, 4, 1);
-  ocn_launch(k_rhs, grid3(m->gd, b), b, m->ctx->stream, m->gd, (const double*)m->u.interior(),
-             (const double*)m->v.interior(), (const double*)m->w.interior(), 1.0 / dt, mult_dz, rhs);
+  ocn_launch(k_rhs, grid3(m->gd, b), b, m->ctx->stream, m->gd, (const double*)pred_u(m).interior(),
+             (const double*)pred_v(m).interior(), (const double*)pred_w(m).interior(), 1.0 / dt, mult_dz, rhs);
 }
 
 // ---- projection (pressure_correction.jl:34-40) -----------------------------------------------------------------
-__global__ void k_pcorrect(GridDev g, const double* __restrict__ p, double dt, double* __restrict__ u,
-                           double* __restrict__ v, double* __restrict__ w) {
+// us, vs, ws: the predictor (the same arrays as u, v, w, or the separate predictor buffers of the tiled Bounded-z path)
+__global__ void k_pcorrect(GridDev g, const double* __restrict__ p, double dt, const double* us, const double* vs,
+                           const double* ws, double* u, double* v, double* w) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long c = i + j * g.sy + k * g.sz;
   double pc = p[c];
-  u[c] -= (pc - p[c - 1]) * g.rdx * dt;
-  v[c] -= (pc - p[c - g.sy]) * g.rdy * dt;
-  if (!g.zflat) w[c] -= (pc - p[c - g.sz]) / g_dzf(g, k) * dt;
+  u[c] = us[c] - (pc - p[c - 1]) * g.rdx * dt;
+  v[c] = vs[c] - (pc - p[c - g.sy]) * g.rdy * dt;
+  if (!g.zflat) w[c] = ws[c] - (pc - p[c - g.sz]) / g_dzf(g, k) * dt;
 }
 
 void launch_pcorrect(ocn_model* m, double dt) {
   ProfScope ps(m->ctx, "pcorrect");
   dim3 b(64, 4, 1);
   ocn_launch(k_pcorrect, grid3(m->gd, b), b, m->ctx->stream, m->gd, (const double*)m->pNHS.interior(), dt,
+             (const double*)pred_u(m).interior(), (const double*)pred_v(m).interior(), (const double*)pred_w(m).interior(),
              m->u.interior(), m->v.interior(), m->w.interior());
+  m->pred_active = false;   // u, v, w hold the corrected velocities again
 }
 
 // ---- hydrostatic pressure anomaly (update_hydrostatic_pressure.jl:10-18) ---------------------------------------

@@ -49,7 +49,9 @@ OCN_DEVFN double fast_rcp(double x) {
 #ifndef OCN_HOST_EMU
   double r = __builtin_amdgcn_rcp(x);
   r = fma(fma(-x, r, 1.0), r, r);
+#if !defined(OCN_RCP_NR) || OCN_RCP_NR > 1
   r = fma(fma(-x, r, 1.0), r, r);
+#endif
   return r;
 #else
   return 1.0 / x;
@@ -80,31 +82,37 @@ OCN_DEVFN double recon5(double A3, double A2, double A1, double A0, double B1, b
     const double u0 = fma(-s2, pos ? e3 : e4, t0);   // pos: e4 - 3 e3 = 3A1-4A0+B1 ; neg: 3 e4 - e3 = A1-4A0+3B1
     const double u1 = e2 + e3;                       // (A0 - A2); enters squared
     const double u2 = fma(s2, pos ? e2 : e1, t2);    // pos: 3 e2 - e1 = A3-4A2+3A1 ; neg: e2 - 3 e1 = 3A3-4A2+A1
-    const double eps = 1e-6;
-    // d_k = beta_k + eps = 13/12 t^2 + (1/4 u^2 + eps)
-    const double d0 = fma(13.0 / 12.0, t0 * t0, fma(0.25, u0 * u0, eps));
-    const double d1 = fma(13.0 / 12.0, t1 * t1, fma(0.25, u1 * u1, eps));
-    const double d2 = fma(13.0 / 12.0, t2 * t2, fma(0.25, u2 * u2, eps));
-    // p_k - A1
-    const double p0 = fma(2.0 / 3.0, e3, (-1.0 / 6.0) * e4);
-    const double p1 = fma(1.0 / 3.0, e3, (1.0 / 6.0) * e2);
-    const double p2 = fma(5.0 / 6.0, e2, (-1.0 / 3.0) * e1);
+    // d_k = 12/13 (beta_k + eps) = t^2 + 3/13 u^2 + 12/13 eps.  Only ratios of the (beta_k + eps) enter the
+    // normalised weights (Z: tau / (beta_k + eps); JS: their squares against each other), so the common factor
+    // drops out and each d_k is one product and two fused multiply-adds.
+    const double c3 = 3.0 / 13.0, eps = 1e-6 * (12.0 / 13.0);
+    const double d0 = fma(t0, t0, fma(u0 * c3, u0, eps));
+    const double d1 = fma(t1, t1, fma(u1 * c3, u1, eps));
+    const double d2 = fma(t2, t2, fma(u2 * c3, u2, eps));
+    // candidate values minus A1, times the optimal weights (3, 6, 1) [/10 cancels]:
+    //   3 p0 = 2 e3 - e4/2,  6 p1 = 2 e3 + e2,  p2 = 5/6 e2 - 1/3 e1
+    const double x3 = e3 + e3;
+    const double r0 = fma(-0.5, e4, x3);
+    const double r1 = x3 + e2;
+    const double r2 = fma(5.0 / 6.0, e2, (-1.0 / 3.0) * e1);
     const double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
+    const double P0 = q1 * q2, P1 = q0 * q2, P2 = q0 * q1;
     double a0, a1, a2;
     if (ADV == ADV_WENO_Z) {
-      // alpha_k = C_k (1 + (tau/d_k)^2) ~ C_k (q_k + tau^2) prod_{j != k} q_j   with C = (3, 6, 1)/10
-      const double tau = d2 - d0, tt = tau * tau, tt3 = 3.0 * tt;
-      a0 = fma(3.0, q0, tt3) * (q1 * q2);
-      a1 = fma(6.0, q1, tt3 + tt3) * (q0 * q2);
-      a2 = (q2 + tt) * (q0 * q1);
+      // alpha_k / C_k = 1 + (tau/d_k)^2 = (q_k + tau^2) / q_k  ~  Q + tau^2 P_k   with Q = q0 q1 q2, P_k = Q / q_k
+      const double tau = d2 - d0, tt = tau * tau, Q = q0 * P0;
+      a0 = fma(tt, P0, Q);
+      a1 = fma(tt, P1, Q);
+      a2 = fma(tt, P2, Q);
     } else {
-      // alpha_k = C_k / d_k^2
-      a0 = 3.0 * (q1 * q2);
-      a1 = 6.0 * (q0 * q2);
-      a2 = q0 * q1;
+      // alpha_k / C_k = 1 / d_k^2 ~ P_k
+      a0 = P0;
+      a1 = P1;
+      a2 = P2;
     }
-    const double num = fma(a0, p0, fma(a1, p1, a2 * p2));
-    return fma(num, fast_rcp(a0 + a1 + a2), A1);
+    const double num = fma(a0, r0, fma(a1, r1, a2 * r2));
+    const double den = fma(3.0, a0, fma(6.0, a1, a2));
+    return fma(num, fast_rcp(den), A1);
   }
 }
 

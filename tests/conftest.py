@@ -19,6 +19,9 @@ def pytest_configure(config):
     config._ocn_backend = "gpu" if use_gpu else "hostemu"
     if use_gpu:
         os.environ.pop("OCNHIP_LIB", None)
+        alt = os.environ.get("OCNHIP_TEST_LIB")      # kernel experiments: another GPU build of the same sources
+        if alt and "hostemu" not in alt:
+            os.environ["OCNHIP_LIB"] = os.path.abspath(alt)
     else:
         os.environ["OCNHIP_LIB"] = HOSTEMU
 
