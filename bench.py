@@ -5,12 +5,16 @@
 
 N = 1: BASELINE config 2 -- 256^3 triply-periodic RectilinearGrid, WENO5 (Z weights), AB2, Float64,
 no tracers; u, v, w ~ U[-0.5, 0.5) (PCG64 seed 1), projected by set!; fixed dt = 0.2 dx / max|u|.
-N > 1: one process per GPU (torch.distributed.run), z-slab decomposition of (256, 256, 256 N) --
-weak scaling, RCCL halo exchange + transposed FFT inside libocnhip.so.
+N > 1: one process per GPU, z-slab decomposition inside libocnhip.so (RCCL halo exchange, slab Poisson solver):
+    N = 2, 4 : the same 256^3 box cut into N slabs            (strong scaling of the metric's workload)
+    N = 8    : BASELINE config 4 -- 512 x 512 x 256 in z-slabs of 32 (dx = dy = dz = 1/512)
+    --scaling weak : 256 x 256 x 256 N instead.
+Started without WORLD_SIZE (plain `python bench.py --gpus N`), this process only spawns the N ranks -- before
+anything touches a GPU -- and relays rank 0's line; under torch.distributed.run it is one of the ranks.
 
 One JSON line is printed by rank 0.  `value` is whole-job cell-updates/s with all inputs resident in
 HBM when the timed region starts.  `roofline` is for the dominant kernel (measured live with HIP
-events on the library's stream); `cpu_baseline` is the NumPy oracle timed on this host (rank 0, N = 1).
+events on the library's stream); `cpu_baseline` is the CPU restatement timed on this host (rank 0, N = 1).
 """
 import argparse
 import json
@@ -23,15 +27,69 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TRAFFIC_FILE = "r01_traffic.json"
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 # algorithmic bytes per cell: whole AB2 step and per phase
-B_ALG_STEP = 336.0
+B_ALG_STEP = 336.0          # config 2 / 4: AB2, no tracers; +49 per passive tracer; RK3 = 3 stages
+B_ALG_TRACER = 49.0
+B_ALG_STAGE_C3 = 508.0      # config 3 per RK3 stage (SURVEY.md 8d estimate, frozen here): 1524 per step
+B_ALG_STAGE_C1 = 228.0      # config 1 per RK3 stage: 2-D, u and v only (tendencies 32, updates 64, halos 4, rhs 24,
+                            # r2c transforms fwd + inv over 2 axes 64, projection 40): 684 per step
+
+
+def alg_bytes_per_cell_update(args):
+    if args.config == 3:
+        return 3 * B_ALG_STAGE_C3
+    if args.config == 1:
+        return 3 * B_ALG_STAGE_C1
+    per = B_ALG_STEP + B_ALG_TRACER * args.tracers
+    return per * (3 if args.stepper.upper() in ("RK3", "RUNGEKUTTA3") else 1)
+
 B_ALG_PHASE = {"tendencies": 48.0, "step": 96.0, "rhs": 32.0, "fft_forward": 48.0, "spectral_solve": 16.0,
                "fft_backward": 48.0, "pcorrect": 56.0, "fused_tendency_step": 96.0, "poisson_fused": 80.0}
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """oracle (NumPy restatement of the reference algorithm) on a bounded sample of the same workload."""
+def cpu_baseline():
+    """CPU restatement of the reference's CPU() path on a bounded sample of the same workload (config 2: triply periodic
+    WENO5 AB2 + FFT Poisson), timed on this host: the C++/OpenMP restatement (oracle/cpu/ocn_cpu.cpp) with one thread
+    at 128^3 and with every available core at 256^3, and the NumPy oracle at 64^3.  About 20 s in all."""
+    import ctypes as C
+    import subprocess
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    out = {"unit": "cell-updates/s", "kind": "port", "cpu_model": model, "host_cores": cores}
+    lib = os.path.join(ROOT, "oracle", "cpu", "libocn_cpu.so")
+    try:
+        if not os.path.exists(lib):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        L = C.CDLL(lib)
+        PD = C.POINTER(C.c_double)
+        L.ocncpu_run.restype = C.c_int
+        L.ocncpu_run.argtypes = [C.c_int] * 3 + [C.c_double] * 3 + [PD] * 4 + [C.c_double, C.c_int, C.c_int, PD]
+
+        def run(n, threads, steps):
+            rng = np.random.default_rng(1)
+            a = [np.asfortranarray(rng.random((n, n, n)) - 0.5) for _ in range(3)]
+            secs = C.c_double()
+            rc = L.ocncpu_run(n, n, n, 1.0, 1.0, 1.0, a[0].ctypes.data_as(PD), a[1].ctypes.data_as(PD), a[2].ctypes.data_as(PD),
+                              None, 0.2 / n / 0.5, steps, threads, C.byref(secs))
+            if rc:
+                raise RuntimeError(f"ocncpu_run returned {rc}")
+            return n ** 3 * steps / secs.value
+        one = run(128, 1, 2)
+        allc = run(256, cores, 4) if cores > 1 else one
+        out.update({"value": allc, "cores": cores,
+                    "sample": f"4 AB2 WENO5 steps at 256^3 (the whole workload), C++/OpenMP restatement, {cores} threads",
+                    "single_core": {"value": one, "cores": 1, "sample": "2 steps at 128^3, same code, 1 thread"}})
+    except Exception as e:   # noqa: BLE001 -- the baseline is a reported extra; the bench line must still be printed
+        out.update({"value": None, "cores": 0, "sample": f"C++ restatement unavailable: {e!r}"})
     import oracle as O
     n = 64
     N = (n, n, n)
@@ -43,12 +101,13 @@ def cpu_baseline(seconds_budget=20.0):
     O.time_step(m, dt)   # warm-up (Euler step)
     t0 = time.perf_counter()
     steps = 0
-    while steps < 3 or (time.perf_counter() - t0 < seconds_budget and steps < 40):
+    while steps < 3 or (time.perf_counter() - t0 < 4.0 and steps < 12):
         O.time_step(m, dt)
         steps += 1
     el = time.perf_counter() - t0
-    return {"value": n ** 3 * steps / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{steps} AB2 WENO5 steps at {n}^3 (same workload, 1/64 of the cells), NumPy oracle"}
+    out["numpy_oracle"] = {"value": n ** 3 * steps / el, "cores": 1, "sample": f"{steps} steps at {n}^3, NumPy oracle"}
+    out["reference_published"] = {"value": 8.58e5, "note": "single-core Julia CPU() at 256^3, other host (BASELINE.md); context only"}
+    return out
 
 
 def build_config3(ocn, ctx, args):
@@ -97,12 +156,55 @@ def build_config1(ocn, ctx, args):
     return model, 0.2 * (2 * np.pi / Nx) / 4.0, (Nx, Ny, 1), (Nx, Ny, 1)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has not
+    touched a GPU and never will), relay rank 0's JSON line, exit non-zero if any rank fails."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.rehearse_hostemu:
+        import torch
+        have = torch.cuda.device_count()          # does not initialise the GPU
+        ndev = int(os.environ.get("OCNHIP_BENCH_NDEV", "0"))
+        if have < n and not (ndev and os.environ.get("OCNHIP_TRANSPORT") == "shm"):
+            raise SystemExit(f"bench.py: --gpus {n} but this node shows {have} GPU(s); nothing was measured "
+                             "(rehearse ranks on fewer GPUs with OCNHIP_TRANSPORT=shm OCNHIP_BENCH_NDEV=<gpus>)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("OCNHIP_BENCH_TIMEOUT", "1500"))
+    alive = list(procs)
+    while alive:
+        for pr in list(alive):
+            code = pr.poll()
+            if code is not None:
+                alive.remove(pr)
+                rc = rc or code
+        if alive and (rc or time.time() > deadline):   # a rank failed (or hung): stop exactly the children started here
+            for pr in alive:
+                pr.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    for pr in procs:
+        pr.wait()
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--size", type=int, nargs=3, default=None, help="override per-GPU size (debug)")
+    ap.add_argument("--size", type=int, nargs=3, default=None, help="override the GLOBAL size (debug)")
     ap.add_argument("--stepper", default="AB2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tracers", type=int, default=0, help="passive tracers (config 2b: 1)")
@@ -110,16 +212,28 @@ def main():
     ap.add_argument("--topology", default="PPP", help="config 2 with other x/y/z topologies, e.g. PBB (debug / widening rows)")
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (headline, default), 1 (2-D turbulence) or 3 (ocean LES)")
     ap.add_argument("--lib", default=None, help="another build of libocnhip.so (kernel experiments; never the host emulation)")
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
+                    help="N > 1: strong = 256^3 on 2 / 4 GPUs and config 4 (512x512x256) on 8; weak = 256x256x256N")
+    ap.add_argument("--init", default="random", choices=("random", "smooth"),
+                    help="config 2 initial velocities: U[-0.5,0.5) per cell (SURVEY 8d, the metric) or a smooth sign-coherent field")
+    ap.add_argument("--rehearse-hostemu", action="store_true",
+                    help="plumbing rehearsal on the host emulation of the kernels (CPU only, tiny grid): NOT a measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)           # never returns
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     os.environ.pop("OCNHIP_LIB", None)      # the product library only
-    if args.lib:
+    if args.rehearse_hostemu:
+        os.environ["OCNHIP_LIB"] = os.path.join(ROOT, "tests", "hostemu", "libocnhip_hostemu.so")
+        args.no_cpu_baseline = True
+    elif args.lib:
         if "hostemu" in args.lib:
             raise SystemExit("--lib is for GPU builds of the library only")
         os.environ["OCNHIP_LIB"] = os.path.abspath(args.lib)
@@ -133,26 +247,47 @@ def main():
         dist = dist_
         dist.init_process_group("gloo")     # rendezvous / barriers / max-reduce only; data path is RCCL in the library
 
-    n = tuple(args.size) if args.size else (256, 256, 256)
-    ndev = int(os.environ.get("OCNHIP_BENCH_NDEV", "0"))     # rehearsal on fewer GPUs than ranks (debug only)
-    ctx = ocn.Context(local_rank % ndev if ndev else local_rank)
+    ndev = int(os.environ.get("OCNHIP_BENCH_NDEV", "0"))     # rehearsal on fewer GPUs than ranks (shm transport only)
+    ctx = ocn.Context(0 if args.rehearse_hostemu else (local_rank % ndev if ndev else local_rank))
     if world > 1:
         from importlib import import_module
         par = import_module("ocnhip.parallel")
         par.init_comm(ctx, dist, rank, world)
-    Nglobal = (n[0], n[1], n[2] * world)
+    # global grid: the library cuts triply periodic grids into z-slabs (Nz / world levels per rank) and
+    # (Periodic, Periodic, Bounded) grids into y-slabs
+    if args.size:
+        Nglobal = tuple(args.size)
+    elif args.rehearse_hostemu:
+        Nglobal = (16, 16, 8 * world)
+    elif world > 1 and args.scaling == "weak":
+        Nglobal = (256, 256, 256 * world)
+    elif world == 8:
+        Nglobal = (512, 512, 256)           # BASELINE config 4
+    else:
+        Nglobal = (256, 256, 256)
+    extent = tuple(float(x) / Nglobal[0] for x in Nglobal)    # cubic cells, x extent 1
     if args.config == 3:
         model, dt3, Nglobal, n = build_config3(ocn, ctx, args)
     elif args.config == 1:
         model, dt3, Nglobal, n = build_config1(ocn, ctx, args)
     else:
         topo = tuple({"P": "Periodic", "B": "Bounded"}[c] for c in args.topology.upper())
-        grid = ocn.RectilinearGrid(ctx, size=Nglobal, extent=(1, 1, float(world)), topology=topo)
+        grid = ocn.RectilinearGrid(ctx, size=Nglobal, extent=extent, topology=topo)
         tnames = tuple(f"c{i}" for i in range(args.tracers))
         closure = ocn.ScalarDiffusivity(nu=args.nu, kappa=args.nu) if args.nu else None
         model = ocn.NonhydrostaticModel(grid, advection=ocn.WENO5(), timestepper=args.stepper, tracers=tnames, closure=closure)
+        n = model.u.size                   # this rank's slab
         rng = np.random.default_rng(1 + rank)
-        init = dict(u=rng.random(model.u.size) - 0.5, v=rng.random(model.v.size) - 0.5, w=rng.random(model.w.size) - 0.5)
+        if args.init == "smooth":
+            # sign-coherent velocities (what resolved flows look like): a few Fourier modes, amplitude 0.5
+            X, Y, Z = model.nodes("u")
+            off = rank * n[2] * extent[2] / Nglobal[2]
+            two_pi = 2 * np.pi
+            init = dict(u=0.5 * np.sin(two_pi * X) * np.cos(two_pi * Y) + 0 * Z,
+                        v=-0.5 * np.cos(two_pi * X) * np.sin(two_pi * Y) + 0 * Z,
+                        w=0.25 * np.sin(two_pi * (Z + off) / extent[2]) + 0 * X + 0 * Y)
+        else:
+            init = dict(u=rng.random(model.u.size) - 0.5, v=rng.random(model.v.size) - 0.5, w=rng.random(model.w.size) - 0.5)
         init.update({t: rng.random(model.tracers[t].size) for t in tnames})
         ocn.set_model(model, **init)
     umax = np.abs(model.u.interior()).max()
@@ -161,7 +296,7 @@ def main():
         t = torch.tensor([umax], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         umax = float(t[0])
-    dt = 0.2 * (1.0 / n[0]) / umax
+    dt = 0.2 * (extent[0] / Nglobal[0]) / umax
     if args.config != 2:
         dt = dt3
 
@@ -173,7 +308,9 @@ def main():
     # The card needs ~40 ms of load to leave its idle clocks (a 5-step run of config 2 measures 1.52 ms/step, a 200-step
     # run 1.32): untimed spin-up steps run until 80 ms of stepping have passed (none if the warm-up already covers that).
     spinup = 0
-    if world > 1:
+    if args.rehearse_hostemu:
+        pass
+    elif world > 1:
         for _ in range(40):            # every step is collective: all ranks must run the same number of them
             ocn.time_step(model, dt)
         spinup = 40
@@ -237,24 +374,34 @@ def main():
     roofline = None
     if dom:
         ach = B_ALG_PHASE[dom] * cells_local / (cand[dom]["avg_ms"] * 1e-3)
-        traffic = None
-        try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, calibrated; see profiles/)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if world == 1 and args.config == 2 and not args.size and dom in tj["kernels"]:
+        traffic, traffic_source = None, None
+        try:   # HBM bytes per launch are NOT measured in this run: they come from the committed rocprofv3 --pmc passes
+            tname = TRAFFIC_FILE
+            tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
+            if world == 1 and args.config == 2 and not args.size and args.tracers == 0 and dom in tj["kernels"]:
                 traffic = tj["kernels"][dom]["traffic_bytes_per_launch"]
+                traffic_source = f"profiles/{tname} (separate FETCH_SIZE / WRITE_SIZE passes of the same command)"
         except Exception:
             traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK, "traffic": traffic,
+                    "frac": ach / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
                     "alg_bytes_per_launch": B_ALG_PHASE[dom] * cells_local, "avg_launch_ms": cand[dom]["avg_ms"],
                     "launches_timed": cand[dom]["launches"], "measured_in": "timed region" if timed else "warm-up"}
-    step_frac = value / world * B_ALG_STEP / HBM_PEAK
+    b_alg = alg_bytes_per_cell_update(args)
+    step_frac = value / world * b_alg / HBM_PEAK
+    copy_rate = None
+    if rank == 0 and not args.rehearse_hostemu:
+        try:
+            copy_rate = ctx.copy_rate(1 << 30, 20)      # measured D2D copy ceiling of this GPU (read + write bytes / s)
+        except Exception:   # noqa: BLE001
+            copy_rate = None
 
     if rank == 0:
         out = {
             "metric": "cell-updates/sec per time_step!, 256^3 Nonhydrostatic WENO5", "value": value,
             "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": spinup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if not args.rehearse_hostemu else "rehearsal on the host emulation of the kernels: plumbing check, NOT a measurement",
             "config": {"workload": (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} "
                                     + ("triply-periodic" if args.topology.upper() == "PPP" else f"topology {args.topology.upper()}")
                                     + " RectilinearGrid, "
@@ -265,9 +412,12 @@ def main():
                         "ScalarDiffusivity (BASELINE config 1)") if args.config == 1 else
                        (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} (Periodic,Periodic,Bounded) stretched z, WENO5, RK3, T+S, "
                         "FPlane, linear EOS, AMD, flux/gradient BCs, Fourier-tridiagonal Poisson (BASELINE config 3)"),
-                       "decomposition": f"{'y' if args.config == 3 else 'z'}-slabs x{world}", "dt": dt},
+                       "decomposition": f"{'y' if args.config == 3 else 'z'}-slabs x{world}", "dt": dt, "init": args.init,
+                       "local_size": list(n), "transport": ("shm" if args.rehearse_hostemu else os.environ.get("OCNHIP_TRANSPORT", "rccl")) if world > 1 else None},
             "roofline": roofline,
-            "step_roofline": {"alg_bytes_per_cell_update": B_ALG_STEP, "frac_of_hbm_peak": step_frac},
+            "step_roofline": {"alg_bytes_per_cell_update": b_alg, "frac_of_hbm_peak": step_frac,
+                              "measured_copy_rate_GBps": copy_rate / 1e9 if copy_rate else None,
+                              "frac_of_measured_copy_rate": value / world * b_alg / copy_rate if copy_rate else None},
             "phases_ms_warmup": {k: round(v["avg_ms"], 4) for k, v in phases.items()},
             "max_abs_divergence": div,
         }

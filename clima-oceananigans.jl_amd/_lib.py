@@ -107,6 +107,7 @@ def load():
         "ocn_profile_read": (I, [P, C.c_char_p, PD, C.POINTER(C.c_int64)]),
         "ocn_profile_reset": (I, [P]),
         "ocn_profile_filter": (I, [P, C.c_char_p]),
+        "ocn_measure_copy_rate": (I, [P, C.c_size_t, I, PD]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = the library does not export what the header declares

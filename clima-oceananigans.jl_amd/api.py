@@ -112,6 +112,12 @@ class Context:
     def profile_reset(self):
         check(self.lib.ocn_profile_reset(self.h), self.h)
 
+    def copy_rate(self, nbytes=1 << 30, reps=20):
+        """measured device-to-device copy rate [B/s, read + write]"""
+        out = C.c_double()
+        check(self.lib.ocn_measure_copy_rate(self.h, int(nbytes), int(reps), C.byref(out)), self.h)
+        return out.value
+
     def profile_read(self, phase):
         ms, n = C.c_double(), C.c_int64()
         check(self.lib.ocn_profile_read(self.h, phase.encode(), C.byref(ms), C.byref(n)), self.h)

@@ -1013,6 +1013,38 @@ int ocn_max_abs_divergence(ocn_model* m, double* out) {
   return OCN_OK;
 }
 
+int ocn_measure_copy_rate(ocn_ctx* ctx, size_t bytes, int reps, double* bytes_per_s) {
+  if (!ctx || !bytes_per_s || bytes == 0 || reps < 1) return OCN_EINVAL;
+  char *a = nullptr, *b = nullptr;
+  OCN_HIP_CHECK(ctx, hipMalloc((void**)&a, bytes));
+  if (hipMalloc((void**)&b, bytes) != hipSuccess) {
+    hipFree(a);
+    ocn_set_error(ctx, "ocn_measure_copy_rate: allocation of %zu bytes failed", bytes);
+    return OCN_ENOMEM;
+  }
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipMemsetAsync(a, 1, bytes, ctx->stream);
+  hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, ctx->stream);   // warm-up
+  hipEventRecord(e0, ctx->stream);
+  for (int r = 0; r < reps; ++r) hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+  hipEventRecord(e1, ctx->stream);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipFree(a);
+  hipFree(b);
+  if (e != hipSuccess || !(ms > 0)) {
+    ocn_set_error(ctx, "ocn_measure_copy_rate: copy failed");
+    return OCN_EHIP;
+  }
+  *bytes_per_s = 2.0 * (double)bytes * reps / (ms * 1e-3);
+  return OCN_OK;
+}
+
 // ---- multi-GPU: ocn_comm_unique_id / ocn_comm_init live in comm.hip -----------------------------------------------
 int ocn_comm_rank(const ocn_ctx* ctx, int* rank, int* nranks) {
   if (!ctx) return OCN_EINVAL;

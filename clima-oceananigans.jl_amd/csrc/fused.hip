@@ -40,7 +40,15 @@ struct FusedArgs {
   int ntx, BXo;                   // x-tiled variant: tiles along x, output columns per tile
   int dbg_nobar;                  // timing experiments only (OCNHIP_DBG_NOBAR): results are wrong
   double nu;                      // ScalarDiffusivity viscosity (0: none); see the viscous-flux note in k_tend_step3
+#ifdef OCN_DIAG_STAMPS
+  unsigned long long* diag;       // diagnostic build only: per-wave cycle sums {barrier A, flux stage, barrier B, finalize}
+#endif
 };
+#ifdef OCN_DIAG_STAMPS
+#define STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(var)
+#endif
 
 OCN_DEVFN void sto(double* base, unsigned boff, double v) { *(double*)((char*)base + boff) = v; }
 
@@ -81,6 +89,9 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
   const long total = (long)a.ntiles * g.Nz;
   long lo = seg * total / nseg;
   const long hi = (seg + 1) * total / nseg;
+#ifdef OCN_DIAG_STAMPS
+  unsigned long long dA = 0, dF = 0, dB = 0, dZ = 0;
+#endif
   while (lo < hi) {
   const int ytile = (int)(lo / g.Nz);
   const int k0 = (int)(lo - (long)ytile * g.Nz);
@@ -152,7 +163,9 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
     const unsigned c = cxy + (unsigned)k * szb;
     const bool last = (k == k1);
     commit();
+    STAMP(t0);
     if (!(a.dbg_nobar & 2)) __syncthreads();
+    STAMP(t1);
     if (EARLY && !last) prefetch(k + 1);   // next level's slab in flight during the whole flux stage
     double gm0 = 0, gm1 = 0, gm2 = 0;      // G^- of the level finalized below, also fetched early
     double rs0 = 0, rs1 = 0, rs2 = 0;      // REST: the non-advective part of G^n waiting in the G^n arrays
@@ -274,7 +287,9 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
 #undef YSYM
 #undef XREC
 #undef YREC
+    STAMP(t2);
     if (!(a.dbg_nobar & 1)) __syncthreads();
+    STAMP(t3);
     if (!EARLY && !last) prefetch(k + 1);  // in flight during the (cheap) finalize stage; committed at the loop top
     if (full) {
       if (k > k0) {
@@ -325,8 +340,20 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
       zv[5] = ldo(a.v, c + 3 * szb);
       zw[5] = ldo(a.w, c + 3 * szb);
     }
+#ifdef OCN_DIAG_STAMPS
+    {
+      STAMP(t4);
+      dA += t1 - t0; dF += t2 - t1; dB += t3 - t2; dZ += t4 - t3;
+    }
+#endif
   }
   }  // segments
+#ifdef OCN_DIAG_STAMPS
+  if (a.diag && (tid & 63) == 0) {
+    unsigned long long* d = a.diag + ((size_t)blockIdx.x * (T / 64) + tid / 64) * 4;
+    d[0] = dA; d[1] = dF; d[2] = dB; d[3] = dZ;
+  }
+#endif
 #undef SLB
 }
 
@@ -1010,7 +1037,31 @@ static void fused_fill_args(ocn_model* m, FusedArgs& a, double dt, double cn, do
   a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
   a.dbg_nobar = getenv("OCNHIP_DBG_NOBAR") ? atoi(getenv("OCNHIP_DBG_NOBAR")) : 0;
   a.nu = 0.0;
+#ifdef OCN_DIAG_STAMPS
+  a.diag = nullptr;
+#endif
 }
+#ifdef OCN_DIAG_STAMPS
+// diagnostic build: where do the waves of the tendency kernel spend their cycles?  Printed once, after the 30th launch.
+static unsigned long long* g_diag = nullptr;
+static int g_diag_launches = 0;
+static void diag_report(hipStream_t s, int nblocks, int waves) {
+  if (++g_diag_launches != 30) return;
+  hipStreamSynchronize(s);
+  std::vector<unsigned long long> h((size_t)nblocks * waves * 4);
+  hipMemcpy(h.data(), g_diag, h.size() * 8, hipMemcpyDeviceToHost);
+  double sum[2][4] = {{0}}, n[2] = {0, 0};
+  for (int b = 0; b < nblocks; ++b)
+    for (int w = 0; w < waves; ++w) {
+      const int ghost = w >= waves - waves / 4;      // BY = 4: the last quarter of the waves is the ghost row
+      for (int q = 0; q < 4; ++q) sum[ghost][q] += (double)h[((size_t)b * waves + w) * 4 + q];
+      n[ghost] += 1;
+    }
+  for (int gq = 0; gq < 2; ++gq)
+    fprintf(stderr, "[diag] %s waves: barrier A %.0f  flux stage %.0f  barrier B %.0f  finalize+loop %.0f  (memtime ticks per wave per launch)\n",
+            gq ? "ghost-row" : "output-row", sum[gq][0] / n[gq], sum[gq][1] / n[gq], sum[gq][2] / n[gq], sum[gq][3] / n[gq]);
+}
+#endif
 
 // all-in-one path: triply periodic, no closure or ScalarDiffusivity
 void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m) {
@@ -1020,11 +1071,18 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
   a.nu = m->d.closure == OCN_CLOSURE_SCALAR ? m->d.nu : 0.0;
   const FusedShape f = fused_shape(m, a);
   hipStream_t s = m->ctx->stream;
+#ifdef OCN_DIAG_STAMPS
+  if (!g_diag) hipMalloc((void**)&g_diag, (size_t)f.grd.x * 16 * 4 * 8);
+  a.diag = g_diag;
+#endif
   if (a.nu != 0.0) {
     FUSED_BY_SCHEME(true, false, false)
   } else {
     FUSED_BY_SCHEME(false, false, false)
   }
+#ifdef OCN_DIAG_STAMPS
+  diag_report(s, f.grd.x, f.bx * f.by / 64);
+#endif
 }
 
 // ---- Bounded z: advection + time-stepper update of u, v, w on top of the general kernels' other terms ----------------

@@ -210,6 +210,9 @@ int ocn_profile_enable(ocn_ctx* ctx, int on);
 int ocn_profile_filter(ocn_ctx* ctx, const char* phase);
 int ocn_profile_read(ocn_ctx* ctx, const char* phase, double* avg_ms, int64_t* count);
 int ocn_profile_reset(ocn_ctx* ctx);
+/* measured device-to-device copy rate of this GPU: `reps` stream-ordered copies of `bytes` bytes, timed with HIP events;
+ * *bytes_per_s counts bytes read + bytes written (the second roofline denominator of BASELINE.md section 2) */
+int ocn_measure_copy_rate(ocn_ctx* ctx, size_t bytes, int reps, double* bytes_per_s);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,105 @@
+"""The library stepped by several PROCESSES (one per rank) against the single-domain oracle.
+
+CPU runs (`-m "not gpu"`): host emulation of the kernels + the host shared-memory transport of csrc/comm.hip, rendezvous
+over gloo with world_size 2 (and 3 for the y-slabs) -- the control flow of bench.py's multi-rank leg end to end,
+including `python bench.py --gpus 2` spawning its own ranks.
+GPU runs (`-m gpu`): the same workers on libocnhip.so, both ranks on the one GPU of the test box, transport shm.  Only
+the RCCL send/recv itself is then left to the multi-GPU node.
+Reference tests mirrored: test/test_distributed_models.jl:361-453,500-517, test_distributed_poisson_solvers.jl:68-117.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "_dist_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_world(case, backend, world, timeout=900, extra_env=None):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("OCNHIP_LIB", None)
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, WORKER, case, backend], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout)[0])
+    finally:
+        for p in procs:          # exactly the children started here
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} of {case} failed:\n{o[-3000:]}"
+
+
+CPU_CASES = [("zslab_ab2", 2, {}), ("zslab_ab2", 2, {"OCNHIP_DIST_SOLVER": "transpose"}), ("zslab_rk3_tracer", 2, {}),
+             ("poisson", 2, {}), ("poisson", 2, {"OCNHIP_DIST_SOLVER": "transpose"}), ("yslab_amd", 2, {}),
+             ("yslab_scalar", 3, {})]
+
+
+@pytest.mark.parametrize("case,world,env", CPU_CASES, ids=[f"{c}-{w}-{'-'.join(e.values()) or 'green'}" for c, w, e in CPU_CASES])
+def test_library_across_processes_hostemu(case, world, env, backend):
+    if backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    run_world(case, "hostemu", world, extra_env=env)
+
+
+def test_bench_spawns_its_ranks_hostemu(backend):
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself and reports n_gpus 2 (plumbing rehearsal on the
+    host emulation: the number it prints is not a measurement and says so)."""
+    if backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OCNHIP_LIB"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-hostemu", "--steps", "2",
+                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["config"]["decomposition"] == "z-slabs x2"
+    assert "NOT a measurement" in rec["data"]
+    assert rec["max_abs_divergence"] < 1e-10
+
+
+def test_bench_refuses_missing_gpus():
+    """--gpus N on a node with fewer GPUs exits non-zero instead of silently measuring one GPU"""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OCNHIP_TRANSPORT", "OCNHIP_BENCH_NDEV"):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.device_count() >= 64:
+        pytest.skip("a node with 64 GPUs")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0
+    assert "n_gpus" not in out.stdout
+
+
+GPU_CASES = [("zslab_ab2", {}), ("zslab_rk3_tracer", {"OCNHIP_DIST_SOLVER": "transpose"}), ("zslab_wide", {}),
+             ("yslab_amd", {}), ("poisson", {})]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,env", GPU_CASES, ids=[c for c, _ in GPU_CASES])
+def test_library_two_ranks_one_gpu(case, env):
+    """two processes, one MI355X, host shared-memory transport: slab kernels, pack / unpack, exchange order and the
+    distributed solvers of the product library against the single-domain oracle"""
+    run_world(case, "gpu", 2, extra_env=env)

@@ -175,3 +175,94 @@ def test_bitwise_reproducible(ocn, kind):
         out.append([m.u.parent(), m.v.parent(), m.w.parent(), m.pNHS.parent(), m.tracers["c"].parent()])
     for a, b in zip(*out):
         assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+# ---- slab code paths on ONE GPU: OCNHIP_FORCE_DIST=1 is read per grid creation (csrc/api.hip ocn_grid_create), so the
+# z-slab / y-slab kernels (k_zslab_*, k_pack_rows, k_yslab_*, fused_exchange_*) and both distributed solvers run on
+# hardware in the driver's `-m gpu` pass, exchanging with themselves, against the single-domain oracle.
+FORCED = ["ppp_weno_ab2", "ppp_weno_rk3_2tracers", "ppb_amd_config3", "ppb_weno_full", "regr_ocean_les_amd"]
+
+
+@pytest.mark.parametrize("solver", ["green", "transpose"])
+@pytest.mark.parametrize("name", [n for n in FORCED if n in CASES])
+def test_forced_slab_case_matches_oracle(ocn, name, solver, monkeypatch):
+    monkeypatch.setenv("OCNHIP_FORCE_DIST", "1")
+    monkeypatch.setenv("OCNHIP_DIST_SOLVER", solver)
+    worst = run_case(ocn, name)
+    bad = {k: v for k, v in worst.items() if v > CASES[name].get("tol", 2e-11)}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("forced", [False, True])
+def test_config4_slab_shape_vs_oracle(ocn, forced, monkeypatch):
+    """512 x 512 x 32: one z-slab of BASELINE config 4 (512 x 512 x 256 on 8 GPUs).  Two WENO5 AB2 steps against the oracle,
+    as a single periodic domain and through the slab code path (x-tiled tendency kernel, slab Poisson solver, plane
+    exchanges with itself)."""
+    import oracle as O
+    if forced:
+        monkeypatch.setenv("OCNHIP_FORCE_DIST", "1")
+    N = (512, 512, 32)
+    rng = np.random.default_rng(4)
+    init = {n: rng.random(N) - 0.5 for n in "uvw"}
+    kw = dict(size=N, extent=(1, 1, 32 / 512), topology=("Periodic",) * 3)
+    m = ocn.NonhydrostaticModel(ocn.RectilinearGrid(**kw), advection=ocn.WENO5())
+    om = O.NonhydrostaticModel(O.RectilinearGrid(**kw), advection=O.WENO5())
+    ocn.set_model(m, **init)
+    O.set_model(om, **init)
+    dt = 0.2 / 512 / np.abs(om.u.data).max()
+    for _ in range(2):
+        ocn.time_step(m, dt)
+        O.time_step(om, dt)
+    for a, b in ((m.u, om.u), (m.v, om.v), (m.w, om.w), (m.pNHS, om.pNHS)):
+        assert np.abs(a.parent() - b.data).max() <= 2e-11 * np.abs(b.data).max()
+    assert m.max_abs_divergence() <= 1e-9
+
+
+def test_config3_full_size_properties(ocn):
+    """BASELINE config 3 at full size (256 x 256 x 128, stretched Bounded z, T and S, FPlane, linear EOS, AMD, flux /
+    gradient conditions, RK3, WENO5): after three steps the velocity is divergence free, w vanishes on both walls, and
+    the T and S budgets changed by exactly the imposed boundary fluxes (test_boundary_conditions_integration.jl:26-50:
+    d/dt of the volume integral = -(top flux - bottom flux) x area; advection and diffusion are conservative)."""
+    Nx, Ny, Nz = 256, 256, 128
+    Lz, refinement, stretching = 32.0, 1.2, 12.0
+    k = np.arange(1, Nz + 2)
+    h = (k - 1) / Nz
+    zf = Lz * ((1 + (h - 1) / refinement) * (1 - np.exp(-stretching * h)) / (1 - np.exp(-stretching)) - 1)
+    grid = ocn.RectilinearGrid(size=(Nx, Ny, Nz), x=(0.0, 512.0), y=(0.0, 512.0), z=zf, topology=("Periodic", "Periodic", "Bounded"))
+    QT = 200.0 / (1026.0 * 3991.0)
+    Qu = -1.225 / 1026.0 * 2.5e-3 * 100
+    QS = -1e-3 / 3600 * 35.0
+    dTdz = 0.01
+    bcs = {"u": {"top": ocn.FluxBC(Qu)}, "T": {"top": ocn.FluxBC(QT), "bottom": ocn.GradientBC(dTdz)}, "S": {"top": ocn.FluxBC(QS)}}
+    m = ocn.NonhydrostaticModel(grid, advection=ocn.WENO5(), timestepper="RungeKutta3", tracers=("T", "S"),
+                                coriolis=ocn.FPlane(1e-4), closure=ocn.AnisotropicMinimumDissipation(),
+                                buoyancy=ocn.SeawaterBuoyancy(thermal_expansion=2e-4, haline_contraction=8e-4),
+                                boundary_conditions=bcs)
+    rng = np.random.default_rng(3)
+    zc = 0.5 * (zf[1:] + zf[:-1]).reshape(1, 1, -1)
+    noise = lambda z, shape: rng.standard_normal(shape) * z / Lz * (1 + z / Lz)   # noqa: E731
+    T0 = 20 + dTdz * zc + dTdz * Lz * 1e-6 * noise(zc, (Nx, Ny, Nz))
+    u0 = np.sqrt(abs(Qu)) * 1e-3 * noise(zc, (Nx, Ny, Nz))
+    ocn.set_model(m, u=u0, T=T0, S=35.0)
+    dz = np.diff(zf).reshape(1, 1, -1)
+    vol = 2.0 * 2.0 * dz
+    T_before = (m.tracers["T"].interior() * vol).sum()
+    S_before = (m.tracers["S"].interior() * vol).sum()
+    dt, nsteps = 1.0, 3
+    for _ in range(nsteps):
+        ocn.time_step(m, dt)
+    w = m.w.interior()
+    assert w.shape[2] == Nz + 1 and np.all(w[:, :, 0] == 0) and np.all(w[:, :, -1] == 0)
+    umax = max(np.abs(m.u.interior()).max(), 1e-12)
+    assert m.max_abs_divergence() <= 1e-9 * umax / dz.min()
+    area = 512.0 * 512.0
+    T_after = (m.tracers["T"].interior() * vol).sum()
+    S_after = (m.tracers["S"].interior() * vol).sum()
+    # S has flux conditions only: its budget is exact.  T also loses what diffuses through the bottom wall under the
+    # gradient condition, -kappa_e dT/dz there (>= 0 and tiny: the AMD diffusivity of a quiescent bottom layer).
+    tS, tT = -QS * area * dt * nsteps, -QT * area * dt * nsteps
+    assert abs((S_after - S_before) - tS) <= 1e-12 * abs(S_before) + 1e-9 * abs(tS)
+    leak = np.abs(m.kappa_e["T"].interior()[:, :, 0]).max() * dTdz * area * dt * nsteps
+    dT = (T_after - T_before) - tT
+    assert -1.01 * leak - 1e-12 * abs(T_before) - 1e-9 * abs(tT) <= dT <= 1e-12 * abs(T_before) + 1e-9 * abs(tT)
+    assert np.isfinite(m.tracers["T"].interior()).all()
