@@ -16,6 +16,11 @@ _TOPO = {Periodic: L.PERIODIC, Bounded: L.BOUNDED, Flat: L.FLAT}
 
 
 # ---- advection schemes (Advection/) -----------------------------------------------------------------
+class NoAdvection:
+    """``advection = nothing`` (nonhydrostatic_model.jl:106): no advective terms at all."""
+    code = L.ADV_NONE
+
+
 class CenteredSecondOrder:
     code = L.ADV_C2
 

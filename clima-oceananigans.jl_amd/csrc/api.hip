@@ -7,6 +7,7 @@
 #ifdef OCN_HOST_EMU
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 emu_barrier g_emu_barrier;
+double g_emu_shfl[4096];
 std::recursive_mutex g_emu_launch_mutex;
 #endif
 

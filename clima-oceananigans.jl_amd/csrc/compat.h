@@ -35,6 +35,24 @@ static inline void ocn_launch_sync(K kern, dim3 grid, dim3 block, hipStream_t s,
 #define OCN_SHARED __shared__
 #define OCN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// ---- wave-level primitives of the tiled kernels ----------------------------------------------------------------------
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4: no VGPR round trip): lane l of the
+// wave lands at dst_wave_base + 16 l; EXEC-masked lanes neither load nor write (tools/micro_checks.hip).
+typedef __attribute__((address_space(3))) void ocn_lds_void;
+typedef const __attribute__((address_space(1))) void ocn_glb_void;
+__device__ __forceinline__ void ocn_glds16(const void* src_lane, void* dst_wave_base, int /*lane*/) {
+  __builtin_amdgcn_global_load_lds((ocn_glb_void*)src_lane, (ocn_lds_void*)dst_wave_base, 16, 0, 0);
+}
+// value held by the next lane of the wave (lane + 1); lane 63 receives 0.  v_mov_b32_dpp wave_shl:1, two per double.
+__device__ __forceinline__ double ocn_shfl_next(double x) {
+  union { double d; int i[2]; } a, b;
+  a.d = x;
+  b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x130, 0xf, 0xf, false);
+  b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x130, 0xf, 0xf, false);
+  return b.d;
+}
+#define OCN_WAVE 64
+
 #else
 // ------------------------------------------------------------------------------------------------
 #include <chrono>
@@ -122,6 +140,22 @@ struct emu_barrier {
 };
 extern emu_barrier g_emu_barrier;
 static inline void __syncthreads() { g_emu_barrier.wait(); }
+
+// wave-level primitives, emulated with one OS thread per GPU thread (every thread of the block must make the call)
+#define OCN_WAVE 64
+static inline void ocn_glds16(const void* src_lane, void* dst_wave_base, int lane) {
+  memcpy((char*)dst_wave_base + 16 * lane, src_lane, 16);
+}
+extern double g_emu_shfl[4096];
+static inline double ocn_shfl_next(double x) {
+  const unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+  const unsigned n = blockDim.x * blockDim.y * blockDim.z;
+  g_emu_shfl[tid] = x;
+  g_emu_barrier.wait();
+  const double y = ((tid & 63) != 63 && tid + 1 < n) ? g_emu_shfl[tid + 1] : 0.0;
+  g_emu_barrier.wait();
+  return y;
+}
 
 template <class K, class... A>
 static inline void ocn_launch_sync(K kern, dim3 grid, dim3 block, hipStream_t, A... args) {

@@ -39,6 +39,7 @@ struct FusedArgs {
   int ntiles;                     // y-tiles (v3: segment decomposition); x-tiled variant: ntx * nty
   int ntx, BXo;                   // x-tiled variant: tiles along x, output columns per tile
   int dbg_nobar;                  // timing experiments only (OCNHIP_DBG_NOBAR): results are wrong
+  int prio;                       // wave-priority scheme of the tendency kernels (see PRIO_* below)
   double nu;                      // ScalarDiffusivity viscosity (0: none); see the viscous-flux note in k_tend_step3
 #ifdef OCN_DIAG_STAMPS
   unsigned long long* diag;       // diagnostic build only: per-wave cycle sums {barrier A, flux stage, barrier B, finalize}
@@ -49,6 +50,25 @@ struct FusedArgs {
 #else
 #define STAMP(var)
 #endif
+
+// Wave priorities (s_setprio).  The VALU of a SIMD is handed out by priority, then by age, so the four waves a SIMD holds
+// (one per thread row) do not advance together: in-kernel stamps of round 2 show the ghost-row wave -- a third of the
+// work, but the youngest -- starved until the others are done, and every wave then waiting for it at the barrier.
+//   1: ghost-row waves run at priority 3 (they are short: get them out of the way first)
+//   2: 1 + the first output row drops to the lowest priority half way through a level, the last one rises
+//   3: priority = row index (inverts the age order)
+#ifndef OCN_HOST_EMU
+#define OCN_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define OCN_SETPRIO(n) ((void)0)
+#endif
+OCN_DEVFN void prio_start(int mode, int ty, int BY) {
+  if (mode == 1 || mode == 2) { if (ty == BY - 1) OCN_SETPRIO(3); else if (mode == 2 && ty == 0) OCN_SETPRIO(2); else if (mode == 2 && ty == BY - 2) OCN_SETPRIO(0); else OCN_SETPRIO(1); }
+  else if (mode == 3) { if (ty >= 3) OCN_SETPRIO(3); else if (ty == 2) OCN_SETPRIO(2); else if (ty == 1) OCN_SETPRIO(1); else OCN_SETPRIO(0); }
+}
+OCN_DEVFN void prio_mid(int mode, int ty, int BY) {
+  if (mode == 2) { if (ty == 0) OCN_SETPRIO(0); else if (ty == BY - 2) OCN_SETPRIO(2); }
+}
 
 OCN_DEVFN void sto(double* base, unsigned boff, double v) { *(double*)((char*)base + boff) = v; }
 
@@ -166,6 +186,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
     STAMP(t0);
     if (!(a.dbg_nobar & 2)) __syncthreads();
     STAMP(t1);
+    prio_start(a.prio, ty, BY);
     if (EARLY && !last) prefetch(k + 1);   // next level's slab in flight during the whole flux stage
     double gm0 = 0, gm1 = 0, gm2 = 0;      // G^- of the level finalized below, also fetched early
     double rs0 = 0, rs1 = 0, rs2 = 0;      // REST: the non-advective part of G^n waiting in the G^n arrays
@@ -247,6 +268,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
         fx[2 * T + tid] = utw * XREC(2, utw, ix) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 3, 2)) * rdx : 0.0);
         if (FENCE3) OCN_SCHED_FENCE();
       }
+      prio_mid(a.prio, ty, BY);
       if (do_y) {
         double vtu = XSYM(1, ix);                      // v interpolated in x to the u column
         fx[3 * T + tid] = vtu * YREC(0, vtu, jy) - (visc ? a.nu * (SLB(0, 3, 3) - SLB(0, 2, 3)) * rdy : 0.0);
@@ -354,6 +376,337 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
     d[0] = dA; d[1] = dF; d[2] = dB; d[3] = dZ;
   }
 #endif
+#undef SLB
+}
+
+// ---- k_tend4: the same work as k_tend_step3 (complete rows, Nx <= BX) with ONE barrier per level ----------------------
+// What changed against k_tend_step3, and why (rocprofv3 of round 2: VALU busy 58 %, every wave parked 46 % of its
+// cycles, most of it correlated -- all 16 waves of the CU's only workgroup meet at two barriers per level):
+//   * the slab of the NEXT level goes straight from HBM into the other half of a double-buffered LDS slab with
+//     global_load_lds_dwordx4 (DMA = true: the parent arrays have the slab's pitch, Nx + 6, so a level's nine rows of a
+//     field are ONE contiguous 18.4 KB chunk with its x halos in place; 3 - 6 instructions per thread and level, no VGPR
+//     round trip, no ds_write, no image selects).  DMA = false keeps the register-staged commit (any Nx <= BX).
+//   * west-face (x) fluxes reach the east neighbour by a lane shift inside the wave (v_mov_b32_dpp wave_shl:1); only
+//     the first lane of each wave also drops its three values into a small LDS table for the last lane of the wave
+//     before it.  South-face (y) fluxes still go through LDS (the north neighbour is another wave), double buffered.
+//   * the horizontal divergence and the bottom fluxes of the previous level are carried in registers (they lived in
+//     LDS before: that space now holds the second slab buffer).
+//   With every LDS buffer double buffered by level parity a level needs one barrier: after it, every thread has
+//   finished the flux stage of level k-1, so level k-1's neighbour fluxes are complete, slab[k&1] has landed, and
+//   slab[(k+1)&1] (last read at level k-1) is free to be refilled.  The update of level k-1 then runs in the same
+//   interval as the flux stage of level k, which gives the scheduler independent work to overlap.
+template <int ADV, int BX, int BY, bool DMA, bool VISC, bool ZB, bool REST>
+__global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
+  constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
+  constexpr int WV = BX < OCN_WAVE ? BX : OCN_WAVE;   // lanes of a wave that lie in one row
+  constexpr int NW = BX / WV;                         // waves per row
+  constexpr int SLAB = 3 * NR * SX;                   // doubles per slab buffer; (f, r, s) <-> (j0 - 3 + r, s - 3)
+  constexpr int NP = NR * SX / 2;                     // 16-byte pieces of one field's slab
+  constexpr int NPR = (NP + T - 1) / T;
+  constexpr int NG = (NR + BY - 1) / BY;              // row groups of the register-staged slab load (DMA = false)
+  static_assert((NR * SX) % 2 == 0 && BX % WV == 0, "slab of a field must be a whole number of 16-byte pieces");
+  OCN_SHARED double lds[2 * SLAB + 6 * T + 6 * BY * NW] __attribute__((aligned(16)));
+  double* const fyb = lds + 2 * SLAB;                 // [parity][field][thread]: south-face fluxes
+  double* const fxe = fyb + 6 * T;                    // [parity][field][row * NW + wave]: west-face fluxes of each wave's first lane
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tid = ty * BX + tx;
+  const int lane = tid & (OCN_WAVE - 1);
+  const int i = tx;
+  const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
+  const double rdx = g.rdx, rdy = g.rdy, rdz = 1.0 / g.dz;
+  const int nbz = (ADV == ADV_C4) ? 1 : 2;
+  const bool col_ok = i < g.Nx;
+  const bool ghost = (ty == BY - 1);
+  // east neighbour: the next lane, except for the last lane of a wave and for the last column of the row (periodic wrap)
+  const bool xedge = (tx % WV == WV - 1) || (tx + 1 >= g.Nx);
+  const int txe = (tx + 1 >= g.Nx) ? 0 : tx + 1;
+  const int eidx = ty * NW + txe / WV;
+  const int nid_n = (ty + 1 < BY ? ty + 1 : ty) * BX + tx;
+  const int nseg = gridDim.x, per = nseg / 8;
+  const long seg = (nseg % 8 == 0) ? (long)(blockIdx.x % 8) * per + blockIdx.x / 8 : (long)blockIdx.x;
+  const long total = (long)a.ntiles * g.Nz;
+  long lo = seg * total / nseg;
+  const long hi = (seg + 1) * total / nseg;
+  while (lo < hi) {
+  const int ytile = (int)(lo / g.Nz);
+  const int k0 = (int)(lo - (long)ytile * g.Nz);
+  const int k1 = (k0 + (hi - lo) < g.Nz) ? (int)(k0 + (hi - lo)) : g.Nz;
+  lo += k1 - k0;
+  const int j0 = ytile * (BY - 1);
+  const int j = j0 + ty;
+  const bool row_ok = j < g.Ny;
+  const bool do_y = col_ok && j <= g.Ny;
+  const bool full = col_ok && row_ok && !ghost;
+  const unsigned cxy = a.org + (unsigned)(col_ok ? i : 0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
+
+  // ---- slab staging ------------------------------------------------------------------------------------------------
+  // DMA: rows j0-3 .. j0+BY+1, columns -3 .. Nx+2 of level k are NR * SX consecutive doubles of the parent array
+  auto dma = [&](int k, int buf) {
+    const unsigned src0 = (unsigned)((long)a.org + ((long)(j0 - 3) * g.sy + (long)k * g.sz - 3) * 8);
+#pragma unroll
+    for (int r = 0; r < NPR; ++r) {
+      const int p = tid + r * T;
+      if (p < NP) {
+        char* dst = (char*)(lds + buf * SLAB) + 16 * (p - lane);
+        const unsigned so = src0 + 16u * (unsigned)p;      // one 32-bit offset on a scalar base, as ldo()
+        ocn_glds16((const char*)a.u + so, dst, lane);
+        ocn_glds16((const char*)a.v + so, dst + NR * SX * 8, lane);
+        ocn_glds16((const char*)a.w + so, dst + 2 * NR * SX * 8, lane);
+      }
+    }
+  };
+  const unsigned grow = a.org + (unsigned)(col_ok ? i : 0) * sxb;
+  double pf[DMA ? 1 : 3][DMA ? 1 : NG];
+  auto prefetch = [&](int k) {
+    if (DMA) return;
+#pragma unroll
+    for (int gq = 0; gq < (DMA ? 0 : NG); ++gq) {
+      int r = ty + BY * gq;
+      if (r < NR) {
+        int jg = j0 - 3 + r;
+        if (jg > g.Ny + 2) jg = g.Ny + 2;
+        unsigned o = grow + (unsigned)(jg + 3) * syb - 3u * syb + (unsigned)k * szb;
+        pf[0][gq] = ldo(a.u, o);
+        pf[1 % (DMA ? 1 : 3)][gq] = ldo(a.v, o);
+        pf[2 % (DMA ? 1 : 3)][gq] = ldo(a.w, o);
+      }
+    }
+  };
+  const bool img_e = tx < 3, img_w = tx >= g.Nx - 3;
+  auto commit = [&](int buf) {
+    if (DMA) return;
+#pragma unroll
+    for (int gq = 0; gq < (DMA ? 0 : NG); ++gq) {
+      int r = ty + BY * gq;
+      if (r < NR && col_ok) {
+#pragma unroll
+        for (int fl = 0; fl < 3; ++fl) {
+          double* row = lds + buf * SLAB + (fl * NR + r) * SX;
+          double val = pf[fl % (DMA ? 1 : 3)][gq];
+          row[tx + 3] = val;
+          if (img_e) row[tx + 3 + g.Nx] = val;
+          if (img_w) row[tx + 3 - g.Nx] = val;
+        }
+      }
+    }
+  };
+#define SLB(f, d, e) S[(f) * NR * SX + (d) * SX + (e)]
+
+  double zu[6], zv[6], zw[6];
+  {
+    const unsigned c = cxy + (unsigned)k0 * szb;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      zu[q] = ldo(a.u, c + (unsigned)(q - 3) * szb);
+      zv[q] = ldo(a.v, c + (unsigned)(q - 3) * szb);
+      zw[q] = ldo(a.w, c + (unsigned)(q - 3) * szb);
+    }
+  }
+  double dprev = 0.0;
+  if (VISC) {
+    const unsigned cb = cxy + (unsigned)k0 * szb - szb;
+    dprev = (ldo(a.u, cb + sxb) - zu[2]) * rdx + (ldo(a.v, cb + syb) - zv[2]) * rdy + (zw[3] - zw[2]) * rdz;
+  }
+  // carried from the previous level: horizontal divergence without the north (and, on x-edge lanes, east) fluxes, bottom fluxes
+  double hu = 0, hv = 0, hw = 0, bu = 0, bv = 0, bw = 0;
+  __syncthreads();                          // a previous segment's readers are done with every LDS buffer
+  if (DMA) dma(k0, k0 & 1);
+  else {
+    prefetch(k0);
+    commit(k0 & 1);
+    prefetch(k0 + 1);                       // k1 > k0, and level k1 is staged too: its w feeds the last bottom fluxes
+  }
+  for (int k = k0; k <= k1; ++k) {
+    const unsigned c = cxy + (unsigned)k * szb;
+    const bool last = (k == k1);
+    const int kb = k & 1;
+    __syncthreads();                        // the one barrier of the level (with DMA in flight it also waits for vmcnt(0))
+    if (!last) {                            // stage level k+1 (up to k1) into the buffer level k-1 was read from
+      if (DMA) dma(k + 1, kb ^ 1);
+      else {
+        commit(kb ^ 1);
+        if (k + 2 <= k1) prefetch(k + 2);
+      }
+    }
+    prio_start(a.prio, ty, BY);
+    const double* S = lds + kb * SLAB + ty * SX + tx;
+    double gm0 = 0, gm1 = 0, gm2 = 0, rs0 = 0, rs1 = 0, rs2 = 0;
+    if (REST && full && k > k0) {
+      rs0 = ldo(a.gnu, c - szb);
+      rs1 = ldo(a.gnv, c - szb);
+      rs2 = ldo(a.gnw, c - szb);
+    }
+    if (a.use_m && full && k > k0) {
+      gm0 = ldo(a.gmu, c - szb);
+      gm1 = ldo(a.gmv, c - szb);
+      gm2 = ldo(a.gmw, c - szb);
+    }
+    // complete the horizontal divergence of level k-1 with the neighbours' fluxes (complete since the barrier)
+    if (full && k > k0) {
+      const double* fyp = fyb + (kb ^ 1) * 3 * T;
+      hu = fma(fyp[0 * T + nid_n], rdy, hu);
+      hv = fma(fyp[1 * T + nid_n], rdy, hv);
+      hw = fma(fyp[2 * T + nid_n], rdy, hw);
+      if (xedge) {
+        const double* fxp = fxe + (kb ^ 1) * 3 * BY * NW;
+        hu = fma(fxp[0 * BY * NW + eidx], rdx, hu);
+        hv = fma(fxp[1 * BY * NW + eidx], rdx, hv);
+        hw = fma(fxp[2 * BY * NW + eidx], rdx, hw);
+      }
+    }
+    constexpr bool visc = VISC;
+    double wxm = 0, wym = 0;
+    if (visc && !last) {
+      wxm = ldo(a.w, c + szb - sxb);
+      wym = ldo(a.w, c + szb - syb);
+    }
+    auto symz_at = [&](const double* z, int idx) {
+      if (ZB && !(idx > nbz && idx < g.Nz + 1 - nbz)) return 0.5 * (z[2] + z[3]);
+      return sym4_v(z[1], z[2], z[3], z[4]);
+    };
+    auto symz = [&](const double* z) { return symz_at(z, k + 1); };
+    auto reconz_at = [&](const double* z, double ut, int idx) {
+      bool pos = ut > 0.0;
+      if (ZB) {
+        const bool ok = pos ? (idx > nbz && idx < g.Nz + 1 - (nbz - 1)) : (idx > nbz - 1 && idx < g.Nz + 1 - nbz);
+        if (!ok) return 0.5 * (z[2] + z[3]);
+      }
+      return recon5<ADV>(pos ? z[0] : z[5], pos ? z[1] : z[4], pos ? z[2] : z[3], pos ? z[3] : z[2],
+                         pos ? z[4] : z[1], pos);
+    };
+    auto reconz = [&](const double* z, double ut) { return reconz_at(z, ut, k + 1); };
+    auto sym_v = [&](double m2, double m1, double c0, double c1) { return sym4_v(m2, m1, c0, c1); };
+    auto rec_v = [&](double m3, double m2, double m1, double c0, double c1, double c2, double ut) {
+      bool pos = ut > 0.0;
+      return recon5<ADV>(pos ? m3 : c2, pos ? m2 : c1, pos ? m1 : c0, pos ? c0 : m1, pos ? c1 : m2, pos);
+    };
+    auto in_sym = [&](int idx, int N) { return idx > nbz && idx < N + 1 - nbz; };
+    auto in_rec = [&](bool pos, int idx, int N) {
+      return pos ? (idx > nbz && idx < N + 1 - (nbz - 1)) : (idx > nbz - 1 && idx < N + 1 - nbz);
+    };
+    const bool wy = REST && g.yb != 0;        // walls in y (runtime flag of the REST variants); walls in x take the x-tiled kernel
+    const int jy = j + 1;
+#define XSYM(f) sym_v(SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4))
+#define YSYM(f, idx) ((wy && !in_sym(idx, g.Ny)) ? 0.5 * (SLB(f, 2, 3) + SLB(f, 3, 3)) \
+                                               : sym_v(SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3)))
+#define XREC(f, ut) rec_v(SLB(f, 3, 0), SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4), SLB(f, 3, 5), ut)
+#define YREC(f, ut, idx) ((wy && !in_rec((ut) > 0.0, idx, g.Ny)) ? 0.5 * (SLB(f, 2, 3) + SLB(f, 3, 3)) \
+                              : rec_v(SLB(f, 0, 3), SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3), SLB(f, 5, 3), ut))
+    double f0 = 0, f1 = 0, f2 = 0;            // fluxes through the west faces of this thread's u, v, w cells (level k)
+    double s0 = 0, s1 = 0, s2 = 0;            // ... through the south faces
+    if (!last) {
+      if (full) {
+        double utu = XSYM(0);                          // centre i-1
+        f0 = utu * XREC(0, utu);
+        if (visc) {
+          const double dux = (SLB(0, 3, 3) - SLB(0, 3, 2)) * rdx;
+          const double divw = dux + (SLB(1, 4, 2) - SLB(1, 3, 2)) * rdy + (wxm - SLB(2, 3, 2)) * rdz;   // div U at (i-1, j, k)
+          f0 -= a.nu * (dux + divw);
+        }
+        double utv = YSYM(0, jy);                      // u interpolated in y to the v row
+        f1 = utv * XREC(1, utv) - (visc ? a.nu * (SLB(1, 3, 3) - SLB(1, 3, 2)) * rdx : 0.0);
+        double utw = symz(zu);                         // u interpolated in z to the w level
+        f2 = utw * XREC(2, utw) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 3, 2)) * rdx : 0.0);
+      }
+      prio_mid(a.prio, ty, BY);
+      if (do_y) {
+        double vtu = XSYM(1);                          // v interpolated in x to the u column
+        s0 = vtu * YREC(0, vtu, jy) - (visc ? a.nu * (SLB(0, 3, 3) - SLB(0, 2, 3)) * rdy : 0.0);
+        double vtv = YSYM(1, jy - 1);                  // centre j-1
+        s1 = vtv * YREC(1, vtv, jy - 1);
+        if (visc) {
+          const double dvy = (SLB(1, 3, 3) - SLB(1, 2, 3)) * rdy;
+          const double divs = (SLB(0, 2, 4) - SLB(0, 2, 3)) * rdx + dvy + (wym - SLB(2, 2, 3)) * rdz;   // div U at (i, j-1, k)
+          s1 -= a.nu * (dvy + divs);
+        }
+        double vtw = symz(zv);
+        s2 = vtw * YREC(2, vtw, jy) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 2, 3)) * rdy : 0.0);
+        double* fyn = fyb + kb * 3 * T;
+        fyn[0 * T + tid] = s0;
+        fyn[1 * T + tid] = s1;
+        fyn[2 * T + tid] = s2;
+      }
+    }
+    double Fwu = 0, Fwv = 0, Fww = 0;
+    if (full) {
+      double wtu = XSYM(2);
+      Fwu = wtu * reconz(zu, wtu);
+      double wtv = YSYM(2, jy);
+      Fwv = wtv * reconz(zv, wtv);
+      double wtw = symz_at(zw, k);                    // centre below face k
+      Fww = wtw * reconz_at(zw, wtw, k);
+      if (visc) {
+        Fwu -= a.nu * (zu[3] - zu[2]) * rdz;
+        Fwv -= a.nu * (zv[3] - zv[2]) * rdz;
+        const double dwz = (zw[3] - zw[2]) * rdz;
+        Fww -= a.nu * (dwz + dprev);                    // dprev = div U at (i, j, k-1)
+        if (!last) dprev = (SLB(0, 3, 4) - SLB(0, 3, 3)) * rdx + (SLB(1, 4, 3) - SLB(1, 3, 3)) * rdy + (zw[4] - zw[3]) * rdz;
+      }
+    }
+#undef XSYM
+#undef YSYM
+#undef XREC
+#undef YREC
+    // east fluxes: the next lane's west fluxes (uniform control flow: every lane of every wave takes part)
+    double e0 = 0, e1 = 0, e2 = 0;
+    if (!last) {
+      e0 = ocn_shfl_next(f0);
+      e1 = ocn_shfl_next(f1);
+      e2 = ocn_shfl_next(f2);
+      if (tx % WV == 0 && full) {
+        double* fxn = fxe + kb * 3 * BY * NW + ty * NW + tx / WV;
+        fxn[0 * BY * NW] = f0;
+        fxn[1 * BY * NW] = f1;
+        fxn[2 * BY * NW] = f2;
+      }
+    }
+    if (full) {
+      if (k > k0) {
+        const unsigned cm1 = c - szb;
+        const double rzc = ZB ? g_rdzc(g, k - 1) : rdz, rzf = ZB ? g_rdzf(g, k - 1) : rdz;
+        double Gu = rs0 - (hu + (Fwu - bu) * rzc);
+        double Gv = rs1 - (hv + (Fwv - bv) * rzc);
+        double Gw = rs2 - (hw + (Fww - bw) * rzf);
+        sto(a.gnu, cm1, Gu);
+        sto(a.gnv, cm1, Gv);
+        sto(a.gnw, cm1, Gw);
+        double iu, iv, iw;
+        if (a.use_m) {
+          iu = a.dt * (a.cn * Gu + a.cm * gm0);
+          iv = a.dt * (a.cn * Gv + a.cm * gm1);
+          iw = a.dt * (a.cn * Gw + a.cm * gm2);
+        } else {
+          iu = a.dt * a.cn * Gu;
+          iv = a.dt * a.cn * Gv;
+          iw = a.dt * a.cn * Gw;
+        }
+        sto(a.us, cm1, zu[2] + iu);
+        sto(a.vs, cm1, zv[2] + iv);
+        sto(a.ws, cm1, zw[2] + iw);
+      }
+      if (!last) {
+        // (east - west) / dx - south / dy now; north / dy (and east / dx on x-edge lanes) after the next barrier
+        hu = fma(xedge ? -f0 : e0 - f0, rdx, -s0 * rdy);
+        hv = fma(xedge ? -f1 : e1 - f1, rdx, -s1 * rdy);
+        hw = fma(xedge ? -f2 : e2 - f2, rdx, -s2 * rdy);
+        bu = Fwu;
+        bv = Fwv;
+        bw = Fww;
+      }
+    }
+    if (!last) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        zu[q] = zu[q + 1];
+        zv[q] = zv[q + 1];
+        zw[q] = zw[q + 1];
+      }
+      zu[5] = ldo(a.u, c + 3 * szb);
+      zv[5] = ldo(a.v, c + 3 * szb);
+      zw[5] = ldo(a.w, c + 3 * szb);
+    }
+  }
+  }  // segments
 #undef SLB
 }
 
@@ -961,6 +1314,8 @@ static int fused_cu_count(const ocn_model* m) {
 struct FusedShape {
   int bx, by;
   bool wide, small;
+  bool dma;      // complete rows with the slab's pitch in memory: LDS-DMA staging (k_tend4<DMA = true>)
+  bool v3;       // OCNHIP_TEND3=1: the two-barrier kernel of round 1 (A/B timing only)
   dim3 blk, grd;
 };
 static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
@@ -1002,6 +1357,12 @@ static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
 #endif
   f.blk = dim3(f.bx, f.by, 1);
   f.grd = dim3(nseg, 1, 1);
+  static const int env_v3 = getenv("OCNHIP_TEND3") ? atoi(getenv("OCNHIP_TEND3")) : 0;
+  static const int env_nodma = getenv("OCNHIP_NO_LDS_DMA") ? atoi(getenv("OCNHIP_NO_LDS_DMA")) : 0;
+  f.v3 = env_v3 != 0;
+  // 16-byte pieces: the slab chunk starts at column -3 of a row, i.e. at parent column Hx - 3 = 0, rows are sy = Nx + 6
+  // (even) doubles apart and planes sz = sy * rows doubles; the arrays come from hipMalloc (256-byte aligned)
+  f.dma = !f.wide && !env_nodma && gd.Nx == f.bx && gd.Hx == 3 && gd.sy == gd.Nx + 6 && (gd.sy % 2 == 0) && (gd.sz % 2 == 0);
   return f;
 }
 
@@ -1009,18 +1370,22 @@ static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
 #ifdef OCN_HOST_EMU
 #define FUSED_EMU16(ADVV, VISCV, ZBV, RESTV)                                                                               \
   if (f.bx == 16 && f.small) ocn_launch_sync(k_tend_step3x<ADVV, 16, 4, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);     \
-  else if (f.bx == 16) ocn_launch_sync(k_tend_step3<ADVV, 16, 4, true, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); \
+  else if (f.bx == 16) FUSED_T4(ADVV, 16, 4, VISCV, ZBV, RESTV)                                                            \
   else
 #else
 #define FUSED_EMU16(ADVV, VISCV, ZBV, RESTV)
 #endif
+#define FUSED_T4(ADVV, BXV, BYV, VISCV, ZBV, RESTV)                                                                        \
+  { if (f.dma) ocn_launch_sync(k_tend4<ADVV, BXV, BYV, true, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);               \
+    else ocn_launch_sync(k_tend4<ADVV, BXV, BYV, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); }
 #define FUSED_LAUNCH(ADVV, VISCV, ZBV, RESTV)                                                                              \
   FUSED_EMU16(ADVV, VISCV, ZBV, RESTV)                                                                                     \
   if (f.small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);                  \
   else if (f.wide) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);             \
-  else if (f.bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); \
-  else if (f.bx == 128) ocn_launch_sync(k_tend_step3<ADVV, 128, 8, true, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); \
-  else ocn_launch_sync(k_tend_step3<ADVV, 64, 8, true, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);
+  else if (f.v3 && f.bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); \
+  else if (f.bx == 256) FUSED_T4(ADVV, 256, 4, VISCV, ZBV, RESTV)                                                          \
+  else if (f.bx == 128) FUSED_T4(ADVV, 128, 8, VISCV, ZBV, RESTV)                                                          \
+  else FUSED_T4(ADVV, 64, 8, VISCV, ZBV, RESTV)
 #define FUSED_BY_SCHEME(VISCV, ZBV, RESTV)                            \
   switch (m->d.advection) {                                           \
     case ADV_WENO_Z: { FUSED_LAUNCH(ADV_WENO_Z, VISCV, ZBV, RESTV) } break;   \
@@ -1035,7 +1400,10 @@ static void fused_fill_args(ocn_model* m, FusedArgs& a, double dt, double cn, do
   a.us = m->us.d; a.vs = m->vs.d; a.ws = m->ws.d;
   a.org = (unsigned)((m->u.Hx + m->u.Hy * m->u.sy + m->u.Hz * m->u.sz) * sizeof(double));
   a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
-  a.dbg_nobar = getenv("OCNHIP_DBG_NOBAR") ? atoi(getenv("OCNHIP_DBG_NOBAR")) : 0;
+  static const int env_nobar = getenv("OCNHIP_DBG_NOBAR") ? atoi(getenv("OCNHIP_DBG_NOBAR")) : 0;
+  static const int env_prio = getenv("OCNHIP_PRIO") ? atoi(getenv("OCNHIP_PRIO")) : 0;
+  a.dbg_nobar = env_nobar;
+  a.prio = env_prio;
   a.nu = 0.0;
 #ifdef OCN_DIAG_STAMPS
   a.diag = nullptr;
