@@ -56,6 +56,13 @@ def cpu_baseline():
     import ctypes as C
     import subprocess
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:    # a container's CPU share (cgroup v2 quota) is what this process can really use: more threads only thrash
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, int(os.environ.get("OCNHIP_CPU_THREADS", "64")))
     model = "unknown"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -245,7 +252,18 @@ def main():
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("gloo")     # rendezvous / barriers / max-reduce only; data path is RCCL in the library
+        # rendezvous / barriers / max-reduce only; the data path is RCCL inside the library.  gloo prints its connection
+        # banner on stdout: keep stdout for the one JSON line.
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     ndev = int(os.environ.get("OCNHIP_BENCH_NDEV", "0"))     # rehearsal on fewer GPUs than ranks (shm transport only)
     ctx = ocn.Context(0 if args.rehearse_hostemu else (local_rank % ndev if ndev else local_rank))
@@ -401,7 +419,9 @@ def main():
             "metric": "cell-updates/sec per time_step!, 256^3 Nonhydrostatic WENO5", "value": value,
             "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": spinup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic" if not args.rehearse_hostemu else "rehearsal on the host emulation of the kernels: plumbing check, NOT a measurement",
+            "data": ("rehearsal on the host emulation of the kernels: plumbing check, NOT a measurement" if args.rehearse_hostemu else
+                     "synthetic; REHEARSAL: ranks share GPUs and exchange through host shared memory -- not a scaling measurement"
+                     if world > 1 and os.environ.get("OCNHIP_TRANSPORT") == "shm" else "synthetic"),
             "config": {"workload": (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} "
                                     + ("triply-periodic" if args.topology.upper() == "PPP" else f"topology {args.topology.upper()}")
                                     + " RectilinearGrid, "

@@ -730,6 +730,7 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
     ocn_model_destroy(m);
     return OCN_ENOMEM;
   }
+  fused_read_knobs(m);
   m->fast_path = fused_available(m) ? 1 : 0;
   if (getenv("OCNHIP_DEBUG")) fprintf(stderr, "[ocnhip] model: fast_path=%d\n", m->fast_path);
   m->bz_fast = (!m->fast_path && fused_bz_available(m)) ? 1 : 0;

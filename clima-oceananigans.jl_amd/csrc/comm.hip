@@ -259,7 +259,11 @@ int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* id128) {
   if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return OCN_EINVAL;
   ctx->rank = rank;
   ctx->nranks = nranks;
-  if (nranks == 1) return OCN_OK;
+  // OCNHIP_RCCL_SELF=1 (tests on a one-GPU box): a one-rank RCCL communicator through which the slab code paths forced
+  // by OCNHIP_FORCE_DIST send to themselves -- the same grouped ncclSend / ncclRecv calls a multi-GPU run makes
+  const bool self_rccl = nranks == 1 && id128 && getenv("OCNHIP_RCCL_SELF") && atoi(getenv("OCNHIP_RCCL_SELF")) != 0 &&
+                         strncmp((const char*)id128, "SHM:", 4) != 0;
+  if (nranks == 1 && !self_rccl) return OCN_OK;
   if (!id128) return OCN_EINVAL;
   if (strncmp((const char*)id128, "SHM:", 4) == 0) {
     char nm[128];
@@ -290,6 +294,16 @@ int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* id128) {
 // with matching sends / receives (same tag on both sides).  Self-messages are plain device copies.
 int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs) {
   hipStream_t st = c->stream;
+#ifndef OCN_HOST_EMU
+  if (c->nranks == 1 && c->comm) {   // one-rank communicator (OCNHIP_RCCL_SELF): self messages through RCCL itself
+    ncclComm_t comm1 = (ncclComm_t)c->comm;
+    NCCL_OK(c, ncclGroupStart());
+    for (const CommOp& s : sends) NCCL_OK(c, ncclSend(s.buf, s.bytes, ncclChar, 0, comm1, st));
+    for (const CommOp& r : recvs) NCCL_OK(c, ncclRecv(r.buf, r.bytes, ncclChar, 0, comm1, st));
+    NCCL_OK(c, ncclGroupEnd());
+    return OCN_OK;
+  }
+#endif
   // self messages
   for (const CommOp& r : recvs)
     if (r.peer == c->rank)

@@ -1,10 +1,11 @@
 // fused.hip -- the tiled kernels of the time_step! hot path (upwind-biased 5th-order advection: WENO5 Z / JS, U5).
 //
-//   k_tend_step3 / k_tend_step3x : calculate_G{u,v,w}! + ab2_step_field! / rk3_substep_field! in ONE pass
+//   k_tend4     : calculate_G{u,v,w}! + ab2_step_field! / rk3_substep_field! in ONE pass
 //                 (calculate_nonhydrostatic_tendencies.jl:155-170, quasi_adams_bashforth_2.jl:158-166,
 //                  runge_kutta_3.jl:204-218).  G^- <- G^n becomes a pointer rotation (store_tendencies.jl).
 //                 Template flags: VISC (ScalarDiffusivity as face fluxes), ZB (Bounded z), REST (G^n arrives holding
-//                 the non-advective terms computed by the general kernels).  3x: rows wider than a workgroup.
+//                 the non-advective terms computed by the general kernels), XT (rows wider than a workgroup or walls
+//                 in x: x-tiles with a ghost column), DMA (slab staged by global_load_lds).
 //   k_tracer_step: calculate_Gc! + update for passive tracers (periodic path)
 //   k_rhs_wrap  : calculate_pressure_source_term_fft_based_solver! reading the predictor with periodic
 //                 wrap indexing (no halo fill of U* needed)           (solve_for_pressure.jl:15-18)
@@ -38,18 +39,9 @@ struct FusedArgs {
   int BYo;                        // output rows per workgroup (= blockDim.y - 1)
   int ntiles;                     // y-tiles (v3: segment decomposition); x-tiled variant: ntx * nty
   int ntx, BXo;                   // x-tiled variant: tiles along x, output columns per tile
-  int dbg_nobar;                  // timing experiments only (OCNHIP_DBG_NOBAR): results are wrong
   int prio;                       // wave-priority scheme of the tendency kernels (see PRIO_* below)
   double nu;                      // ScalarDiffusivity viscosity (0: none); see the viscous-flux note in k_tend_step3
-#ifdef OCN_DIAG_STAMPS
-  unsigned long long* diag;       // diagnostic build only: per-wave cycle sums {barrier A, flux stage, barrier B, finalize}
-#endif
 };
-#ifdef OCN_DIAG_STAMPS
-#define STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#else
-#define STAMP(var)
-#endif
 
 // Wave priorities (s_setprio).  The VALU of a SIMD is handed out by priority, then by age, so the four waves a SIMD holds
 // (one per thread row) do not advance together: in-kernel stamps of round 2 show the ghost-row wave -- a third of the
@@ -62,8 +54,15 @@ struct FusedArgs {
 #else
 #define OCN_SETPRIO(n) ((void)0)
 #endif
+//   4 (experiment): output rows rotate through priorities 0..2 after every reconstruction pair
+OCN_DEVFN void prio_rot(int mode, int ty, int BY, int idx) {
+  if (mode != 4 || ty == BY - 1) return;
+  const int p = (ty + idx) % 3;
+  if (p == 0) OCN_SETPRIO(0); else if (p == 1) OCN_SETPRIO(1); else OCN_SETPRIO(2);
+}
 OCN_DEVFN void prio_start(int mode, int ty, int BY) {
-  if (mode == 1 || mode == 2) { if (ty == BY - 1) OCN_SETPRIO(3); else if (mode == 2 && ty == 0) OCN_SETPRIO(2); else if (mode == 2 && ty == BY - 2) OCN_SETPRIO(0); else OCN_SETPRIO(1); }
+  if (mode == 4) { if (ty == BY - 1) OCN_SETPRIO(3); else prio_rot(4, ty, BY, 0); }
+  else if (mode == 1 || mode == 2) { if (ty == BY - 1) OCN_SETPRIO(3); else if (mode == 2 && ty == 0) OCN_SETPRIO(2); else if (mode == 2 && ty == BY - 2) OCN_SETPRIO(0); else OCN_SETPRIO(1); }
   else if (mode == 3) { if (ty >= 3) OCN_SETPRIO(3); else if (ty == 2) OCN_SETPRIO(2); else if (ty == 1) OCN_SETPRIO(1); else OCN_SETPRIO(0); }
 }
 OCN_DEVFN void prio_mid(int mode, int ty, int BY) {
@@ -72,95 +71,147 @@ OCN_DEVFN void prio_mid(int mode, int ty, int BY) {
 
 OCN_DEVFN void sto(double* base, unsigned boff, double v) { *(double*)((char*)base + boff) = v; }
 
-// ---- the level's x/y neighbourhood is staged through LDS --------------------------------------------------------
-// (A first version read every stencil from global memory: ~50 vector-memory instructions per thread and level, all
-// 16 waves stalling on them together -- VALU busy 50 %.)  The workgroup loads the level's slab -- (BY+5) rows x (Nx+6) columns of u, v, w -- once (9 loads per thread,
-// issued one level ahead), and every x / y stencil is read from LDS with compile-time offsets from ONE
-// base address (workgroup shape is a template parameter, so row / field strides are immediates).
-//   LDS: slab 3*(BY+5)*(BX+6) + flux exchange 6*T + carry 6*T doubles  (BX = 256, BY = 4: 151.3 KB of 160)
-#define SLAB_MAXG 3
-template <int ADV, int BX, int BY, bool EARLY, bool FENCE3, bool VISC, bool ZB, bool REST>
-__global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
-  // ZB: Bounded z (regular or stretched).  The march is the same; what changes is uniform per level: the spacings,
-  // the 2nd-order fallback of every z stencil inside the boundary buffer (topologically_conditional_interpolation.jl:
-  // 46-79) and the tendency that is completed here -- G^n arrives holding everything but advection (closure,
-  // Coriolis, pressure gradient, boundary fluxes from the general kernels) and leaves as the full tendency.
+// ---- k_tend4: tendencies of u, v, w + time-stepper update, ONE barrier per level --------------------------------------
+// A workgroup owns BY-1 output rows (+ one ghost row of threads that only produces the south-face fluxes of the row above
+// the tile) of either complete x rows (XT = false: Nx <= BX, the periodic wrap stays inside the workgroup) or of an
+// x-tile of up to BX-7 output columns plus a ghost COLUMN that only produces west-face fluxes (XT = true: rows wider
+// than a workgroup, or walls in x).  It marches up its share of levels; every thread forms the fluxes through the
+// WEST / SOUTH / BOTTOM faces of its u, v, w cells (9 reconstructions per cell instead of the reference's 36), EAST
+// and NORTH fluxes come from the neighbours, TOP fluxes are the next level's BOTTOM fluxes.
+//
+// What round 2 changed against the two-barrier kernel of round 1, and why (rocprofv3: VALU busy 58 %, every wave
+// parked 46 % of its cycles, most of it correlated -- all 16 waves of the CU's only workgroup met at two barriers per
+// level; in-kernel stamps: output-row waves waited 19 % of their life at the second barrier for the starved ghost row):
+//   * the slab of the NEXT level goes straight from HBM into the other half of a double-buffered LDS slab with
+//     global_load_lds_dwordx4 (DMA = true): a slab row is a contiguous run of a parent-array row, x halos included
+//     (the projection / halo fills keep them current), so one wave-instruction moves 64 x 16 bytes of it; no VGPR
+//     round trip, no ds_write, no image selects.  DMA = false (odd Nx, halo != 3) stages through registers.
+//   * west-face fluxes reach the east neighbour by a lane shift inside the wave (v_mov_b32_dpp wave_shl:1); only the
+//     first lane of each wave also drops its three values into a small LDS table for the last lane of the wave before
+//     it.  South-face fluxes still go through LDS (the north neighbour is another wave), double buffered.
+//   * the horizontal divergence and the bottom fluxes of the previous level are carried in registers (they lived in
+//     LDS before: that space now holds the second slab buffer).
+//   * with every LDS buffer double buffered by level parity a level needs one barrier: after it every thread has
+//     finished the flux stage of level k-1, so that level's neighbour fluxes are complete, slab[k&1] has landed, and
+//     slab[(k+1)&1] (last read at level k-1) is free to be refilled.  The update of level k-1 runs in the same
+//     interval as the flux stage of level k.
+//   * wave priorities (prio_start / prio_mid): the VALU goes to the highest priority, then to the oldest wave; without
+//     them the youngest wave of each SIMD (the ghost row) starves and everybody waits for it.
+// Measured at 256^3 (MI355X, profiles/r02_*): 0.739 -> 0.551 ms together with the leaner WENO algebra of stencils.h.
+//
+// ScalarDiffusivity (VISC; closure_kernel_operators.jl:22-41 with constant nu): div(2 nu Sigma)_i = nu (lap u_i + d_i div U),
+// exactly (centred differences commute on a uniform grid).  Both parts are face fluxes at the very places of the advective
+// ones: -nu d(u_i)/dn through every face, plus -nu div U through the centre-located face of the normal component.
+// ZB: Bounded z (regular or stretched): per-level spacings and the 2nd-order fallback of every z stencil inside the
+// boundary buffer (topologically_conditional_interpolation.jl:46-79).  REST: G^n arrives holding everything but advection
+// (closure, Coriolis, pressure gradient, boundary fluxes from the general kernels) and leaves as the full tendency;
+// walls in x / y are runtime flags of the REST variants (the same fallbacks on the x / y stencils).
+template <int ADV, int BX, int BY, bool XT, bool DMA, bool VISC, bool ZB, bool REST>
+__global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
   constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
-  constexpr int NG = (NR + BY - 1) / BY;   // row groups of the cooperative slab load
-  OCN_SHARED double slab[3 * NR * SX];     // [field][row][column]; element (f, r, s) <-> (j0 - 3 + r, s - 3)
-  OCN_SHARED double fx[6 * T];             // flux exchange
-  OCN_SHARED double own[6 * T];            // carry: horizontal divergence + bottom fluxes of the previous level
+  constexpr int WV = BX < OCN_WAVE ? BX : OCN_WAVE;   // lanes of a wave that lie in one row
+  constexpr int NW = BX / WV;                         // waves per row
+  constexpr int NWV = T / WV;                         // waves per workgroup
+  constexpr int SLAB = 3 * NR * SX;                   // doubles per slab buffer; (f, r, s) <-> (row j0 - 3 + r, column i0 - 3 + s)
+  constexpr int NG = (NR + BY - 1) / BY;              // row groups of the register-staged slab load (DMA = false)
+  static_assert(SX % 2 == 0 && BX % WV == 0 && T % WV == 0, "slab rows must be whole 16-byte pieces");
+  OCN_SHARED double lds[2 * SLAB + 6 * T + 6 * BY * NW] __attribute__((aligned(16)));
+  double* const fyb = lds + 2 * SLAB;                 // [parity][field][thread]: south-face fluxes
+  double* const fxe = fyb + 6 * T;                    // [parity][field][row * NW + wave]: west-face fluxes of each wave's first lane
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int tid = ty * BX + tx;
-  const int i = tx;
+  const int lane = tid % WV, wave = tid / WV;
   const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
   const double rdx = g.rdx, rdy = g.rdy, rdz = 1.0 / g.dz;
-  const int nbz = (ADV == ADV_C4) ? 1 : 2;   // boundary buffer of the scheme (only WENO5 / U5 reach this kernel)
-  const bool col_ok = i < g.Nx;
+  const int nbz = (ADV == ADV_C4) ? 1 : 2;
   const bool ghost = (ty == BY - 1);
-  const int txe = (tx + 1 == g.Nx) ? 0 : tx + 1;
-  const int nid_e = ty * BX + (txe < BX ? txe : tx);
   const int nid_n = (ty + 1 < BY ? ty + 1 : ty) * BX + tx;
-  // Work decomposition: the (y-tile, level) space is cut into gridDim.x equal segments of consecutive levels
-  // (tile-major), so every workgroup marches the same number of levels whatever Ny/(BY-1) is -- no partial
-  // last round.  XCD-aware: workgroups b and b+8 share an L2, so each XCD gets a contiguous band of segments.
+  // Work decomposition: the (tile, level) space is cut into gridDim.x equal segments of consecutive levels (tile-major),
+  // so every workgroup marches the same number of levels -- no partial last round.  XCD-aware: workgroups b and b+8
+  // share an L2, so each XCD gets a contiguous band of segments.
   const int nseg = gridDim.x, per = nseg / 8;
   const long seg = (nseg % 8 == 0) ? (long)(blockIdx.x % 8) * per + blockIdx.x / 8 : (long)blockIdx.x;
   const long total = (long)a.ntiles * g.Nz;
   long lo = seg * total / nseg;
   const long hi = (seg + 1) * total / nseg;
-#ifdef OCN_DIAG_STAMPS
-  unsigned long long dA = 0, dF = 0, dB = 0, dZ = 0;
-#endif
   while (lo < hi) {
-  const int ytile = (int)(lo / g.Nz);
-  const int k0 = (int)(lo - (long)ytile * g.Nz);
+  const int tile = (int)(lo / g.Nz);
+  const int k0 = (int)(lo - (long)tile * g.Nz);
   const int k1 = (k0 + (hi - lo) < g.Nz) ? (int)(k0 + (hi - lo)) : g.Nz;
   lo += k1 - k0;
+  const int ytile = XT ? tile / a.ntx : tile, xt = XT ? tile - ytile * a.ntx : 0;
+  const int i0 = XT ? xt * a.BXo : 0;
+  const int nout = XT ? ((g.Nx - i0 < a.BXo) ? g.Nx - i0 : a.BXo) : g.Nx;   // output columns; XT: column `nout` is the ghost column
+  const int i = i0 + tx;
+  const bool ocol = tx < nout;
+  const bool col_ok = XT ? tx <= nout : ocol;                               // forms west-face fluxes
+  const bool ldcol = XT ? tx < nout + 7 : ocol;                             // register staging: loads a slab column
   const int j0 = ytile * (BY - 1);
   const int j = j0 + ty;
   const bool row_ok = j < g.Ny;
-  const bool do_y = col_ok && j <= g.Ny;
-  const bool full = col_ok && row_ok && !ghost;
-  const unsigned cxy = a.org + (unsigned)(col_ok ? i : 0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
+  const bool do_y = ocol && j <= g.Ny;
+  const bool full = ocol && row_ok && !ghost;
+  const bool do_x = col_ok && row_ok && !ghost;
+  // east neighbour: the next lane, except for the last lane of a wave and (complete rows) the periodic wrap at Nx - 1
+  const bool xedge = (tx % WV == WV - 1) || (!XT && tx + 1 >= g.Nx);
+  const int txe = (!XT && tx + 1 >= g.Nx) ? 0 : (tx + 1 < BX ? tx + 1 : tx);
+  const int eidx = ty * NW + txe / WV;
+  const unsigned cxy = a.org + (unsigned)(col_ok ? i : i0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
 
-  // cooperative slab load: thread row ty handles slab rows r = ty + BY*gq of every field
-  const unsigned grow = a.org + (unsigned)(col_ok ? i : 0) * sxb;
-  double pf[3][NG];
+  // ---- slab staging ------------------------------------------------------------------------------------------------
+  // DMA: slab row r of a field = columns i0-3 ... of parent row j0-3+r, contiguous in memory; PR 16-byte pieces of it are
+  // needed (to the end of the parent row at most).  Wave w takes the (field, row) pairs w, w + NWV, ...
+  const int ncols = (g.Nx + 6 - i0 < SX) ? g.Nx + 6 - i0 : SX;
+  const int PR = ncols / 2;
+  auto dma = [&](int k, int buf) {
+    const long src0 = (long)a.org + ((long)(j0 - 3) * g.sy + (long)k * g.sz + (i0 - 3)) * 8;
+    for (int fr = wave; fr < 3 * NR; fr += NWV) {
+      const int f = fr / NR, r = fr - f * NR;
+      const double* base = f == 0 ? a.u : f == 1 ? a.v : a.w;
+      const unsigned so = (unsigned)(src0 + (long)r * g.sy * 8);
+      char* dst = (char*)(lds + buf * SLAB + fr * SX);
+      for (int q0 = 0; q0 < PR; q0 += WV)
+        if (q0 + lane < PR) ocn_glds16((const char*)base + (so + 16u * (unsigned)(q0 + lane)), dst + 16 * q0, lane);
+    }
+  };
+  const unsigned grow = a.org + (unsigned)((XT ? (ldcol ? i0 + tx : i0 + 3) - 3 : (ocol ? tx : 0))) * sxb;   // XT: slab column tx <-> global column i0 - 3 + tx
+  double pf[DMA ? 1 : 3][DMA ? 1 : NG];
   auto prefetch = [&](int k) {
+    if (DMA) return;
 #pragma unroll
-    for (int gq = 0; gq < NG; ++gq) {
+    for (int gq = 0; gq < (DMA ? 0 : NG); ++gq) {
       int r = ty + BY * gq;
       if (r < NR) {
         int jg = j0 - 3 + r;
         if (jg > g.Ny + 2) jg = g.Ny + 2;              // rows past the halo are never used
         unsigned o = grow + (unsigned)(jg + 3) * syb - 3u * syb + (unsigned)k * szb;
         pf[0][gq] = ldo(a.u, o);
-        pf[1][gq] = ldo(a.v, o);
-        pf[2][gq] = ldo(a.w, o);
+        pf[1 % (DMA ? 1 : 3)][gq] = ldo(a.v, o);
+        pf[2 % (DMA ? 1 : 3)][gq] = ldo(a.w, o);
       }
     }
   };
   const bool img_e = tx < 3, img_w = tx >= g.Nx - 3;
-  auto commit = [&]() {
+  auto commit = [&](int buf) {
+    if (DMA) return;
 #pragma unroll
-    for (int gq = 0; gq < NG; ++gq) {
+    for (int gq = 0; gq < (DMA ? 0 : NG); ++gq) {
       int r = ty + BY * gq;
-      if (r < NR && col_ok) {
+      if (r < NR && ldcol) {
 #pragma unroll
         for (int fl = 0; fl < 3; ++fl) {
-          double* row = slab + (fl * NR + r) * SX;
-          double val = pf[fl][gq];
-          row[tx + 3] = val;
-          if (img_e) row[tx + 3 + g.Nx] = val;         // periodic images: east halo
-          if (img_w) row[tx + 3 - g.Nx] = val;         // west halo
+          double* row = lds + buf * SLAB + (fl * NR + r) * SX;
+          double val = pf[fl % (DMA ? 1 : 3)][gq];
+          if (XT) row[tx] = val;                       // x halos come from the arrays' own halo columns
+          else {
+            row[tx + 3] = val;
+            if (img_e) row[tx + 3 + g.Nx] = val;       // periodic images inside LDS
+            if (img_w) row[tx + 3 - g.Nx] = val;
+          }
         }
       }
     }
   };
-  // lowest corner of this thread's stencil footprint: element (f, ty + d, tx + e) = S[f*NR*SX + d*SX + e],
-  // own cell at d = e = 3.  All offsets below are compile-time constants.
-  const double* S = slab + ty * SX + tx;
 #define SLB(f, d, e) S[(f) * NR * SX + (d) * SX + (e)]
 
   double zu[6], zv[6], zw[6];
@@ -178,34 +229,53 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
     const unsigned cb = cxy + (unsigned)k0 * szb - szb;
     dprev = (ldo(a.u, cb + sxb) - zu[2]) * rdx + (ldo(a.v, cb + syb) - zv[2]) * rdy + (zw[3] - zw[2]) * rdz;
   }
-  prefetch(k0);
+  // carried from the previous level: horizontal divergence without the north (and, on x-edge lanes, east) fluxes, bottom fluxes
+  double hu = 0, hv = 0, hw = 0, bu = 0, bv = 0, bw = 0;
+  __syncthreads();                          // a previous segment's readers are done with every LDS buffer
+  if (DMA) dma(k0, k0 & 1);
+  else {
+    prefetch(k0);
+    commit(k0 & 1);
+    prefetch(k0 + 1);                       // k1 > k0, and level k1 is staged too: its w feeds the last bottom fluxes
+  }
   for (int k = k0; k <= k1; ++k) {
     const unsigned c = cxy + (unsigned)k * szb;
     const bool last = (k == k1);
-    commit();
-    STAMP(t0);
-    if (!(a.dbg_nobar & 2)) __syncthreads();
-    STAMP(t1);
+    const int kb = k & 1;
+    __syncthreads();                        // the one barrier of the level (with DMA in flight it also waits for vmcnt(0))
+    if (!last) {                            // stage level k+1 (up to k1) into the buffer level k-1 was read from
+      if (DMA) dma(k + 1, kb ^ 1);
+      else {
+        commit(kb ^ 1);
+        if (k + 2 <= k1) prefetch(k + 2);
+      }
+    }
     prio_start(a.prio, ty, BY);
-    if (EARLY && !last) prefetch(k + 1);   // next level's slab in flight during the whole flux stage
-    double gm0 = 0, gm1 = 0, gm2 = 0;      // G^- of the level finalized below, also fetched early
-    double rs0 = 0, rs1 = 0, rs2 = 0;      // REST: the non-advective part of G^n waiting in the G^n arrays
+    const double* S = lds + kb * SLAB + ty * SX + tx;     // lowest corner of this thread's stencil footprint; own cell at (3, 3)
+    double gm0 = 0, gm1 = 0, gm2 = 0, rs0 = 0, rs1 = 0, rs2 = 0;
     if (REST && full && k > k0) {
       rs0 = ldo(a.gnu, c - szb);
       rs1 = ldo(a.gnv, c - szb);
       rs2 = ldo(a.gnw, c - szb);
     }
-    if (EARLY && a.use_m && full && k > k0) {
+    if (a.use_m && full && k > k0) {
       gm0 = ldo(a.gmu, c - szb);
       gm1 = ldo(a.gmv, c - szb);
       gm2 = ldo(a.gmw, c - szb);
     }
-    // ScalarDiffusivity (closure_kernel_operators.jl:22-41 with constant nu): div(2 nu Sigma)_i = nu (lap u_i + d_i div U),
-    // exactly (centred differences commute on a uniform grid).  Both parts are face fluxes at the very places of
-    // the advective ones: -nu d(u_i)/dn through every face, plus -nu div U through the centre-located face of the
-    // normal component -- so they ride along in fx / Fw with no extra storage.  div U at the west / south cells
-    // needs w one level up in the neighbouring column (two extra loads); at the cell below it is the value this
-    // thread computed one level earlier (dprev).
+    // complete the horizontal divergence of level k-1 with the neighbours' fluxes (complete since the barrier)
+    if (full && k > k0) {
+      const double* fyp = fyb + (kb ^ 1) * 3 * T;
+      hu = fma(fyp[0 * T + nid_n], rdy, hu);
+      hv = fma(fyp[1 * T + nid_n], rdy, hv);
+      hw = fma(fyp[2 * T + nid_n], rdy, hw);
+      if (xedge) {
+        const double* fxp = fxe + (kb ^ 1) * 3 * BY * NW;
+        hu = fma(fxp[0 * BY * NW + eidx], rdx, hu);
+        hv = fma(fxp[1 * BY * NW + eidx], rdx, hv);
+        hw = fma(fxp[2 * BY * NW + eidx], rdx, hw);
+      }
+    }
     constexpr bool visc = VISC;   // compile-time: the inviscid kernel must not pay registers for these terms
     double wxm = 0, wym = 0;
     if (visc && !last) {
@@ -240,7 +310,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
     auto in_rec = [&](bool pos, int idx, int N) {
       return pos ? (idx > nbz && idx < N + 1 - (nbz - 1)) : (idx > nbz - 1 && idx < N + 1 - nbz);
     };
-    const bool wx = REST && g.xb != 0, wy = REST && g.yb != 0;
+    const bool wx = XT && REST && g.xb != 0, wy = REST && g.yb != 0;
     const int ix = i + 1, jy = j + 1;                 // 1-based face indices of this thread's u / v cells
 #define XSYM(f, idx) ((wx && !in_sym(idx, g.Nx)) ? 0.5 * (SLB(f, 3, 2) + SLB(f, 3, 3)) \
                                                : sym_v(SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4)))
@@ -250,368 +320,30 @@ __global__ void __launch_bounds__(BX* BY) k_tend_step3(GridDev g, FusedArgs a) {
                               : rec_v(SLB(f, 3, 0), SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4), SLB(f, 3, 5), ut))
 #define YREC(f, ut, idx) ((wy && !in_rec((ut) > 0.0, idx, g.Ny)) ? 0.5 * (SLB(f, 2, 3) + SLB(f, 3, 3)) \
                               : rec_v(SLB(f, 0, 3), SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3), SLB(f, 5, 3), ut))
-    if (!last) {
-      if (full) {
-        double utu = XSYM(0, ix - 1);                  // centre i-1
-        double f0 = utu * XREC(0, utu, ix - 1);
-        if (visc) {
-          const double dux = (SLB(0, 3, 3) - SLB(0, 3, 2)) * rdx;
-          const double divw = dux + (SLB(1, 4, 2) - SLB(1, 3, 2)) * rdy + (wxm - SLB(2, 3, 2)) * rdz;   // div U at (i-1, j, k)
-          f0 -= a.nu * (dux + divw);
-        }
-        fx[0 * T + tid] = f0;
-        if (FENCE3) OCN_SCHED_FENCE();
-        double utv = YSYM(0, jy);                      // u interpolated in y to the v row
-        fx[1 * T + tid] = utv * XREC(1, utv, ix) - (visc ? a.nu * (SLB(1, 3, 3) - SLB(1, 3, 2)) * rdx : 0.0);
-        if (FENCE3) OCN_SCHED_FENCE();
-        double utw = symz(zu);                         // u interpolated in z to the w level
-        fx[2 * T + tid] = utw * XREC(2, utw, ix) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 3, 2)) * rdx : 0.0);
-        if (FENCE3) OCN_SCHED_FENCE();
-      }
-      prio_mid(a.prio, ty, BY);
-      if (do_y) {
-        double vtu = XSYM(1, ix);                      // v interpolated in x to the u column
-        fx[3 * T + tid] = vtu * YREC(0, vtu, jy) - (visc ? a.nu * (SLB(0, 3, 3) - SLB(0, 2, 3)) * rdy : 0.0);
-        if (FENCE3) OCN_SCHED_FENCE();
-        double vtv = YSYM(1, jy - 1);                  // centre j-1
-        double f4 = vtv * YREC(1, vtv, jy - 1);
-        if (visc) {
-          const double dvy = (SLB(1, 3, 3) - SLB(1, 2, 3)) * rdy;
-          const double divs = (SLB(0, 2, 4) - SLB(0, 2, 3)) * rdx + dvy + (wym - SLB(2, 2, 3)) * rdz;   // div U at (i, j-1, k)
-          f4 -= a.nu * (dvy + divs);
-        }
-        fx[4 * T + tid] = f4;
-        if (FENCE3) OCN_SCHED_FENCE();
-        double vtw = symz(zv);
-        fx[5 * T + tid] = vtw * YREC(2, vtw, jy) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 2, 3)) * rdy : 0.0);
-        if (FENCE3) OCN_SCHED_FENCE();
-      }
-    }
-    double Fwu = 0, Fwv = 0, Fww = 0;
-    if (full) {
-      double wtu = XSYM(2, ix);
-      Fwu = wtu * reconz(zu, wtu);
-      if (FENCE3) OCN_SCHED_FENCE();
-      double wtv = YSYM(2, jy);
-      Fwv = wtv * reconz(zv, wtv);
-      if (FENCE3) OCN_SCHED_FENCE();
-      double wtw = symz_at(zw, k);                    // centre below face k
-      Fww = wtw * reconz_at(zw, wtw, k);
-      if (visc) {
-        Fwu -= a.nu * (zu[3] - zu[2]) * rdz;
-        Fwv -= a.nu * (zv[3] - zv[2]) * rdz;
-        const double dwz = (zw[3] - zw[2]) * rdz;
-        Fww -= a.nu * (dwz + dprev);                    // dprev = div U at (i, j, k-1)
-        if (!last) dprev = (SLB(0, 3, 4) - SLB(0, 3, 3)) * rdx + (SLB(1, 4, 3) - SLB(1, 3, 3)) * rdy + (zw[4] - zw[3]) * rdz;
-      }
-    }
-#undef XSYM
-#undef YSYM
-#undef XREC
-#undef YREC
-    STAMP(t2);
-    if (!(a.dbg_nobar & 1)) __syncthreads();
-    STAMP(t3);
-    if (!EARLY && !last) prefetch(k + 1);  // in flight during the (cheap) finalize stage; committed at the loop top
-    if (full) {
-      if (k > k0) {
-        const unsigned cm1 = c - szb;
-        const double rzc = ZB ? g_rdzc(g, k - 1) : rdz, rzf = ZB ? g_rdzf(g, k - 1) : rdz;
-        double Gu = rs0 - (own[0 * T + tid] + (Fwu - own[3 * T + tid]) * rzc);
-        double Gv = rs1 - (own[1 * T + tid] + (Fwv - own[4 * T + tid]) * rzc);
-        double Gw = rs2 - (own[2 * T + tid] + (Fww - own[5 * T + tid]) * rzf);
-        sto(a.gnu, cm1, Gu);
-        sto(a.gnv, cm1, Gv);
-        sto(a.gnw, cm1, Gw);
-        double iu, iv, iw;
-        if (a.use_m) {
-          if (!EARLY) {
-            gm0 = ldo(a.gmu, cm1);
-            gm1 = ldo(a.gmv, cm1);
-            gm2 = ldo(a.gmw, cm1);
-          }
-          iu = a.dt * (a.cn * Gu + a.cm * gm0);
-          iv = a.dt * (a.cn * Gv + a.cm * gm1);
-          iw = a.dt * (a.cn * Gw + a.cm * gm2);
-        } else {
-          iu = a.dt * a.cn * Gu;
-          iv = a.dt * a.cn * Gv;
-          iw = a.dt * a.cn * Gw;
-        }
-        sto(a.us, cm1, zu[2] + iu);
-        sto(a.vs, cm1, zv[2] + iv);
-        sto(a.ws, cm1, zw[2] + iw);
-      }
-      if (!last) {
-        own[0 * T + tid] = (fx[0 * T + nid_e] - fx[0 * T + tid]) * rdx + (fx[3 * T + nid_n] - fx[3 * T + tid]) * rdy;
-        own[1 * T + tid] = (fx[1 * T + nid_e] - fx[1 * T + tid]) * rdx + (fx[4 * T + nid_n] - fx[4 * T + tid]) * rdy;
-        own[2 * T + tid] = (fx[2 * T + nid_e] - fx[2 * T + tid]) * rdx + (fx[5 * T + nid_n] - fx[5 * T + tid]) * rdy;
-        own[3 * T + tid] = Fwu;
-        own[4 * T + tid] = Fwv;
-        own[5 * T + tid] = Fww;
-      }
-    }
-    if (!last) {
-#pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        zu[q] = zu[q + 1];
-        zv[q] = zv[q + 1];
-        zw[q] = zw[q + 1];
-      }
-      zu[5] = ldo(a.u, c + 3 * szb);
-      zv[5] = ldo(a.v, c + 3 * szb);
-      zw[5] = ldo(a.w, c + 3 * szb);
-    }
-#ifdef OCN_DIAG_STAMPS
-    {
-      STAMP(t4);
-      dA += t1 - t0; dF += t2 - t1; dB += t3 - t2; dZ += t4 - t3;
-    }
-#endif
-  }
-  }  // segments
-#ifdef OCN_DIAG_STAMPS
-  if (a.diag && (tid & 63) == 0) {
-    unsigned long long* d = a.diag + ((size_t)blockIdx.x * (T / 64) + tid / 64) * 4;
-    d[0] = dA; d[1] = dF; d[2] = dB; d[3] = dZ;
-  }
-#endif
-#undef SLB
-}
-
-// ---- k_tend4: the same work as k_tend_step3 (complete rows, Nx <= BX) with ONE barrier per level ----------------------
-// What changed against k_tend_step3, and why (rocprofv3 of round 2: VALU busy 58 %, every wave parked 46 % of its
-// cycles, most of it correlated -- all 16 waves of the CU's only workgroup meet at two barriers per level):
-//   * the slab of the NEXT level goes straight from HBM into the other half of a double-buffered LDS slab with
-//     global_load_lds_dwordx4 (DMA = true: the parent arrays have the slab's pitch, Nx + 6, so a level's nine rows of a
-//     field are ONE contiguous 18.4 KB chunk with its x halos in place; 3 - 6 instructions per thread and level, no VGPR
-//     round trip, no ds_write, no image selects).  DMA = false keeps the register-staged commit (any Nx <= BX).
-//   * west-face (x) fluxes reach the east neighbour by a lane shift inside the wave (v_mov_b32_dpp wave_shl:1); only
-//     the first lane of each wave also drops its three values into a small LDS table for the last lane of the wave
-//     before it.  South-face (y) fluxes still go through LDS (the north neighbour is another wave), double buffered.
-//   * the horizontal divergence and the bottom fluxes of the previous level are carried in registers (they lived in
-//     LDS before: that space now holds the second slab buffer).
-//   With every LDS buffer double buffered by level parity a level needs one barrier: after it, every thread has
-//   finished the flux stage of level k-1, so level k-1's neighbour fluxes are complete, slab[k&1] has landed, and
-//   slab[(k+1)&1] (last read at level k-1) is free to be refilled.  The update of level k-1 then runs in the same
-//   interval as the flux stage of level k, which gives the scheduler independent work to overlap.
-template <int ADV, int BX, int BY, bool DMA, bool VISC, bool ZB, bool REST>
-__global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
-  constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
-  constexpr int WV = BX < OCN_WAVE ? BX : OCN_WAVE;   // lanes of a wave that lie in one row
-  constexpr int NW = BX / WV;                         // waves per row
-  constexpr int SLAB = 3 * NR * SX;                   // doubles per slab buffer; (f, r, s) <-> (j0 - 3 + r, s - 3)
-  constexpr int NP = NR * SX / 2;                     // 16-byte pieces of one field's slab
-  constexpr int NPR = (NP + T - 1) / T;
-  constexpr int NG = (NR + BY - 1) / BY;              // row groups of the register-staged slab load (DMA = false)
-  static_assert((NR * SX) % 2 == 0 && BX % WV == 0, "slab of a field must be a whole number of 16-byte pieces");
-  OCN_SHARED double lds[2 * SLAB + 6 * T + 6 * BY * NW] __attribute__((aligned(16)));
-  double* const fyb = lds + 2 * SLAB;                 // [parity][field][thread]: south-face fluxes
-  double* const fxe = fyb + 6 * T;                    // [parity][field][row * NW + wave]: west-face fluxes of each wave's first lane
-  const int tx = threadIdx.x, ty = threadIdx.y;
-  const int tid = ty * BX + tx;
-  const int lane = tid & (OCN_WAVE - 1);
-  const int i = tx;
-  const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
-  const double rdx = g.rdx, rdy = g.rdy, rdz = 1.0 / g.dz;
-  const int nbz = (ADV == ADV_C4) ? 1 : 2;
-  const bool col_ok = i < g.Nx;
-  const bool ghost = (ty == BY - 1);
-  // east neighbour: the next lane, except for the last lane of a wave and for the last column of the row (periodic wrap)
-  const bool xedge = (tx % WV == WV - 1) || (tx + 1 >= g.Nx);
-  const int txe = (tx + 1 >= g.Nx) ? 0 : tx + 1;
-  const int eidx = ty * NW + txe / WV;
-  const int nid_n = (ty + 1 < BY ? ty + 1 : ty) * BX + tx;
-  const int nseg = gridDim.x, per = nseg / 8;
-  const long seg = (nseg % 8 == 0) ? (long)(blockIdx.x % 8) * per + blockIdx.x / 8 : (long)blockIdx.x;
-  const long total = (long)a.ntiles * g.Nz;
-  long lo = seg * total / nseg;
-  const long hi = (seg + 1) * total / nseg;
-  while (lo < hi) {
-  const int ytile = (int)(lo / g.Nz);
-  const int k0 = (int)(lo - (long)ytile * g.Nz);
-  const int k1 = (k0 + (hi - lo) < g.Nz) ? (int)(k0 + (hi - lo)) : g.Nz;
-  lo += k1 - k0;
-  const int j0 = ytile * (BY - 1);
-  const int j = j0 + ty;
-  const bool row_ok = j < g.Ny;
-  const bool do_y = col_ok && j <= g.Ny;
-  const bool full = col_ok && row_ok && !ghost;
-  const unsigned cxy = a.org + (unsigned)(col_ok ? i : 0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
-
-  // ---- slab staging ------------------------------------------------------------------------------------------------
-  // DMA: rows j0-3 .. j0+BY+1, columns -3 .. Nx+2 of level k are NR * SX consecutive doubles of the parent array
-  auto dma = [&](int k, int buf) {
-    const unsigned src0 = (unsigned)((long)a.org + ((long)(j0 - 3) * g.sy + (long)k * g.sz - 3) * 8);
-#pragma unroll
-    for (int r = 0; r < NPR; ++r) {
-      const int p = tid + r * T;
-      if (p < NP) {
-        char* dst = (char*)(lds + buf * SLAB) + 16 * (p - lane);
-        const unsigned so = src0 + 16u * (unsigned)p;      // one 32-bit offset on a scalar base, as ldo()
-        ocn_glds16((const char*)a.u + so, dst, lane);
-        ocn_glds16((const char*)a.v + so, dst + NR * SX * 8, lane);
-        ocn_glds16((const char*)a.w + so, dst + 2 * NR * SX * 8, lane);
-      }
-    }
-  };
-  const unsigned grow = a.org + (unsigned)(col_ok ? i : 0) * sxb;
-  double pf[DMA ? 1 : 3][DMA ? 1 : NG];
-  auto prefetch = [&](int k) {
-    if (DMA) return;
-#pragma unroll
-    for (int gq = 0; gq < (DMA ? 0 : NG); ++gq) {
-      int r = ty + BY * gq;
-      if (r < NR) {
-        int jg = j0 - 3 + r;
-        if (jg > g.Ny + 2) jg = g.Ny + 2;
-        unsigned o = grow + (unsigned)(jg + 3) * syb - 3u * syb + (unsigned)k * szb;
-        pf[0][gq] = ldo(a.u, o);
-        pf[1 % (DMA ? 1 : 3)][gq] = ldo(a.v, o);
-        pf[2 % (DMA ? 1 : 3)][gq] = ldo(a.w, o);
-      }
-    }
-  };
-  const bool img_e = tx < 3, img_w = tx >= g.Nx - 3;
-  auto commit = [&](int buf) {
-    if (DMA) return;
-#pragma unroll
-    for (int gq = 0; gq < (DMA ? 0 : NG); ++gq) {
-      int r = ty + BY * gq;
-      if (r < NR && col_ok) {
-#pragma unroll
-        for (int fl = 0; fl < 3; ++fl) {
-          double* row = lds + buf * SLAB + (fl * NR + r) * SX;
-          double val = pf[fl % (DMA ? 1 : 3)][gq];
-          row[tx + 3] = val;
-          if (img_e) row[tx + 3 + g.Nx] = val;
-          if (img_w) row[tx + 3 - g.Nx] = val;
-        }
-      }
-    }
-  };
-#define SLB(f, d, e) S[(f) * NR * SX + (d) * SX + (e)]
-
-  double zu[6], zv[6], zw[6];
-  {
-    const unsigned c = cxy + (unsigned)k0 * szb;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      zu[q] = ldo(a.u, c + (unsigned)(q - 3) * szb);
-      zv[q] = ldo(a.v, c + (unsigned)(q - 3) * szb);
-      zw[q] = ldo(a.w, c + (unsigned)(q - 3) * szb);
-    }
-  }
-  double dprev = 0.0;
-  if (VISC) {
-    const unsigned cb = cxy + (unsigned)k0 * szb - szb;
-    dprev = (ldo(a.u, cb + sxb) - zu[2]) * rdx + (ldo(a.v, cb + syb) - zv[2]) * rdy + (zw[3] - zw[2]) * rdz;
-  }
-  // carried from the previous level: horizontal divergence without the north (and, on x-edge lanes, east) fluxes, bottom fluxes
-  double hu = 0, hv = 0, hw = 0, bu = 0, bv = 0, bw = 0;
-  __syncthreads();                          // a previous segment's readers are done with every LDS buffer
-  if (DMA) dma(k0, k0 & 1);
-  else {
-    prefetch(k0);
-    commit(k0 & 1);
-    prefetch(k0 + 1);                       // k1 > k0, and level k1 is staged too: its w feeds the last bottom fluxes
-  }
-  for (int k = k0; k <= k1; ++k) {
-    const unsigned c = cxy + (unsigned)k * szb;
-    const bool last = (k == k1);
-    const int kb = k & 1;
-    __syncthreads();                        // the one barrier of the level (with DMA in flight it also waits for vmcnt(0))
-    if (!last) {                            // stage level k+1 (up to k1) into the buffer level k-1 was read from
-      if (DMA) dma(k + 1, kb ^ 1);
-      else {
-        commit(kb ^ 1);
-        if (k + 2 <= k1) prefetch(k + 2);
-      }
-    }
-    prio_start(a.prio, ty, BY);
-    const double* S = lds + kb * SLAB + ty * SX + tx;
-    double gm0 = 0, gm1 = 0, gm2 = 0, rs0 = 0, rs1 = 0, rs2 = 0;
-    if (REST && full && k > k0) {
-      rs0 = ldo(a.gnu, c - szb);
-      rs1 = ldo(a.gnv, c - szb);
-      rs2 = ldo(a.gnw, c - szb);
-    }
-    if (a.use_m && full && k > k0) {
-      gm0 = ldo(a.gmu, c - szb);
-      gm1 = ldo(a.gmv, c - szb);
-      gm2 = ldo(a.gmw, c - szb);
-    }
-    // complete the horizontal divergence of level k-1 with the neighbours' fluxes (complete since the barrier)
-    if (full && k > k0) {
-      const double* fyp = fyb + (kb ^ 1) * 3 * T;
-      hu = fma(fyp[0 * T + nid_n], rdy, hu);
-      hv = fma(fyp[1 * T + nid_n], rdy, hv);
-      hw = fma(fyp[2 * T + nid_n], rdy, hw);
-      if (xedge) {
-        const double* fxp = fxe + (kb ^ 1) * 3 * BY * NW;
-        hu = fma(fxp[0 * BY * NW + eidx], rdx, hu);
-        hv = fma(fxp[1 * BY * NW + eidx], rdx, hv);
-        hw = fma(fxp[2 * BY * NW + eidx], rdx, hw);
-      }
-    }
-    constexpr bool visc = VISC;
-    double wxm = 0, wym = 0;
-    if (visc && !last) {
-      wxm = ldo(a.w, c + szb - sxb);
-      wym = ldo(a.w, c + szb - syb);
-    }
-    auto symz_at = [&](const double* z, int idx) {
-      if (ZB && !(idx > nbz && idx < g.Nz + 1 - nbz)) return 0.5 * (z[2] + z[3]);
-      return sym4_v(z[1], z[2], z[3], z[4]);
-    };
-    auto symz = [&](const double* z) { return symz_at(z, k + 1); };
-    auto reconz_at = [&](const double* z, double ut, int idx) {
-      bool pos = ut > 0.0;
-      if (ZB) {
-        const bool ok = pos ? (idx > nbz && idx < g.Nz + 1 - (nbz - 1)) : (idx > nbz - 1 && idx < g.Nz + 1 - nbz);
-        if (!ok) return 0.5 * (z[2] + z[3]);
-      }
-      return recon5<ADV>(pos ? z[0] : z[5], pos ? z[1] : z[4], pos ? z[2] : z[3], pos ? z[3] : z[2],
-                         pos ? z[4] : z[1], pos);
-    };
-    auto reconz = [&](const double* z, double ut) { return reconz_at(z, ut, k + 1); };
-    auto sym_v = [&](double m2, double m1, double c0, double c1) { return sym4_v(m2, m1, c0, c1); };
-    auto rec_v = [&](double m3, double m2, double m1, double c0, double c1, double c2, double ut) {
-      bool pos = ut > 0.0;
-      return recon5<ADV>(pos ? m3 : c2, pos ? m2 : c1, pos ? m1 : c0, pos ? c0 : m1, pos ? c1 : m2, pos);
-    };
-    auto in_sym = [&](int idx, int N) { return idx > nbz && idx < N + 1 - nbz; };
-    auto in_rec = [&](bool pos, int idx, int N) {
-      return pos ? (idx > nbz && idx < N + 1 - (nbz - 1)) : (idx > nbz - 1 && idx < N + 1 - nbz);
-    };
-    const bool wy = REST && g.yb != 0;        // walls in y (runtime flag of the REST variants); walls in x take the x-tiled kernel
-    const int jy = j + 1;
-#define XSYM(f) sym_v(SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4))
-#define YSYM(f, idx) ((wy && !in_sym(idx, g.Ny)) ? 0.5 * (SLB(f, 2, 3) + SLB(f, 3, 3)) \
-                                               : sym_v(SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3)))
-#define XREC(f, ut) rec_v(SLB(f, 3, 0), SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4), SLB(f, 3, 5), ut)
-#define YREC(f, ut, idx) ((wy && !in_rec((ut) > 0.0, idx, g.Ny)) ? 0.5 * (SLB(f, 2, 3) + SLB(f, 3, 3)) \
-                              : rec_v(SLB(f, 0, 3), SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3), SLB(f, 5, 3), ut))
     double f0 = 0, f1 = 0, f2 = 0;            // fluxes through the west faces of this thread's u, v, w cells (level k)
     double s0 = 0, s1 = 0, s2 = 0;            // ... through the south faces
     if (!last) {
-      if (full) {
-        double utu = XSYM(0);                          // centre i-1
-        f0 = utu * XREC(0, utu);
+      if (do_x) {
+        double utu = XSYM(0, ix - 1);                  // centre i-1
+        f0 = utu * XREC(0, utu, ix - 1);
         if (visc) {
           const double dux = (SLB(0, 3, 3) - SLB(0, 3, 2)) * rdx;
           const double divw = dux + (SLB(1, 4, 2) - SLB(1, 3, 2)) * rdy + (wxm - SLB(2, 3, 2)) * rdz;   // div U at (i-1, j, k)
           f0 -= a.nu * (dux + divw);
         }
+        prio_rot(a.prio, ty, BY, 1);
         double utv = YSYM(0, jy);                      // u interpolated in y to the v row
-        f1 = utv * XREC(1, utv) - (visc ? a.nu * (SLB(1, 3, 3) - SLB(1, 3, 2)) * rdx : 0.0);
+        f1 = utv * XREC(1, utv, ix) - (visc ? a.nu * (SLB(1, 3, 3) - SLB(1, 3, 2)) * rdx : 0.0);
+        prio_rot(a.prio, ty, BY, 2);
         double utw = symz(zu);                         // u interpolated in z to the w level
-        f2 = utw * XREC(2, utw) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 3, 2)) * rdx : 0.0);
+        f2 = utw * XREC(2, utw, ix) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 3, 2)) * rdx : 0.0);
       }
       prio_mid(a.prio, ty, BY);
+      prio_rot(a.prio, ty, BY, 3);
       if (do_y) {
-        double vtu = XSYM(1);                          // v interpolated in x to the u column
+        double vtu = XSYM(1, ix);                      // v interpolated in x to the u column
         s0 = vtu * YREC(0, vtu, jy) - (visc ? a.nu * (SLB(0, 3, 3) - SLB(0, 2, 3)) * rdy : 0.0);
+        prio_rot(a.prio, ty, BY, 4);
         double vtv = YSYM(1, jy - 1);                  // centre j-1
         s1 = vtv * YREC(1, vtv, jy - 1);
         if (visc) {
@@ -619,6 +351,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
           const double divs = (SLB(0, 2, 4) - SLB(0, 2, 3)) * rdx + dvy + (wym - SLB(2, 2, 3)) * rdz;   // div U at (i, j-1, k)
           s1 -= a.nu * (dvy + divs);
         }
+        prio_rot(a.prio, ty, BY, 5);
         double vtw = symz(zv);
         s2 = vtw * YREC(2, vtw, jy) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 2, 3)) * rdy : 0.0);
         double* fyn = fyb + kb * 3 * T;
@@ -629,10 +362,13 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
     }
     double Fwu = 0, Fwv = 0, Fww = 0;
     if (full) {
-      double wtu = XSYM(2);
+      prio_rot(a.prio, ty, BY, 6);
+      double wtu = XSYM(2, ix);
       Fwu = wtu * reconz(zu, wtu);
+      prio_rot(a.prio, ty, BY, 7);
       double wtv = YSYM(2, jy);
       Fwv = wtv * reconz(zv, wtv);
+      prio_rot(a.prio, ty, BY, 8);
       double wtw = symz_at(zw, k);                    // centre below face k
       Fww = wtw * reconz_at(zw, wtw, k);
       if (visc) {
@@ -653,7 +389,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
       e0 = ocn_shfl_next(f0);
       e1 = ocn_shfl_next(f1);
       e2 = ocn_shfl_next(f2);
-      if (tx % WV == 0 && full) {
+      if (tx % WV == 0 && do_x) {
         double* fxn = fxe + kb * 3 * BY * NW + ty * NW + tx / WV;
         fxn[0 * BY * NW] = f0;
         fxn[1 * BY * NW] = f1;
@@ -692,281 +428,6 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
         bu = Fwu;
         bv = Fwv;
         bw = Fww;
-      }
-    }
-    if (!last) {
-#pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        zu[q] = zu[q + 1];
-        zv[q] = zv[q + 1];
-        zw[q] = zw[q + 1];
-      }
-      zu[5] = ldo(a.u, c + 3 * szb);
-      zv[5] = ldo(a.v, c + 3 * szb);
-      zw[5] = ldo(a.w, c + 3 * szb);
-    }
-  }
-  }  // segments
-#undef SLB
-}
-
-// ---- x-tiled variant of k_tend_step3 for rows wider than a workgroup (Nx > 256) ------------------------------------
-// A workgroup owns BXo < BX output columns of BY-1 output rows.  Thread column `nout` is a ghost column: it only
-// produces the WEST-face fluxes that the last output column needs as its EAST fluxes (the same device as the ghost
-// row in y); x halos of the slab are read from the arrays' own halo columns (the projection keeps their periodic
-// images current) instead of being wrapped inside LDS.  Tiles are (x-tile, y-tile) pairs, x fastest.
-template <int ADV, int BX, int BY, bool VISC, bool ZB, bool REST>
-__global__ void __launch_bounds__(BX* BY) k_tend_step3x(GridDev g, FusedArgs a) {
-  constexpr bool EARLY = true, FENCE3 = false;
-  constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
-  constexpr int NG = (NR + BY - 1) / BY;   // row groups of the cooperative slab load
-  OCN_SHARED double slab[3 * NR * SX];     // [field][row][column]; element (f, r, s) <-> (j0 - 3 + r, s - 3)
-  OCN_SHARED double fx[6 * T];             // flux exchange
-  OCN_SHARED double own[6 * T];            // carry: horizontal divergence + bottom fluxes of the previous level
-  const int tx = threadIdx.x, ty = threadIdx.y;
-  const int tid = ty * BX + tx;
-  const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
-  const double rdx = g.rdx, rdy = g.rdy, rdz = 1.0 / g.dz;
-  const int nbz = (ADV == ADV_C4) ? 1 : 2;   // boundary buffer of the scheme (ZB, see k_tend_step3)
-  const bool ghost = (ty == BY - 1);
-  const int nid_e = ty * BX + (tx + 1 < BX ? tx + 1 : tx);   // the east neighbour is the next thread (output or ghost column)
-  const int nid_n = (ty + 1 < BY ? ty + 1 : ty) * BX + tx;
-  // Work decomposition: the (y-tile, level) space is cut into gridDim.x equal segments of consecutive levels
-  // (tile-major), so every workgroup marches the same number of levels whatever Ny/(BY-1) is -- no partial
-  // last round.  XCD-aware: workgroups b and b+8 share an L2, so each XCD gets a contiguous band of segments.
-  const int nseg = gridDim.x, per = nseg / 8;
-  const long seg = (nseg % 8 == 0) ? (long)(blockIdx.x % 8) * per + blockIdx.x / 8 : (long)blockIdx.x;
-  const long total = (long)a.ntiles * g.Nz;
-  long lo = seg * total / nseg;
-  const long hi = (seg + 1) * total / nseg;
-  while (lo < hi) {
-  const int tile = (int)(lo / g.Nz);
-  const int k0 = (int)(lo - (long)tile * g.Nz);
-  const int ytile = tile / a.ntx, xt = tile - ytile * a.ntx;
-  const int i0 = xt * a.BXo;
-  const int nout = (g.Nx - i0 < a.BXo) ? g.Nx - i0 : a.BXo;   // output columns of this x-tile; column `nout` is the ghost column
-  const int i = i0 + tx;
-  const bool ocol = tx < nout, col_ok = tx <= nout, ldcol = tx < nout + 7;
-  const int k1 = (k0 + (hi - lo) < g.Nz) ? (int)(k0 + (hi - lo)) : g.Nz;
-  lo += k1 - k0;
-  const int j0 = ytile * (BY - 1);
-  const int j = j0 + ty;
-  const bool row_ok = j < g.Ny;
-  const bool do_y = ocol && j <= g.Ny;
-  const bool full = ocol && row_ok && !ghost;
-  const bool do_x = col_ok && row_ok && !ghost;      // west-face fluxes, ghost column included
-  const unsigned cxy = a.org + (unsigned)(col_ok ? i : 0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
-
-  // cooperative slab load: thread row ty handles slab rows r = ty + BY*gq of every field
-  const unsigned grow = a.org + (unsigned)((ldcol ? i0 + tx : i0 + 3) - 3) * sxb;   // slab column tx <-> global column i0 - 3 + tx
-  double pf[3][NG];
-  auto prefetch = [&](int k) {
-#pragma unroll
-    for (int gq = 0; gq < NG; ++gq) {
-      int r = ty + BY * gq;
-      if (r < NR) {
-        int jg = j0 - 3 + r;
-        if (jg > g.Ny + 2) jg = g.Ny + 2;              // rows past the halo are never used
-        unsigned o = grow + (unsigned)(jg + 3) * syb - 3u * syb + (unsigned)k * szb;
-        pf[0][gq] = ldo(a.u, o);
-        pf[1][gq] = ldo(a.v, o);
-        pf[2][gq] = ldo(a.w, o);
-      }
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int gq = 0; gq < NG; ++gq) {
-      int r = ty + BY * gq;
-      if (r < NR && ldcol) {
-#pragma unroll
-        for (int fl = 0; fl < 3; ++fl) slab[(fl * NR + r) * SX + tx] = pf[fl][gq];   // x halos come from the arrays' own halos
-      }
-    }
-  };
-  // lowest corner of this thread's stencil footprint: element (f, ty + d, tx + e) = S[f*NR*SX + d*SX + e],
-  // own cell at d = e = 3.  All offsets below are compile-time constants.
-  const double* S = slab + ty * SX + tx;
-#define SLB(f, d, e) S[(f) * NR * SX + (d) * SX + (e)]
-
-  double zu[6], zv[6], zw[6];
-  {
-    const unsigned c = cxy + (unsigned)k0 * szb;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      zu[q] = ldo(a.u, c + (unsigned)(q - 3) * szb);
-      zv[q] = ldo(a.v, c + (unsigned)(q - 3) * szb);
-      zw[q] = ldo(a.w, c + (unsigned)(q - 3) * szb);
-    }
-  }
-  double dprev = 0.0;
-  if (VISC) {   // div U of the cell below the first level of this march
-    const unsigned cb = cxy + (unsigned)k0 * szb - szb;
-    dprev = (ldo(a.u, cb + sxb) - zu[2]) * rdx + (ldo(a.v, cb + syb) - zv[2]) * rdy + (zw[3] - zw[2]) * rdz;
-  }
-  prefetch(k0);
-  for (int k = k0; k <= k1; ++k) {
-    const unsigned c = cxy + (unsigned)k * szb;
-    const bool last = (k == k1);
-    commit();
-    if (!(a.dbg_nobar & 2)) __syncthreads();
-    if (EARLY && !last) prefetch(k + 1);   // next level's slab in flight during the whole flux stage
-    double gm0 = 0, gm1 = 0, gm2 = 0;      // G^- of the level finalized below, also fetched early
-    double rs0 = 0, rs1 = 0, rs2 = 0;      // REST: the non-advective part of G^n waiting in the G^n arrays
-    if (REST && full && k > k0) {
-      rs0 = ldo(a.gnu, c - szb);
-      rs1 = ldo(a.gnv, c - szb);
-      rs2 = ldo(a.gnw, c - szb);
-    }
-    if (EARLY && a.use_m && full && k > k0) {
-      gm0 = ldo(a.gmu, c - szb);
-      gm1 = ldo(a.gmv, c - szb);
-      gm2 = ldo(a.gmw, c - szb);
-    }
-    // ScalarDiffusivity (closure_kernel_operators.jl:22-41 with constant nu): div(2 nu Sigma)_i = nu (lap u_i + d_i div U),
-    // exactly (centred differences commute on a uniform grid).  Both parts are face fluxes at the very places of
-    // the advective ones: -nu d(u_i)/dn through every face, plus -nu div U through the centre-located face of the
-    // normal component -- so they ride along in fx / Fw with no extra storage.  div U at the west / south cells
-    // needs w one level up in the neighbouring column (two extra loads); at the cell below it is the value this
-    // thread computed one level earlier (dprev).
-    constexpr bool visc = VISC;   // compile-time: the inviscid kernel must not pay registers for these terms
-    double wxm = 0, wym = 0;
-    if (visc && !last) {
-      wxm = ldo(a.w, c + szb - sxb);
-      wym = ldo(a.w, c + szb - syb);
-    }
-    auto symz_at = [&](const double* z, int idx) {
-      if (ZB && !(idx > nbz && idx < g.Nz + 1 - nbz)) return 0.5 * (z[2] + z[3]);
-      return sym4_v(z[1], z[2], z[3], z[4]);
-    };
-    auto symz = [&](const double* z) { return symz_at(z, k + 1); };
-    auto reconz_at = [&](const double* z, double ut, int idx) {
-      bool pos = ut > 0.0;
-      if (ZB) {
-        const bool ok = pos ? (idx > nbz && idx < g.Nz + 1 - (nbz - 1)) : (idx > nbz - 1 && idx < g.Nz + 1 - nbz);
-        if (!ok) return 0.5 * (z[2] + z[3]);
-      }
-      return recon5<ADV>(pos ? z[0] : z[5], pos ? z[1] : z[4], pos ? z[2] : z[3], pos ? z[3] : z[2],
-                         pos ? z[4] : z[1], pos);
-    };
-    auto reconz = [&](const double* z, double ut) { return reconz_at(z, ut, k + 1); };
-    auto sym_v = [&](double m2, double m1, double c0, double c1) { return sym4_v(m2, m1, c0, c1); };  // midway m1|c0
-    auto rec_v = [&](double m3, double m2, double m1, double c0, double c1, double c2, double ut) {
-      bool pos = ut > 0.0;                                            // face between m1 and c0
-      return recon5<ADV>(pos ? m3 : c2, pos ? m2 : c1, pos ? m1 : c0, pos ? c0 : m1, pos ? c1 : m2, pos);
-    };
-    // Walls in x / y (REST variants only; g.xb / g.yb are runtime flags): inside the boundary buffer every stencil falls
-    // back to 2nd order, exactly as adv_flux_b / sym_b of the general kernels (idx: 1-based index along the stencil).
-    auto in_sym = [&](int idx, int N) { return idx > nbz && idx < N + 1 - nbz; };
-    auto in_rec = [&](bool pos, int idx, int N) {
-      return pos ? (idx > nbz && idx < N + 1 - (nbz - 1)) : (idx > nbz - 1 && idx < N + 1 - nbz);
-    };
-    const bool wx = REST && g.xb != 0, wy = REST && g.yb != 0;
-    const int ix = i + 1, jy = j + 1;                 // 1-based face indices of this thread's u / v cells
-#define XSYM(f, idx) ((wx && !in_sym(idx, g.Nx)) ? 0.5 * (SLB(f, 3, 2) + SLB(f, 3, 3)) \
-                                               : sym_v(SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4)))
-#define YSYM(f, idx) ((wy && !in_sym(idx, g.Ny)) ? 0.5 * (SLB(f, 2, 3) + SLB(f, 3, 3)) \
-                                               : sym_v(SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3)))
-#define XREC(f, ut, idx) ((wx && !in_rec((ut) > 0.0, idx, g.Nx)) ? 0.5 * (SLB(f, 3, 2) + SLB(f, 3, 3)) \
-                              : rec_v(SLB(f, 3, 0), SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4), SLB(f, 3, 5), ut))
-#define YREC(f, ut, idx) ((wy && !in_rec((ut) > 0.0, idx, g.Ny)) ? 0.5 * (SLB(f, 2, 3) + SLB(f, 3, 3)) \
-                              : rec_v(SLB(f, 0, 3), SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3), SLB(f, 5, 3), ut))
-    if (!last) {
-      if (do_x) {
-        double utu = XSYM(0, ix - 1);                  // centre i-1
-        double f0 = utu * XREC(0, utu, ix - 1);
-        if (visc) {
-          const double dux = (SLB(0, 3, 3) - SLB(0, 3, 2)) * rdx;
-          const double divw = dux + (SLB(1, 4, 2) - SLB(1, 3, 2)) * rdy + (wxm - SLB(2, 3, 2)) * rdz;   // div U at (i-1, j, k)
-          f0 -= a.nu * (dux + divw);
-        }
-        fx[0 * T + tid] = f0;
-        if (FENCE3) OCN_SCHED_FENCE();
-        double utv = YSYM(0, jy);                      // u interpolated in y to the v row
-        fx[1 * T + tid] = utv * XREC(1, utv, ix) - (visc ? a.nu * (SLB(1, 3, 3) - SLB(1, 3, 2)) * rdx : 0.0);
-        if (FENCE3) OCN_SCHED_FENCE();
-        double utw = symz(zu);                         // u interpolated in z to the w level
-        fx[2 * T + tid] = utw * XREC(2, utw, ix) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 3, 2)) * rdx : 0.0);
-        if (FENCE3) OCN_SCHED_FENCE();
-      }
-      if (do_y) {
-        double vtu = XSYM(1, ix);                      // v interpolated in x to the u column
-        fx[3 * T + tid] = vtu * YREC(0, vtu, jy) - (visc ? a.nu * (SLB(0, 3, 3) - SLB(0, 2, 3)) * rdy : 0.0);
-        if (FENCE3) OCN_SCHED_FENCE();
-        double vtv = YSYM(1, jy - 1);                  // centre j-1
-        double f4 = vtv * YREC(1, vtv, jy - 1);
-        if (visc) {
-          const double dvy = (SLB(1, 3, 3) - SLB(1, 2, 3)) * rdy;
-          const double divs = (SLB(0, 2, 4) - SLB(0, 2, 3)) * rdx + dvy + (wym - SLB(2, 2, 3)) * rdz;   // div U at (i, j-1, k)
-          f4 -= a.nu * (dvy + divs);
-        }
-        fx[4 * T + tid] = f4;
-        if (FENCE3) OCN_SCHED_FENCE();
-        double vtw = symz(zv);
-        fx[5 * T + tid] = vtw * YREC(2, vtw, jy) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 2, 3)) * rdy : 0.0);
-        if (FENCE3) OCN_SCHED_FENCE();
-      }
-    }
-    double Fwu = 0, Fwv = 0, Fww = 0;
-    if (full) {
-      double wtu = XSYM(2, ix);
-      Fwu = wtu * reconz(zu, wtu);
-      if (FENCE3) OCN_SCHED_FENCE();
-      double wtv = YSYM(2, jy);
-      Fwv = wtv * reconz(zv, wtv);
-      if (FENCE3) OCN_SCHED_FENCE();
-      double wtw = symz_at(zw, k);                    // centre below face k
-      Fww = wtw * reconz_at(zw, wtw, k);
-      if (visc) {
-        Fwu -= a.nu * (zu[3] - zu[2]) * rdz;
-        Fwv -= a.nu * (zv[3] - zv[2]) * rdz;
-        const double dwz = (zw[3] - zw[2]) * rdz;
-        Fww -= a.nu * (dwz + dprev);                    // dprev = div U at (i, j, k-1)
-        if (!last) dprev = (SLB(0, 3, 4) - SLB(0, 3, 3)) * rdx + (SLB(1, 4, 3) - SLB(1, 3, 3)) * rdy + (zw[4] - zw[3]) * rdz;
-      }
-    }
-#undef XSYM
-#undef YSYM
-#undef XREC
-#undef YREC
-    if (!(a.dbg_nobar & 1)) __syncthreads();
-    if (!EARLY && !last) prefetch(k + 1);  // in flight during the (cheap) finalize stage; committed at the loop top
-    if (full) {
-      if (k > k0) {
-        const unsigned cm1 = c - szb;
-        const double rzc = ZB ? g_rdzc(g, k - 1) : rdz, rzf = ZB ? g_rdzf(g, k - 1) : rdz;
-        double Gu = rs0 - (own[0 * T + tid] + (Fwu - own[3 * T + tid]) * rzc);
-        double Gv = rs1 - (own[1 * T + tid] + (Fwv - own[4 * T + tid]) * rzc);
-        double Gw = rs2 - (own[2 * T + tid] + (Fww - own[5 * T + tid]) * rzf);
-        sto(a.gnu, cm1, Gu);
-        sto(a.gnv, cm1, Gv);
-        sto(a.gnw, cm1, Gw);
-        double iu, iv, iw;
-        if (a.use_m) {
-          if (!EARLY) {
-            gm0 = ldo(a.gmu, cm1);
-            gm1 = ldo(a.gmv, cm1);
-            gm2 = ldo(a.gmw, cm1);
-          }
-          iu = a.dt * (a.cn * Gu + a.cm * gm0);
-          iv = a.dt * (a.cn * Gv + a.cm * gm1);
-          iw = a.dt * (a.cn * Gw + a.cm * gm2);
-        } else {
-          iu = a.dt * a.cn * Gu;
-          iv = a.dt * a.cn * Gv;
-          iw = a.dt * a.cn * Gw;
-        }
-        sto(a.us, cm1, zu[2] + iu);
-        sto(a.vs, cm1, zv[2] + iv);
-        sto(a.ws, cm1, zw[2] + iw);
-      }
-      if (!last) {
-        own[0 * T + tid] = (fx[0 * T + nid_e] - fx[0 * T + tid]) * rdx + (fx[3 * T + nid_n] - fx[3 * T + tid]) * rdy;
-        own[1 * T + tid] = (fx[1 * T + nid_e] - fx[1 * T + tid]) * rdx + (fx[4 * T + nid_n] - fx[4 * T + tid]) * rdy;
-        own[2 * T + tid] = (fx[2 * T + nid_e] - fx[2 * T + tid]) * rdx + (fx[5 * T + nid_n] - fx[5 * T + tid]) * rdy;
-        own[3 * T + tid] = Fwu;
-        own[4 * T + tid] = Fwv;
-        own[5 * T + tid] = Fww;
       }
     }
     if (!last) {
@@ -1314,19 +775,31 @@ static int fused_cu_count(const ocn_model* m) {
 struct FusedShape {
   int bx, by;
   bool wide, small;
-  bool dma;      // complete rows with the slab's pitch in memory: LDS-DMA staging (k_tend4<DMA = true>)
-  bool v3;       // OCNHIP_TEND3=1: the two-barrier kernel of round 1 (A/B timing only)
+  bool dma;      // slab rows staged by global_load_lds (k_tend4<DMA = true>)
   dim3 blk, grd;
 };
+
+// Tuning / test knobs of the tiled kernels: read ONCE, when the model is created, never on a launch path.
+//   OCNHIP_FUSED_XT=1     force the x-tiled variant on small grids (tests)
+//   OCNHIP_NO_LDS_DMA=1   stage the slab through registers even where the LDS-DMA path is legal (tests)
+//   OCNHIP_NO_TRACER3=1   column tracer kernel instead of the tiled one (tests)
+//   OCNHIP_PRIO=n         wave-priority scheme (default 2; 0 = none)
+void fused_read_knobs(ocn_model* m) {
+  auto env = [](const char* n, int def) { const char* e = getenv(n); return e ? atoi(e) : def; };
+  m->knob_fused_xt = env("OCNHIP_FUSED_XT", 0);
+  m->knob_no_dma = env("OCNHIP_NO_LDS_DMA", 0);
+  m->knob_no_tracer3 = env("OCNHIP_NO_TRACER3", 0);
+  m->knob_prio = env("OCNHIP_PRIO", 2);
+}
+
 static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
   const GridDev& gd = m->gd;
   FusedShape f;
-  const int xt_env = getenv("OCNHIP_FUSED_XT") ? atoi(getenv("OCNHIP_FUSED_XT")) : 0;   // 1: force the x-tiled kernel (tests)
-  f.small = xt_env == 1 && gd.Nx <= 57 * 4;       // test shape: 64 x 4 threads, up to 57 output columns, >= 2 tiles
+  f.small = m->knob_fused_xt == 1 && gd.Nx <= 57 * 4;   // test shape: 64 x 4 threads, up to 56 output columns, >= 2 tiles
 #ifdef OCN_HOST_EMU
   if (gd.xb && gd.Nx <= 57 * 4) f.small = true;   // the emulation spawns one OS thread per GPU thread: keep workgroups small
 #endif
-  f.wide = gd.Nx > 256 || f.small || gd.xb;          // walls in x: no periodic wrap inside LDS -> the x-tiled kernel
+  f.wide = gd.Nx > 256 || f.small || gd.xb;          // walls in x: no periodic wrap inside LDS -> x-tiles
   f.bx = f.small ? 64 : f.wide ? 192 : gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
   f.by = f.small ? 4 : f.wide ? 5 : f.bx == 256 ? 4 : 8;
 #ifdef OCN_HOST_EMU
@@ -1342,10 +815,12 @@ static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
   a.ntx = 1;
   a.BXo = 0;
   if (f.wide) {
-    const int cap = f.bx - 7;                     // the slab of a tile is loaded by one thread per column: outputs + 7
-    a.ntx = (gd.Nx + cap - 1) / cap;
+    const int cap = (f.bx - 7) & ~1;              // outputs + ghost column + 6 halo columns <= bx; even, so that every
+    a.ntx = (gd.Nx + cap - 1) / cap;              // tile's slab rows start on a 16-byte boundary (LDS-DMA)
     if (f.small && a.ntx < 2) a.ntx = 2;
     a.BXo = (gd.Nx + a.ntx - 1) / a.ntx;
+    a.BXo += a.BXo & 1;
+    a.ntx = (gd.Nx + a.BXo - 1) / a.BXo;
     a.ntiles *= a.ntx;
   }
   int nseg = fused_cu_count(m);                   // one workgroup is resident per CU
@@ -1357,35 +832,31 @@ static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
 #endif
   f.blk = dim3(f.bx, f.by, 1);
   f.grd = dim3(nseg, 1, 1);
-  static const int env_v3 = getenv("OCNHIP_TEND3") ? atoi(getenv("OCNHIP_TEND3")) : 0;
-  static const int env_nodma = getenv("OCNHIP_NO_LDS_DMA") ? atoi(getenv("OCNHIP_NO_LDS_DMA")) : 0;
-  f.v3 = env_v3 != 0;
-  // 16-byte pieces: the slab chunk starts at column -3 of a row, i.e. at parent column Hx - 3 = 0, rows are sy = Nx + 6
-  // (even) doubles apart and planes sz = sy * rows doubles; the arrays come from hipMalloc (256-byte aligned)
-  f.dma = !f.wide && !env_nodma && gd.Nx == f.bx && gd.Hx == 3 && gd.sy == gd.Nx + 6 && (gd.sy % 2 == 0) && (gd.sz % 2 == 0);
+  // 16-byte pieces: a slab row starts at parent column Hx - 3 + i0 (i0 = x-tile origin, even), rows are sy doubles apart,
+  // planes sz doubles; the arrays come from hipMalloc (256-byte aligned)
+  f.dma = !m->knob_no_dma && gd.Hx == 3 && gd.Nx % 2 == 0 && gd.sy % 2 == 0 && gd.sz % 2 == 0;
   return f;
 }
 
 // launch one of the instantiations: VISCV / ZBV / RESTV are compile-time constants at the call site
+#define FUSED_T4(ADVV, BXV, BYV, XTV, VISCV, ZBV, RESTV)                                                                   \
+  { if (f.dma) ocn_launch_sync(k_tend4<ADVV, BXV, BYV, XTV, true, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);          \
+    else ocn_launch_sync(k_tend4<ADVV, BXV, BYV, XTV, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); }
 #ifdef OCN_HOST_EMU
 #define FUSED_EMU16(ADVV, VISCV, ZBV, RESTV)                                                                               \
-  if (f.bx == 16 && f.small) ocn_launch_sync(k_tend_step3x<ADVV, 16, 4, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);     \
-  else if (f.bx == 16) FUSED_T4(ADVV, 16, 4, VISCV, ZBV, RESTV)                                                            \
+  if (f.bx == 16 && f.small) FUSED_T4(ADVV, 16, 4, true, VISCV, ZBV, RESTV)                                                \
+  else if (f.bx == 16) FUSED_T4(ADVV, 16, 4, false, VISCV, ZBV, RESTV)                                                     \
   else
 #else
 #define FUSED_EMU16(ADVV, VISCV, ZBV, RESTV)
 #endif
-#define FUSED_T4(ADVV, BXV, BYV, VISCV, ZBV, RESTV)                                                                        \
-  { if (f.dma) ocn_launch_sync(k_tend4<ADVV, BXV, BYV, true, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);               \
-    else ocn_launch_sync(k_tend4<ADVV, BXV, BYV, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); }
 #define FUSED_LAUNCH(ADVV, VISCV, ZBV, RESTV)                                                                              \
   FUSED_EMU16(ADVV, VISCV, ZBV, RESTV)                                                                                     \
-  if (f.small) ocn_launch_sync(k_tend_step3x<ADVV, 64, 4, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);                  \
-  else if (f.wide) ocn_launch_sync(k_tend_step3x<ADVV, 192, 5, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);             \
-  else if (f.v3 && f.bx == 256) ocn_launch_sync(k_tend_step3<ADVV, 256, 4, true, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); \
-  else if (f.bx == 256) FUSED_T4(ADVV, 256, 4, VISCV, ZBV, RESTV)                                                          \
-  else if (f.bx == 128) FUSED_T4(ADVV, 128, 8, VISCV, ZBV, RESTV)                                                          \
-  else FUSED_T4(ADVV, 64, 8, VISCV, ZBV, RESTV)
+  if (f.small) FUSED_T4(ADVV, 64, 4, true, VISCV, ZBV, RESTV)                                                              \
+  else if (f.wide) FUSED_T4(ADVV, 192, 5, true, VISCV, ZBV, RESTV)                                                         \
+  else if (f.bx == 256) FUSED_T4(ADVV, 256, 4, false, VISCV, ZBV, RESTV)                                                   \
+  else if (f.bx == 128) FUSED_T4(ADVV, 128, 8, false, VISCV, ZBV, RESTV)                                                   \
+  else FUSED_T4(ADVV, 64, 8, false, VISCV, ZBV, RESTV)
 #define FUSED_BY_SCHEME(VISCV, ZBV, RESTV)                            \
   switch (m->d.advection) {                                           \
     case ADV_WENO_Z: { FUSED_LAUNCH(ADV_WENO_Z, VISCV, ZBV, RESTV) } break;   \
@@ -1400,36 +871,9 @@ static void fused_fill_args(ocn_model* m, FusedArgs& a, double dt, double cn, do
   a.us = m->us.d; a.vs = m->vs.d; a.ws = m->ws.d;
   a.org = (unsigned)((m->u.Hx + m->u.Hy * m->u.sy + m->u.Hz * m->u.sz) * sizeof(double));
   a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
-  static const int env_nobar = getenv("OCNHIP_DBG_NOBAR") ? atoi(getenv("OCNHIP_DBG_NOBAR")) : 0;
-  static const int env_prio = getenv("OCNHIP_PRIO") ? atoi(getenv("OCNHIP_PRIO")) : 0;
-  a.dbg_nobar = env_nobar;
-  a.prio = env_prio;
+  a.prio = m->knob_prio;
   a.nu = 0.0;
-#ifdef OCN_DIAG_STAMPS
-  a.diag = nullptr;
-#endif
 }
-#ifdef OCN_DIAG_STAMPS
-// diagnostic build: where do the waves of the tendency kernel spend their cycles?  Printed once, after the 30th launch.
-static unsigned long long* g_diag = nullptr;
-static int g_diag_launches = 0;
-static void diag_report(hipStream_t s, int nblocks, int waves) {
-  if (++g_diag_launches != 30) return;
-  hipStreamSynchronize(s);
-  std::vector<unsigned long long> h((size_t)nblocks * waves * 4);
-  hipMemcpy(h.data(), g_diag, h.size() * 8, hipMemcpyDeviceToHost);
-  double sum[2][4] = {{0}}, n[2] = {0, 0};
-  for (int b = 0; b < nblocks; ++b)
-    for (int w = 0; w < waves; ++w) {
-      const int ghost = w >= waves - waves / 4;      // BY = 4: the last quarter of the waves is the ghost row
-      for (int q = 0; q < 4; ++q) sum[ghost][q] += (double)h[((size_t)b * waves + w) * 4 + q];
-      n[ghost] += 1;
-    }
-  for (int gq = 0; gq < 2; ++gq)
-    fprintf(stderr, "[diag] %s waves: barrier A %.0f  flux stage %.0f  barrier B %.0f  finalize+loop %.0f  (memtime ticks per wave per launch)\n",
-            gq ? "ghost-row" : "output-row", sum[gq][0] / n[gq], sum[gq][1] / n[gq], sum[gq][2] / n[gq], sum[gq][3] / n[gq]);
-}
-#endif
 
 // all-in-one path: triply periodic, no closure or ScalarDiffusivity
 void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m) {
@@ -1439,18 +883,11 @@ void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int u
   a.nu = m->d.closure == OCN_CLOSURE_SCALAR ? m->d.nu : 0.0;
   const FusedShape f = fused_shape(m, a);
   hipStream_t s = m->ctx->stream;
-#ifdef OCN_DIAG_STAMPS
-  if (!g_diag) hipMalloc((void**)&g_diag, (size_t)f.grd.x * 16 * 4 * 8);
-  a.diag = g_diag;
-#endif
   if (a.nu != 0.0) {
     FUSED_BY_SCHEME(true, false, false)
   } else {
     FUSED_BY_SCHEME(false, false, false)
   }
-#ifdef OCN_DIAG_STAMPS
-  diag_report(s, f.grd.x, f.bx * f.by / 64);
-#endif
 }
 
 // ---- Bounded z: advection + time-stepper update of u, v, w on top of the general kernels' other terms ----------------
@@ -1464,7 +901,7 @@ bool fused_bz_available(const ocn_model* m) {
   for (int d = 0; d < 3; ++d)
     if (g->H[d] < 3 || g->N[d] < 2 * g->H[d]) return false;
   if (m->u.n * sizeof(double) >= (1ull << 31) || m->w.n * sizeof(double) >= (1ull << 31)) return false;
-  if (getenv("OCNHIP_NO_FUSED") || getenv("OCNHIP_NO_FUSED_BZ")) return false;
+  if (getenv("OCNHIP_NO_FUSED") || getenv("OCNHIP_NO_FUSED_BZ")) return false;   // model creation only
   return true;
 }
 
@@ -1488,8 +925,7 @@ void launch_fused_bz(ocn_model* m, double dt, double cn, double cm, int use_m) {
 void launch_rhs_wrap(ocn_model* m, double dt, double* rhs) {
   ProfScope ps(m->ctx, "rhs");
   const GridDev& g = m->gd;
-  static const int bxr = getenv("OCNHIP_PROJ_BX") ? atoi(getenv("OCNHIP_PROJ_BX")) : 256;
-  dim3 b(bxr, 256 / bxr, 1), gr((g.Nx + b.x - 1) / b.x, (g.Ny + b.y - 1) / b.y, g.Nz);
+  dim3 b(256, 1, 1), gr((g.Nx + b.x - 1) / b.x, (g.Ny + b.y - 1) / b.y, g.Nz);
   ocn_launch(k_rhs_wrap, gr, b, m->ctx->stream, g, (const double*)m->us.interior(), (const double*)m->vs.interior(),
              (const double*)m->ws.interior(), 1.0 / dt, m->g->dist ? 0 : 1, rhs);
 }
@@ -1504,8 +940,7 @@ void launch_project(ocn_model* m, double dt, const double* phi) {
   a.dt = dt;
   a.zwrap = m->g->dist ? 0 : 1;
   a.phi_below = m->phi_below;
-  static const int bxp = getenv("OCNHIP_PROJ_BX") ? atoi(getenv("OCNHIP_PROJ_BX")) : 256;
-  dim3 b(bxp, 256 / bxp, 1), gr((g.Nx + b.x - 1) / b.x, (g.Ny + b.y - 1) / b.y, g.Nz);
+  dim3 b(256, 1, 1), gr((g.Nx + b.x - 1) / b.x, (g.Ny + b.y - 1) / b.y, g.Nz);
   ocn_launch(k_project, gr, b, m->ctx->stream, g, a);
 }
 
@@ -1534,7 +969,7 @@ int fused_exchange_phi(ocn_model* m, const double* phi) {
 }
 
 bool fused_tracer3_ok(const ocn_model* m) {
-  return m->gd.Nx <= 256 && !m->gd.xb && !getenv("OCNHIP_NO_TRACER3");
+  return m->gd.Nx <= 256 && !m->gd.xb && !m->knob_no_tracer3;
 }
 
 // tiled tracer kernel for every tracer; rest: G^n(tracers) holds the non-advective terms and halos are filled by the caller

@@ -115,6 +115,7 @@ struct ocn_model {
   // the projection writes u = U* - dt grad p back into u, v, w, so their device pointers never change.
   bool pred_active = false;
   ocn_grid* own_grid = nullptr;   // private copy of the caller's grid when the advection scheme needs wider halos
+  int knob_fused_xt = 0, knob_no_dma = 0, knob_no_tracer3 = 0, knob_prio = 2;   // fused_read_knobs(), at creation
 };
 inline Field& pred_u(ocn_model* m) { return m->pred_active ? m->us : m->u; }
 inline Field& pred_v(ocn_model* m) { return m->pred_active ? m->vs : m->v; }
@@ -144,6 +145,7 @@ void launch_amd(ocn_model* m);
 int amd_build_table(ocn_model* m);
 
 // ---- fused.hip -----------------------------------------------------------------------------------------
+void fused_read_knobs(ocn_model* m);
 bool fused_available(const ocn_model* m);
 bool fused_bz_available(const ocn_model* m);
 void launch_fused_bz(ocn_model* m, double dt, double cn, double cm, int use_m);

@@ -22,6 +22,14 @@ def init_comm(ctx, dist, rank, world):
     check(ctx.lib.ocn_comm_init(ctx.h, int(rank), int(world), raw), ctx.h)
 
 
+def init_comm_self(ctx):
+    """one-rank communicator (tests on a one-GPU box, with OCNHIP_RCCL_SELF=1): forced slab runs then exchange with
+    themselves through RCCL's grouped send / recv instead of plain device copies."""
+    raw = (C.c_char * 128)()
+    check(ctx.lib.ocn_comm_unique_id(raw))
+    check(ctx.lib.ocn_comm_init(ctx.h, 0, 1, raw), ctx.h)
+
+
 def init_comm_local(ctx, rank, world):
     """host-emulation ranks living in one process (tests): the id is ignored."""
     raw = (C.c_char * 128)()

@@ -266,3 +266,31 @@ def test_config3_full_size_properties(ocn):
     dT = (T_after - T_before) - tT
     assert -1.01 * leak - 1e-12 * abs(T_before) - 1e-9 * abs(tT) <= dT <= 1e-12 * abs(T_before) + 1e-9 * abs(tT)
     assert np.isfinite(m.tracers["T"].interior()).all()
+
+
+def test_forced_slab_through_rccl_self(ocn, monkeypatch):
+    """The slab code path exchanging with itself through RCCL (a one-rank communicator, grouped ncclSend / ncclRecv on the
+    library's stream, byte counts as in a multi-GPU run) instead of device copies: z-slab WENO5 AB2 vs the oracle.  Sends
+    and receives of one group pair up in posting order -- the rule the multi-rank exchanges rely on."""
+    import oracle as O
+    from importlib import import_module
+    monkeypatch.setenv("OCNHIP_FORCE_DIST", "1")
+    monkeypatch.setenv("OCNHIP_RCCL_SELF", "1")
+    monkeypatch.delenv("OCNHIP_TRANSPORT", raising=False)
+    par = import_module("ocnhip.parallel")
+    ctx = ocn.Context(0)
+    par.init_comm_self(ctx)
+    N = (32, 24, 18)
+    rng = np.random.default_rng(11)
+    init = {n: rng.random(N) - 0.5 for n in "uvw"}
+    init["c"] = rng.random(N)
+    kw = dict(size=N, extent=(1, 0.75, 0.5), topology=("Periodic",) * 3)
+    m = ocn.NonhydrostaticModel(ocn.RectilinearGrid(ctx, **kw), advection=ocn.WENO5(), tracers=("c",))
+    om = O.NonhydrostaticModel(O.RectilinearGrid(**kw), advection=O.WENO5(), tracers=("c",))
+    ocn.set_model(m, **init)
+    O.set_model(om, **init)
+    for _ in range(2):
+        ocn.time_step(m, 2e-3)
+        O.time_step(om, 2e-3)
+    for a, b in ((m.u, om.u), (m.v, om.v), (m.w, om.w), (m.pNHS, om.pNHS), (m.tracers["c"], om.tracers["c"])):
+        assert np.abs(a.parent() - b.data).max() <= 2e-11 * np.abs(b.data).max()
