@@ -52,6 +52,9 @@ __device__ __forceinline__ double ocn_shfl_next(double x) {
   return b.d;
 }
 #define OCN_WAVE 64
+// a value that is the same in every lane of the wave, moved to a scalar register: branches on it are scalar branches
+// (s_setprio and the LDS-DMA base in M0 are scalar state -- behind a "divergent" branch they would execute regardless of EXEC)
+#define OCN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 
 #else
 // ------------------------------------------------------------------------------------------------
@@ -143,6 +146,7 @@ static inline void __syncthreads() { g_emu_barrier.wait(); }
 
 // wave-level primitives, emulated with one OS thread per GPU thread (every thread of the block must make the call)
 #define OCN_WAVE 64
+#define OCN_UNIFORM(x) (x)
 static inline void ocn_glds16(const void* src_lane, void* dst_wave_base, int lane) {
   memcpy((char*)dst_wave_base + 16 * lane, src_lane, 16);
 }

@@ -49,20 +49,16 @@ struct FusedArgs {
 //   1: ghost-row waves run at priority 3 (they are short: get them out of the way first)
 //   2: 1 + the first output row drops to the lowest priority half way through a level, the last one rises
 //   3: priority = row index (inverts the age order)
+// Measured (256^3, ms per launch): none 0.583, 1: 0.592, 2: 0.551, 3: 0.588.  A finer rotation (a priority change after
+// every reconstruction) made it 0.85: every s_setprio sits behind a wave-uniform branch, and nine more basic-block
+// boundaries per level take away the scheduler's freedom to interleave the reconstructions.
 #ifndef OCN_HOST_EMU
 #define OCN_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #else
 #define OCN_SETPRIO(n) ((void)0)
 #endif
-//   4 (experiment): output rows rotate through priorities 0..2 after every reconstruction pair
-OCN_DEVFN void prio_rot(int mode, int ty, int BY, int idx) {
-  if (mode != 4 || ty == BY - 1) return;
-  const int p = (ty + idx) % 3;
-  if (p == 0) OCN_SETPRIO(0); else if (p == 1) OCN_SETPRIO(1); else OCN_SETPRIO(2);
-}
 OCN_DEVFN void prio_start(int mode, int ty, int BY) {
-  if (mode == 4) { if (ty == BY - 1) OCN_SETPRIO(3); else prio_rot(4, ty, BY, 0); }
-  else if (mode == 1 || mode == 2) { if (ty == BY - 1) OCN_SETPRIO(3); else if (mode == 2 && ty == 0) OCN_SETPRIO(2); else if (mode == 2 && ty == BY - 2) OCN_SETPRIO(0); else OCN_SETPRIO(1); }
+  if (mode == 1 || mode == 2) { if (ty == BY - 1) OCN_SETPRIO(3); else if (mode == 2 && ty == 0) OCN_SETPRIO(2); else if (mode == 2 && ty == BY - 2) OCN_SETPRIO(0); else OCN_SETPRIO(1); }
   else if (mode == 3) { if (ty >= 3) OCN_SETPRIO(3); else if (ty == 2) OCN_SETPRIO(2); else if (ty == 1) OCN_SETPRIO(1); else OCN_SETPRIO(0); }
 }
 OCN_DEVFN void prio_mid(int mode, int ty, int BY) {
@@ -120,7 +116,9 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
   double* const fxe = fyb + 6 * T;                    // [parity][field][row * NW + wave]: west-face fluxes of each wave's first lane
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int tid = ty * BX + tx;
-  const int lane = tid % WV, wave = tid / WV;
+  const int lane = tid % WV;
+  const int wave = OCN_UNIFORM(tid / WV);            // scalar: the staging loops and the priority switches branch on it
+  const int sty = OCN_UNIFORM(ty);                   // (BX is a multiple of the wave width: a wave lies in one row)
   const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
   const double rdx = g.rdx, rdy = g.rdy, rdz = 1.0 / g.dz;
   const int nbz = (ADV == ADV_C4) ? 1 : 2;
@@ -250,7 +248,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
         if (k + 2 <= k1) prefetch(k + 2);
       }
     }
-    prio_start(a.prio, ty, BY);
+    prio_start(a.prio, sty, BY);
     const double* S = lds + kb * SLAB + ty * SX + tx;     // lowest corner of this thread's stencil footprint; own cell at (3, 3)
     double gm0 = 0, gm1 = 0, gm2 = 0, rs0 = 0, rs1 = 0, rs2 = 0;
     if (REST && full && k > k0) {
@@ -331,19 +329,15 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
           const double divw = dux + (SLB(1, 4, 2) - SLB(1, 3, 2)) * rdy + (wxm - SLB(2, 3, 2)) * rdz;   // div U at (i-1, j, k)
           f0 -= a.nu * (dux + divw);
         }
-        prio_rot(a.prio, ty, BY, 1);
         double utv = YSYM(0, jy);                      // u interpolated in y to the v row
         f1 = utv * XREC(1, utv, ix) - (visc ? a.nu * (SLB(1, 3, 3) - SLB(1, 3, 2)) * rdx : 0.0);
-        prio_rot(a.prio, ty, BY, 2);
         double utw = symz(zu);                         // u interpolated in z to the w level
         f2 = utw * XREC(2, utw, ix) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 3, 2)) * rdx : 0.0);
       }
-      prio_mid(a.prio, ty, BY);
-      prio_rot(a.prio, ty, BY, 3);
+      prio_mid(a.prio, sty, BY);
       if (do_y) {
         double vtu = XSYM(1, ix);                      // v interpolated in x to the u column
         s0 = vtu * YREC(0, vtu, jy) - (visc ? a.nu * (SLB(0, 3, 3) - SLB(0, 2, 3)) * rdy : 0.0);
-        prio_rot(a.prio, ty, BY, 4);
         double vtv = YSYM(1, jy - 1);                  // centre j-1
         s1 = vtv * YREC(1, vtv, jy - 1);
         if (visc) {
@@ -351,7 +345,6 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
           const double divs = (SLB(0, 2, 4) - SLB(0, 2, 3)) * rdx + dvy + (wym - SLB(2, 2, 3)) * rdz;   // div U at (i, j-1, k)
           s1 -= a.nu * (dvy + divs);
         }
-        prio_rot(a.prio, ty, BY, 5);
         double vtw = symz(zv);
         s2 = vtw * YREC(2, vtw, jy) - (visc ? a.nu * (SLB(2, 3, 3) - SLB(2, 2, 3)) * rdy : 0.0);
         double* fyn = fyb + kb * 3 * T;
@@ -362,13 +355,10 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
     }
     double Fwu = 0, Fwv = 0, Fww = 0;
     if (full) {
-      prio_rot(a.prio, ty, BY, 6);
       double wtu = XSYM(2, ix);
       Fwu = wtu * reconz(zu, wtu);
-      prio_rot(a.prio, ty, BY, 7);
       double wtv = YSYM(2, jy);
       Fwv = wtv * reconz(zv, wtv);
-      prio_rot(a.prio, ty, BY, 8);
       double wtw = symz_at(zw, k);                    // centre below face k
       Fww = wtw * reconz_at(zw, wtw, k);
       if (visc) {

@@ -20,6 +20,13 @@
  *     Center-located fields; a Flat x / y direction is stored with broadcast copies).  ocn_field_layout()
  *     returns the element strides and the origin of the logical parent inside the allocation, so the
  *     alias becomes a strided view; ocn_field_upload / download always speak the dense parent layout.
+ *   - pointer stability: ocn_field_device_ptr() of u, v, w, pHY', pNHS, nu_e and kappa_e never changes during the life
+ *     of a model (every time-stepping path writes the corrected velocities back into the same arrays).  The
+ *     tendency sets G^n / G^- and, on the tiled kernels' paths, the tracers are double buffered and ROTATE:
+ *     re-query their pointers after every ocn_time_step (tests/test_model_contracts.py asserts both halves).
+ *   - a model that needs wider halos than its grid has (WENO5 / U5: 3) works on a private copy of the grid with the
+ *     wider halo, as the reference's with_halo does (nonhydrostatic_model.jl:140-148); the caller's grid and other
+ *     models on it are left alone.
  *   - one context = one device + one in-order HIP stream.  Compute calls are asynchronous with
  *     respect to the host and ordered on that stream; only ocn_sync, uploads and downloads block.
  *   - handles are not thread-safe: one host thread per context.
