@@ -46,23 +46,25 @@ struct FusedArgs {
 // Wave priorities (s_setprio).  The VALU of a SIMD is handed out by priority, then by age, so the four waves a SIMD holds
 // (one per thread row) do not advance together: in-kernel stamps of round 2 show the ghost-row wave -- a third of the
 // work, but the youngest -- starved until the others are done, and every wave then waiting for it at the barrier.
-//   1: ghost-row waves run at priority 3 (they are short: get them out of the way first)
-//   2: 1 + the first output row drops to the lowest priority half way through a level, the last one rises
-//   3: priority = row index (inverts the age order)
-// Measured (256^3, ms per launch): none 0.583, 1: 0.592, 2: 0.551, 3: 0.588.  A finer rotation (a priority change after
-// every reconstruction) made it 0.85: every s_setprio sits behind a wave-uniform branch, and nine more basic-block
-// boundaries per level take away the scheduler's freedom to interleave the reconstructions.
+// s_setprio is scalar state: it must sit behind SCALAR branches (on a readfirstlane'd row index) -- behind a "divergent"
+// branch on threadIdx.y it executes whatever EXEC says, and the last one in program order wins for every wave.
 #ifndef OCN_HOST_EMU
 #define OCN_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #else
 #define OCN_SETPRIO(n) ((void)0)
 #endif
-OCN_DEVFN void prio_start(int mode, int ty, int BY) {
-  if (mode == 1 || mode == 2) { if (ty == BY - 1) OCN_SETPRIO(3); else if (mode == 2 && ty == 0) OCN_SETPRIO(2); else if (mode == 2 && ty == BY - 2) OCN_SETPRIO(0); else OCN_SETPRIO(1); }
-  else if (mode == 3) { if (ty >= 3) OCN_SETPRIO(3); else if (ty == 2) OCN_SETPRIO(2); else if (ty == 1) OCN_SETPRIO(1); else OCN_SETPRIO(0); }
+// a.prio packs eight 2-bit priorities: bits [2r+1:2r] = priority of thread row class r at the start of a level, bits
+// [8+2r+1:8+2r] from the middle of its flux stage on; classes: 0 = first output row, 1 = rows between, 2 = last output
+// row, 3 = ghost row.  0 = leave the hardware default (age order).  All switches are scalar branches (sty is an SGPR).
+OCN_DEVFN void prio_set(int v) {
+  if (v == 0) OCN_SETPRIO(0); else if (v == 1) OCN_SETPRIO(1); else if (v == 2) OCN_SETPRIO(2); else OCN_SETPRIO(3);
 }
-OCN_DEVFN void prio_mid(int mode, int ty, int BY) {
-  if (mode == 2) { if (ty == 0) OCN_SETPRIO(0); else if (ty == BY - 2) OCN_SETPRIO(2); }
+OCN_DEVFN int prio_class(int sty, int BY) { return sty == BY - 1 ? 3 : sty == 0 ? 0 : sty == BY - 2 ? 2 : 1; }
+OCN_DEVFN void prio_start(int code, int sty, int BY) {
+  if (code) prio_set((code >> (2 * prio_class(sty, BY))) & 3);
+}
+OCN_DEVFN void prio_mid(int code, int sty, int BY) {
+  if (code) prio_set((code >> (8 + 2 * prio_class(sty, BY))) & 3);
 }
 
 OCN_DEVFN void sto(double* base, unsigned boff, double v) { *(double*)((char*)base + boff) = v; }
@@ -102,7 +104,7 @@ OCN_DEVFN void sto(double* base, unsigned boff, double v) { *(double*)((char*)ba
 // boundary buffer (topologically_conditional_interpolation.jl:46-79).  REST: G^n arrives holding everything but advection
 // (closure, Coriolis, pressure gradient, boundary fluxes from the general kernels) and leaves as the full tendency;
 // walls in x / y are runtime flags of the REST variants (the same fallbacks on the x / y stencils).
-template <int ADV, int BX, int BY, bool XT, bool DMA, bool VISC, bool ZB, bool REST>
+template <int ADV, int BX, int BY, bool XT, int DMA, bool VISC, bool ZB, bool REST>
 __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
   constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
   constexpr int WV = BX < OCN_WAVE ? BX : OCN_WAVE;   // lanes of a wave that lie in one row
@@ -157,12 +159,28 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
   const unsigned cxy = a.org + (unsigned)(col_ok ? i : i0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
 
   // ---- slab staging ------------------------------------------------------------------------------------------------
-  // DMA: slab row r of a field = columns i0-3 ... of parent row j0-3+r, contiguous in memory; PR 16-byte pieces of it are
-  // needed (to the end of the parent row at most).  Wave w takes the (field, row) pairs w, w + NWV, ...
+  // DMA == 1: slab row r of a field = columns i0-3 ... of parent row j0-3+r, contiguous in memory; PR 16-byte pieces of it
+  // are needed (to the end of the parent row at most).  Wave w takes the (field, row) pairs w, w + NWV, ...
   const int ncols = (g.Nx + 6 - i0 < SX) ? g.Nx + 6 - i0 : SX;
   const int PR = ncols / 2;
+  constexpr int NP = NR * SX / 2, NPR = (NP + T - 1) / T;   // DMA == 2: 16-byte pieces of a field's whole slab
   auto dma = [&](int k, int buf) {
     const long src0 = (long)a.org + ((long)(j0 - 3) * g.sy + (long)k * g.sz + (i0 - 3)) * 8;
+    if (DMA == 2) {
+      // complete rows whose pitch equals the slab's (Nx == BX): the NR rows of a field are ONE contiguous chunk
+#pragma unroll
+      for (int r = 0; r < NPR; ++r) {
+        const int p = tid + r * T;
+        if (p < NP) {
+          const unsigned so = (unsigned)src0 + 16u * (unsigned)p;
+          char* dst = (char*)(lds + buf * SLAB) + 16 * (p - lane);
+          ocn_glds16((const char*)a.u + so, dst, lane);
+          ocn_glds16((const char*)a.v + so, dst + NR * SX * 8, lane);
+          ocn_glds16((const char*)a.w + so, dst + 2 * NR * SX * 8, lane);
+        }
+      }
+      return;
+    }
     for (int fr = wave; fr < 3 * NR; fr += NWV) {
       const int f = fr / NR, r = fr - f * NR;
       const double* base = f == 0 ? a.u : f == 1 ? a.v : a.w;
@@ -765,21 +783,22 @@ static int fused_cu_count(const ocn_model* m) {
 struct FusedShape {
   int bx, by;
   bool wide, small;
-  bool dma;      // slab rows staged by global_load_lds (k_tend4<DMA = true>)
+  int dma;       // slab staged by global_load_lds: 1 row by row, 2 one chunk per field (rows with the slab's pitch); 0: registers
   dim3 blk, grd;
 };
 
 // Tuning / test knobs of the tiled kernels: read ONCE, when the model is created, never on a launch path.
 //   OCNHIP_FUSED_XT=1     force the x-tiled variant on small grids (tests)
-//   OCNHIP_NO_LDS_DMA=1   stage the slab through registers even where the LDS-DMA path is legal (tests)
+//   OCNHIP_NO_LDS_DMA=1   stage the slab through registers even where the LDS-DMA path is legal (tests); =2: never the
+//                         one-chunk form
 //   OCNHIP_NO_TRACER3=1   column tracer kernel instead of the tiled one (tests)
-//   OCNHIP_PRIO=n         wave-priority scheme (default 2; 0 = none)
+//   OCNHIP_PRIO=code      wave-priority code (see prio_start; 0 = hardware default)
 void fused_read_knobs(ocn_model* m) {
   auto env = [](const char* n, int def) { const char* e = getenv(n); return e ? atoi(e) : def; };
   m->knob_fused_xt = env("OCNHIP_FUSED_XT", 0);
   m->knob_no_dma = env("OCNHIP_NO_LDS_DMA", 0);
   m->knob_no_tracer3 = env("OCNHIP_NO_TRACER3", 0);
-  m->knob_prio = env("OCNHIP_PRIO", 2);
+  { const char* e = getenv("OCNHIP_PRIO"); m->knob_prio = e ? (int)strtol(e, nullptr, 0) : 0; }
 }
 
 static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
@@ -824,14 +843,16 @@ static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
   f.grd = dim3(nseg, 1, 1);
   // 16-byte pieces: a slab row starts at parent column Hx - 3 + i0 (i0 = x-tile origin, even), rows are sy doubles apart,
   // planes sz doubles; the arrays come from hipMalloc (256-byte aligned)
-  f.dma = !m->knob_no_dma && gd.Hx == 3 && gd.Nx % 2 == 0 && gd.sy % 2 == 0 && gd.sz % 2 == 0;
+  f.dma = (!m->knob_no_dma && gd.Hx == 3 && gd.Nx % 2 == 0 && gd.sy % 2 == 0 && gd.sz % 2 == 0) ? 1 : 0;
+  if (f.dma && !f.wide && gd.Nx == f.bx && gd.sy == gd.Nx + 6 && m->knob_no_dma != 2) f.dma = 2;
   return f;
 }
 
 // launch one of the instantiations: VISCV / ZBV / RESTV are compile-time constants at the call site
 #define FUSED_T4(ADVV, BXV, BYV, XTV, VISCV, ZBV, RESTV)                                                                   \
-  { if (f.dma) ocn_launch_sync(k_tend4<ADVV, BXV, BYV, XTV, true, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);          \
-    else ocn_launch_sync(k_tend4<ADVV, BXV, BYV, XTV, false, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); }
+  { if (f.dma == 2 && !XTV) ocn_launch_sync(k_tend4<ADVV, BXV, BYV, XTV, XTV ? 1 : 2, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); \
+    else if (f.dma) ocn_launch_sync(k_tend4<ADVV, BXV, BYV, XTV, 1, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a);       \
+    else ocn_launch_sync(k_tend4<ADVV, BXV, BYV, XTV, 0, VISCV, ZBV, RESTV>, f.grd, f.blk, s, m->gd, a); }
 #ifdef OCN_HOST_EMU
 #define FUSED_EMU16(ADVV, VISCV, ZBV, RESTV)                                                                               \
   if (f.bx == 16 && f.small) FUSED_T4(ADVV, 16, 4, true, VISCV, ZBV, RESTV)                                                \
