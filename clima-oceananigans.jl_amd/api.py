@@ -340,6 +340,13 @@ class NonhydrostaticModel:
         except Exception:
             pass
 
+    @property
+    def kernel_path(self):
+        """which kernels serve this model and, when it is not the fastest set, why"""
+        buf = C.create_string_buffer(256)
+        check(self.lib.ocn_model_path(self.h, buf, 256), self.ctx.h)
+        return buf.value.decode()
+
     def prognostic(self):
         d = {"u": self.u, "v": self.v, "w": self.w}
         d.update(self.tracers)

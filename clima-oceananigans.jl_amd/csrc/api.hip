@@ -732,9 +732,12 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
   }
   fused_read_knobs(m);
   m->fast_path = fused_available(m) ? 1 : 0;
-  if (getenv("OCNHIP_DEBUG")) fprintf(stderr, "[ocnhip] model: fast_path=%d\n", m->fast_path);
   m->bz_fast = (!m->fast_path && fused_bz_available(m)) ? 1 : 0;
-  if (getenv("OCNHIP_DEBUG")) fprintf(stderr, "[ocnhip] model: bz_fast=%d\n", m->bz_fast);
+  if (getenv("OCNHIP_DEBUG")) {
+    char why[256];
+    fused_describe(m, why, sizeof(why));
+    fprintf(stderr, "[ocnhip] model: %s\n", why);
+  }
   if (m->fast_path || m->bz_fast) {
     int r2 = field_alloc(m, m->us, OCN_FACE, OCN_CENTER, OCN_CENTER) | field_alloc(m, m->vs, OCN_CENTER, OCN_FACE, OCN_CENTER) |
              field_alloc(m, m->ws, OCN_CENTER, OCN_CENTER, OCN_FACE);
@@ -782,6 +785,12 @@ void ocn_model_destroy(ocn_model* m) {
   poisson_destroy(m->solver);
   ocn_grid_destroy(m->own_grid);
   delete m;
+}
+
+int ocn_model_path(const ocn_model* m, char* buf, size_t n) {
+  if (!m || !buf || n == 0) return OCN_EINVAL;
+  fused_describe(m, buf, n);
+  return OCN_OK;
 }
 
 int ocn_model_halo(const ocn_model* m, int32_t H[3]) {

@@ -749,20 +749,37 @@ __global__ void __launch_bounds__(BX* BY) k_tracer_step3(GridDev g, Tracer3Args 
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------
+// why (not): the reason is kept on the model for ocn_model_path()
+static const char* tiled_blocker(const ocn_model* m) {
+  const ocn_grid* g = m->g;
+  const int adv = m->d.advection;
+  if (adv != ADV_WENO_Z && adv != ADV_WENO_JS && adv != ADV_U5) return "the advection scheme is not an upwind-biased 5th-order one";
+  for (int d = 0; d < 3; ++d)
+    if (g->topo[d] != OCN_FLAT && (g->H[d] < 3 || g->N[d] < 2 * g->H[d])) return "a direction has fewer than 6 cells";
+  if (m->u.n * sizeof(double) >= (1ull << 31) || m->w.n * sizeof(double) >= (1ull << 31))
+    return "parent arrays of 2 GiB or more exceed the tiled kernels' 32-bit byte offsets";
+  return nullptr;
+}
+
 bool fused_available(const ocn_model* m) {
   const ocn_grid* g = m->g;
   if (g->topo[0] != OCN_PERIODIC || g->topo[1] != OCN_PERIODIC || g->topo[2] != OCN_PERIODIC) return false;
   if (!g->z_regular) return false;
-  int adv = m->d.advection;
-  if (adv != ADV_WENO_Z && adv != ADV_WENO_JS && adv != ADV_U5) return false;
   // ScalarDiffusivity (constant nu, kappa) rides in the face fluxes of the fused kernels; other closures, Coriolis and
   // buoyancy take the general path
   if (m->d.closure == OCN_CLOSURE_AMD || m->d.coriolis_fplane || m->d.buoyancy != OCN_BUOYANCY_NONE) return false;
-  for (int d = 0; d < 3; ++d)
-    if (g->H[d] < 3 || g->N[d] < 2 * g->H[d]) return false;
-  if (m->u.n * sizeof(double) >= (1ull << 31)) return false;   // 32-bit byte offsets
-  if (getenv("OCNHIP_NO_FUSED")) return false;
+  if (tiled_blocker(m)) return false;
+  if (getenv("OCNHIP_NO_FUSED")) return false;   // model creation only
   return true;
+}
+
+void fused_describe(const ocn_model* m, char* buf, size_t n) {
+  const char* why = tiled_blocker(m);
+  if (m->fast_path) snprintf(buf, n, "all-in-one periodic path: k_tend4 + fused Poisson passes + k_project");
+  else if (m->bz_fast) snprintf(buf, n, "tiled advection + update (k_tend4, REST) on top of the general kernels' other terms");
+  else if (why) snprintf(buf, n, "general kernels: %s", why);
+  else if (m->g->topo[0] == OCN_FLAT || m->g->topo[1] == OCN_FLAT) snprintf(buf, n, "general kernels: Flat x / y slices are outside the tiled kernels");
+  else snprintf(buf, n, "general kernels (tiled path disabled or not applicable to this topology / decomposition)");
 }
 
 static int fused_cu_count(const ocn_model* m) {
@@ -798,7 +815,9 @@ void fused_read_knobs(ocn_model* m) {
   m->knob_fused_xt = env("OCNHIP_FUSED_XT", 0);
   m->knob_no_dma = env("OCNHIP_NO_LDS_DMA", 0);
   m->knob_no_tracer3 = env("OCNHIP_NO_TRACER3", 0);
-  { const char* e = getenv("OCNHIP_PRIO"); m->knob_prio = e ? (int)strtol(e, nullptr, 0) : 0; }
+  // default 0x20FF: every row at priority 3 until the middle of its flux stage, then only the last output row keeps 2
+  // (256^3: 0.575 ms against 0.590 with the hardware's age order; ten codes tried, all within 0.575 - 0.613)
+  { const char* e = getenv("OCNHIP_PRIO"); m->knob_prio = e ? (int)strtol(e, nullptr, 0) : 0x20FF; }
 }
 
 static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
@@ -843,7 +862,7 @@ static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
   f.grd = dim3(nseg, 1, 1);
   // 16-byte pieces: a slab row starts at parent column Hx - 3 + i0 (i0 = x-tile origin, even), rows are sy doubles apart,
   // planes sz doubles; the arrays come from hipMalloc (256-byte aligned)
-  f.dma = (!m->knob_no_dma && gd.Hx == 3 && gd.Nx % 2 == 0 && gd.sy % 2 == 0 && gd.sz % 2 == 0) ? 1 : 0;
+  f.dma = (m->knob_no_dma != 1 && gd.Hx == 3 && gd.Nx % 2 == 0 && gd.sy % 2 == 0 && gd.sz % 2 == 0) ? 1 : 0;
   if (f.dma && !f.wide && gd.Nx == f.bx && gd.sy == gd.Nx + 6 && m->knob_no_dma != 2) f.dma = 2;
   return f;
 }
@@ -907,11 +926,7 @@ bool fused_bz_available(const ocn_model* m) {
   if (g->topo[0] == OCN_FLAT || g->topo[1] == OCN_FLAT) return false;      // walls in x / y are fine (runtime flags of the REST variants)
   if (g->dist_y && (g->topo[0] != OCN_PERIODIC || g->topo[1] != OCN_PERIODIC)) return false;
   if (g->topo[2] == OCN_FLAT || (g->topo[2] == OCN_PERIODIC && (!g->z_regular || g->dist))) return false;
-  int adv = m->d.advection;
-  if (adv != ADV_WENO_Z && adv != ADV_WENO_JS && adv != ADV_U5) return false;
-  for (int d = 0; d < 3; ++d)
-    if (g->H[d] < 3 || g->N[d] < 2 * g->H[d]) return false;
-  if (m->u.n * sizeof(double) >= (1ull << 31) || m->w.n * sizeof(double) >= (1ull << 31)) return false;
+  if (tiled_blocker(m)) return false;
   if (getenv("OCNHIP_NO_FUSED") || getenv("OCNHIP_NO_FUSED_BZ")) return false;   // model creation only
   return true;
 }

@@ -146,6 +146,7 @@ int amd_build_table(ocn_model* m);
 
 // ---- fused.hip -----------------------------------------------------------------------------------------
 void fused_read_knobs(ocn_model* m);
+void fused_describe(const ocn_model* m, char* buf, size_t n);
 bool fused_available(const ocn_model* m);
 bool fused_bz_available(const ocn_model* m);
 void launch_fused_bz(ocn_model* m, double dt, double cn, double cm, int use_m);
@@ -169,9 +170,10 @@ double* poisson_rhs_buffer(PoissonSolver* s);
 // ---- zfft.hip ---------------------------------------------------------------------------------------------
 void* zsolve_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::vector<double>& ly_local);
 void zsolve_destroy(void* z);
-void zsolve_run(ocn_ctx* ctx, void* z, void* spec, const double* lz, double norm, long zero_col);
-void yfft256_run(ocn_ctx* ctx, void* z, void* spec, int Nxh, int Nz, int inverse);
-void xfft_rhs256_run(ocn_model* m, void* z, void* spec, double dt);
+void zsolve_run(ocn_ctx* ctx, void* z, void* spec, int Nz, const double* lz, double norm, long zero_col);
+void yfft_run(ocn_ctx* ctx, void* z, void* spec, int Nxh, int Ny, int Nz, int inverse);
+void xfft_rhs_run(ocn_model* m, void* z, void* spec, double dt);
+bool fft_size_ok(int n);   // 128, 256, 512: sizes of the custom transform passes
 bool poisson_custom_xy(const ocn_model* m);
 int poisson_run_from_predictor(ocn_model* m, double dt);   // fused rhs + custom x/y passes (fast path)
 

@@ -168,7 +168,7 @@ PoissonSolver* poisson_create(ocn_model* m) {
     double dz = g->L[2] / g->Nzg;
     s->dz2 = dz * dz;
   }
-  const bool want_zs = !use_slab && g->topo[2] == OCN_PERIODIC && (g->dist ? g->Nzg : s->Nz) == 256 &&
+  const bool want_zs = !use_slab && g->topo[2] == OCN_PERIODIC && fft_size_ok(g->dist ? g->Nzg : s->Nz) &&
                        !(getenv("OCNHIP_NO_ZSOLVE") && atoi(getenv("OCNHIP_NO_ZSOLVE")) != 0);
   if (want_zs) {
     std::vector<double> lxh = eigenvalues_periodic(s->Nx, g->L[0]);
@@ -182,8 +182,8 @@ PoissonSolver* poisson_create(ocn_model* m) {
     }
     if (s->kind == 0) s->kind = 3;   // 2-D transforms per plane + fused z stage
   }
-  // custom x / y passes: 256-point transforms in x and y, triply periodic, any z stage
-  if (s->Nx == 256 && s->Ny == 256 && g->topo[2] == OCN_PERIODIC && g->z_regular &&
+  // custom x / y passes: 128-, 256- or 512-point transforms in x and y, triply periodic, any z stage
+  if (fft_size_ok(s->Nx) && fft_size_ok(s->Ny) && g->topo[2] == OCN_PERIODIC && g->z_regular &&
       !(getenv("OCNHIP_NO_CUSTOM_XY") && atoi(getenv("OCNHIP_NO_CUSTOM_XY")) != 0)) {
     if (!s->zs && !s->zsl) {
       // no fused z kernel for this Nz: the Green's-function z stage works for any Nz (one "slab")
@@ -987,7 +987,7 @@ static int run_solver(ocn_model* m) {
     if (rc) return rc;
     if (s->zs) {
       ProfScope ps(m->ctx, "spectral_solve");
-      zsolve_run(m->ctx, s->zs, s->tb, s->lz, 1.0 / ((double)s->Nx * s->Ny * s->Nzg), s->rank == 0 ? 0 : -1);
+      zsolve_run(m->ctx, s->zs, s->tb, s->Nzg, s->lz, 1.0 / ((double)s->Nx * s->Ny * s->Nzg), s->rank == 0 ? 0 : -1);
     } else
     {
       ProfScope ps(m->ctx, "spectral_solve");
@@ -1021,7 +1021,7 @@ static int run_solver(ocn_model* m) {
     }
   } else if (s->kind == 3) {
     ProfScope ps(m->ctx, "spectral_solve");
-    zsolve_run(m->ctx, s->zs, s->spec, s->lz, 1.0 / ((double)s->Nx * s->Ny * s->Nz), 0);
+    zsolve_run(m->ctx, s->zs, s->spec, s->Nz, s->lz, 1.0 / ((double)s->Nx * s->Ny * s->Nz), 0);
   } else {
     ProfScope ps(m->ctx, "spectral_solve");
     dim3 b(64, 4, 1);
@@ -1083,19 +1083,19 @@ int poisson_run_from_predictor(ocn_model* m, double dt) {
   PoissonSolver* s = m->solver;
   {
     ProfScope ps(m->ctx, "fft_forward");
-    xfft_rhs256_run(m, s->tw, s->spec, dt);
-    yfft256_run(m->ctx, s->tw, s->spec, s->Nxh, s->Nz, 0);
+    xfft_rhs_run(m, s->tw, s->spec, dt);
+    yfft_run(m->ctx, s->tw, s->spec, s->Nxh, s->Ny, s->Nz, 0);
   }
   if (s->zs) {
     ProfScope ps(m->ctx, "spectral_solve");
-    zsolve_run(m->ctx, s->zs, s->spec, s->lz, 1.0 / ((double)s->Nx * s->Ny * s->Nz), 0);
+    zsolve_run(m->ctx, s->zs, s->spec, s->Nz, s->lz, 1.0 / ((double)s->Nx * s->Ny * s->Nz), 0);
   } else {
     int rc = zslab_run(m->ctx, s->zsl, s->spec, s->dz2, 1.0 / ((double)s->Nx * s->Ny));
     if (rc) return rc;
   }
   {
     ProfScope ps(m->ctx, "fft_backward");
-    yfft256_run(m->ctx, s->tw, s->spec, s->Nxh, s->Nz, 1);
+    yfft_run(m->ctx, s->tw, s->spec, s->Nxh, s->Ny, s->Nz, 1);
 #ifndef OCN_HOST_EMU
     if (hipfftExecZ2D(s->xinv, (hipfftDoubleComplex*)s->spec, s->rhs) != HIPFFT_SUCCESS) {
       ocn_set_error(m->ctx, "hipfftExecZ2D (x inverse) failed");

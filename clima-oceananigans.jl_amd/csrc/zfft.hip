@@ -10,7 +10,9 @@
 // 256-point FFT = four-step 16 x 16: each thread transforms 16 points in registers (radix-4 x radix-4),
 // twiddles, one LDS transpose, second 16-point transform.  After the forward transform thread (col, k1) holds
 // the frequencies kz = k1 + 16 k2, multiplies them by -norm / (lx + ly + lz[kz]) and runs the same network
-// backwards, so the data never leaves registers/LDS in spectral space.
+// backwards, so the data never leaves registers/LDS in spectral space.  128 points: 16 x 8 (two 8-point transforms per
+// thread in the second stage); 512 points: a radix-2 decimation-in-frequency step across two half-teams in front of the
+// 256-point network.  The same three sizes serve the x pass (fused with the right-hand side) and the y passes.
 #include "internal.h"
 
 struct cd {
@@ -62,11 +64,167 @@ template <int S> OCN_DEVFN void dft16(cd* v) {
     }
 }
 
-// 16 x 16 x 16 transpose through LDS in two halves (real parts, then imaginary parts): 32 KB per workgroup
-// instead of 64, so four workgroups fit a CU and twice as many loads are in flight (these passes are
-// HBM-latency bound).  wi(q) / ri(q): element index written / read for register q.
-template <class WI, class RI>
-OCN_DEVFN void transpose_halves(double* sm, cd* v, WI wi, RI ri) {
+// in-place 8-point DFT, natural order in and out (radix 2 x 4)
+template <int S> OCN_DEVFN void dft8(cd* v) {
+  cd e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  dft4<S>(e0, e1, e2, e3);
+  dft4<S>(o0, o1, o2, o3);
+  const double R = 0.70710678118654752440;
+  auto tw = [&](cd z, double c, double s) { return cd{z.x * c + S * z.y * s, z.y * c - S * z.x * s}; };   // z * (c - i S s)
+  o1 = tw(o1, R, R);
+  o2 = mul_mi<S>(o2);
+  o3 = tw(o3, -R, R);
+  v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+  v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+  v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+  v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+
+// ---- N-point transforms (N = 128, 256, 512) by teams of threads of a 256-thread workgroup, 16 points per thread ---------
+// `tw`: table of exp(-2 pi i m / 512), m = 0..511 (stride 512 / N gives the N-th roots).  LDS: SMN doubles.
+//   N = 256: four-step 16 x 16, team of 16 threads (r = n2 on the way in, k1 on the way out): v[k2] = X[r + 16 k2]
+//   N = 128: four-step 16 x 8, team of 8: the second stage is two 8-point transforms per thread:
+//            v[k2 + 8 h] = X[(r + 8 h) + 16 k2]
+//   N = 512: one radix-2 decimation-in-frequency step across two half-teams (h = 0: x[n] + x[n + 256], h = 1:
+//            (x[n] - x[n + 256]) W512^n), then each half-team runs the 256-point network:
+//            v[k2] = X[2 (r + 16 k2) + h].  The partner's 16 points travel through LDS.
+// Columns per workgroup: 32 (N = 128), 16 (256), 8 (512); `c` is the column slot of the thread INCLUDING the half for
+// N = 512 (c = col + 8 h), so the 256-point network below serves both.
+#define SMN (16 * (256 + 32))
+template <int N> struct FftGeo {
+  static constexpr int M = N / 16;                   // threads per transform
+  static constexpr int C = 256 / M;                  // columns per workgroup
+  static constexpr int CS = N == 512 ? 16 : C;       // column slots of the LDS images (N = 512: column + 8 half)
+  static constexpr int RS = N == 128 ? 8 : 16;       // threads per team in the LDS images
+  static constexpr int K1S = RS * CS + CS;           // padded stride of the k1 index: rows of different r hit different banks
+};
+
+// all threads of the workgroup take part (barriers inside)
+template <int N, int S> OCN_DEVFN void fft_stage2(double* sm, cd* v, int r, int c, const cd* tw) {
+  typedef FftGeo<N> G;
+  constexpr int TS = 512 / (N == 512 ? 256 : N);     // table stride of the inner transform's roots
+  // twiddles W^(r k1) of the inner transform (n2 = r)
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) {
+    cd w = tw[((r * k1) * TS) & 511];
+    if (S < 0) w.y = -w.y;
+    v[k1] = cmul(v[k1], w);
+  }
+  // transpose: element (k1, n2 = r) -> the thread(s) that own k1
+  auto wi = [&](int k1) { return k1 * G::K1S + r * G::CS + c; };
+  if (N == 128) {
+    // thread r takes k1 = r and r + 8: reads n2 = 0..7 of each
+    auto ri = [&](int q) { return (r + 8 * (q >> 3)) * G::K1S + (q & 7) * G::CS + c; };
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sm[wi(q)] = v[q].x;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].x = sm[ri(q)];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sm[wi(q)] = v[q].y;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].y = sm[ri(q)];
+    dft8<S>(v);
+    dft8<S>(v + 8);
+  } else {
+    auto ri = [&](int n2) { return r * G::K1S + n2 * G::CS + c; };
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sm[wi(q)] = v[q].x;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].x = sm[ri(q)];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sm[wi(q)] = v[q].y;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].y = sm[ri(q)];
+    dft16<S>(v);
+  }
+}
+
+// the 16 points of the partner thread (same column and r, other half) through LDS; barriers inside
+OCN_DEVFN void fft512_partner(double* sm, const cd* v, cd* p, int r, int c) {
+  const int me = r * 16 + c, other = r * 16 + (c ^ 8);          // [q][r][c]: consecutive lanes, consecutive words
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) sm[q * 256 + me] = v[q].x;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) p[q].x = sm[q * 256 + other];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) sm[q * 256 + me] = v[q].y;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) p[q].y = sm[q * 256 + other];
+  __syncthreads();
+}
+
+// forward / backward N-point transform of the team's points.  In: v[n1] = x[r + M' n1 (+ 256 h)] with M' = 8 (N = 128)
+// or 16; out: see the table above.  Unnormalised; S = +1: exp(-i ...), S = -1: exp(+i ...).
+template <int N, int S> OCN_DEVFN void fft_fwd(double* sm, cd* v, int r, int c, const cd* tw) {
+  if (N == 512) {
+    cd p[16];
+    fft512_partner(sm, v, p, r, c);
+    const int h = (c >> 3) & 1;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      if (h == 0) v[n1] = cadd(v[n1], p[n1]);                    // x[n] + x[n + 256]
+      else {
+        cd w = tw[(r + 16 * n1) & 511];                          // W512^n, n = r + 16 n1
+        if (S < 0) w.y = -w.y;
+        v[n1] = cmul(csub(p[n1], v[n1]), w);                     // (x[n] - x[n + 256]) W^n: own = x[n + 256]
+      }
+    }
+  }
+  dft16<S>(v);
+  fft_stage2<N, S>(sm, v, r, c, tw);
+}
+
+// the same network run backwards: from the spectral layout of fft_fwd<N, +1> back to v[n1] = x[r + M' n1 (+ 256 h)],
+// unnormalised (x N)
+template <int N> OCN_DEVFN void fft_back(double* sm, cd* v, int r, int c, const cd* tw) {
+  typedef FftGeo<N> G;
+  constexpr int TS = 512 / (N == 512 ? 256 : N);
+  if (N == 128) {
+    dft8<-1>(v);
+    dft8<-1>(v + 8);                                             // v[n2 + 8 h] = Z[k1 = r + 8 h][n2]
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      cd w = tw[(((r + 8 * (q >> 3)) * (q & 7)) * TS) & 511];    // conj W128^(k1 n2)
+      w.y = -w.y;
+      v[q] = cmul(v[q], w);
+    }
+    auto wi = [&](int q) { return (r + 8 * (q >> 3)) * G::K1S + (q & 7) * G::CS + c; };
+    auto ri = [&](int k1) { return k1 * G::K1S + r * G::CS + c; };
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sm[wi(q)] = v[q].x;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].x = sm[ri(q)];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sm[wi(q)] = v[q].y;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q].y = sm[ri(q)];
+    dft16<-1>(v);
+    return;
+  }
+  dft16<-1>(v);                                                  // v[n2] = Z[k1 = r][n2]
+#pragma unroll
+  for (int n2 = 1; n2 < 16; ++n2) {
+    cd w = tw[((r * n2) * TS) & 511];
+    w.y = -w.y;
+    v[n2] = cmul(v[n2], w);
+  }
+  auto wi = [&](int n2) { return r * G::K1S + n2 * G::CS + c; };
+  auto ri = [&](int k1) { return k1 * G::K1S + r * G::CS + c; };
+  __syncthreads();
 #pragma unroll
   for (int q = 0; q < 16; ++q) sm[wi(q)] = v[q].x;
   __syncthreads();
@@ -78,114 +236,124 @@ OCN_DEVFN void transpose_halves(double* sm, cd* v, WI wi, RI ri) {
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 16; ++q) v[q].y = sm[ri(q)];
+  dft16<-1>(v);                                                  // r = n2 again: v[n1] = u_h[r + 16 n1]
+  if (N == 512) {
+    // undo the decimation step: u0 = x[n] + x[n+256], u1 = (x[n] - x[n+256]) W^n  ->  2 x[n] = u0 + u1 conj(W^n), ...
+    const int h = (c >> 3) & 1;
+    if (h == 1) {
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) {
+        cd w = tw[(r + 16 * n1) & 511];
+        w.y = -w.y;
+        v[n1] = cmul(v[n1], w);
+      }
+    }
+    cd p[16];
+    fft512_partner(sm, v, p, r, c);
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = h == 0 ? cadd(v[n1], p[n1]) : csub(p[n1], v[n1]);   // 2 x[n], 2 x[n + 256]
+  }
 }
 
-// `a`: (ncol, 256) complex, element (col, z) at a[col + ncol * z].  lxy[col]: lx + ly of the column.
-// lz[kz]; tw256[m] = exp(-2 pi i m / 256).  zero_col: flattened column whose kz = 0 mode is set to 0 (or -1).
-__global__ void __launch_bounds__(256) k_zsolve256(cd* __restrict__ a, long ncol, const double* __restrict__ lxy,
-                                                   const double* __restrict__ lz, const cd* __restrict__ tw256,
-                                                   double norm, long zero_col) {
-  OCN_SHARED cd sm[16 * 16 * 16];           // [p][q][col], column fastest: conflict-free b128 writes and reads
-  const int t = threadIdx.x;
-  const int col = t & 15, r = t >> 4;       // r plays n2 (loads / stores) and k1 (spectral side)
-  const long gcol = (long)blockIdx.x * 16 + col;
+// thread -> (r, column slot c, element index of v[q] along the transformed direction) for data whose COLUMNS are adjacent
+// in memory (y and z passes): t = c + CS * r
+template <int N> OCN_DEVFN void team_of(int t, int& r, int& c, int& col) {
+  typedef FftGeo<N> G;
+  c = t % G::CS;
+  r = t / G::CS;
+  col = N == 512 ? (c & 7) : c;
+}
+// position along the transformed direction of v[n1] on the way in (physical side) ...
+template <int N> OCN_DEVFN int pos_in(int r, int c, int n1) {
+  return N == 128 ? r + 8 * n1 : N == 256 ? r + 16 * n1 : r + 16 * n1 + 256 * ((c >> 3) & 1);
+}
+// ... and of v[q] on the way out (spectral side)
+template <int N> OCN_DEVFN int pos_out(int r, int c, int q) {
+  return N == 128 ? (r + 8 * (q >> 3)) + 16 * (q & 7) : N == 256 ? r + 16 * q : 2 * (r + 16 * q) + ((c >> 3) & 1);
+}
+
+// ---- fused z stage: forward transform, eigenvalue division, backward transform in one pass ------------------------------
+// `a`: (ncol, N) complex, element (col, z) at a[col + ncol * z].  lxy[col]: lx + ly of the column; lz[kz].
+// zero_col: flattened column whose kz = 0 mode is set to 0 (or -1).  norm: 1 / (Nx Ny Nz).
+template <int N>
+__global__ void __launch_bounds__(256) k_zsolve(cd* __restrict__ a, long ncol, const double* __restrict__ lxy,
+                                                const double* __restrict__ lz, const cd* __restrict__ tw, double norm, long zero_col) {
+  OCN_SHARED double sm[SMN];
+  int r, c, col;
+  team_of<N>(threadIdx.x, r, c, col);
+  const long gcol = (long)blockIdx.x * FftGeo<N>::C + col;
   const bool ok = gcol < ncol;
   cd v[16];
-  // ---- load x[n2 + 16 n1], n1 = 0..15 (each wave instruction: four 256-byte rows) ----
 #pragma unroll
-  for (int n1 = 0; n1 < 16; ++n1) v[n1] = ok ? a[gcol + ncol * (r + 16 * n1)] : cd{0, 0};
-  // ---- forward: DFT over n1 -> Y[n2][k1]; twiddle W256^(n2 k1); transpose; DFT over n2 ----
-  dft16<1>(v);
-#pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], tw256[(r * k1) & 255]);
-#pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) sm[(k1 * 16 + r) * 16 + col] = v[k1];
-  __syncthreads();
-#pragma unroll
-  for (int n2 = 0; n2 < 16; ++n2) v[n2] = sm[(r * 16 + n2) * 16 + col];   // now r = k1
-  dft16<1>(v);                                                            // v[k2] = X[k1 + 16 k2]
-  // ---- eigenvalue division (fft_based_poisson_solver.jl:106-111) ----
+  for (int n1 = 0; n1 < 16; ++n1) v[n1] = ok ? a[gcol + ncol * pos_in<N>(r, c, n1)] : cd{0, 0};
+  fft_fwd<N, 1>(sm, v, r, c, tw);
+  // eigenvalue division (fft_based_poisson_solver.jl:106-111)
   const double lc = ok ? lxy[gcol] : 1.0;
 #pragma unroll
-  for (int k2 = 0; k2 < 16; ++k2) {
-    const int kz = r + 16 * k2;
+  for (int q = 0; q < 16; ++q) {
+    const int kz = pos_out<N>(r, c, q);
     double f = -norm / (lc + lz[kz]);
     if (gcol == zero_col && kz == 0) f = 0.0;
-    v[k2].x *= f;
-    v[k2].y *= f;
+    v[q].x *= f;
+    v[q].y *= f;
   }
-  // ---- inverse: DFT(+) over k2 -> Z[k1][n2]; twiddle conj W256^(n2 k1); transpose; DFT(+) over k1 ----
-  dft16<-1>(v);
-#pragma unroll
-  for (int n2 = 1; n2 < 16; ++n2) {
-    cd w = tw256[(r * n2) & 255];
-    w.y = -w.y;
-    v[n2] = cmul(v[n2], w);
-  }
-  __syncthreads();                           // everyone finished reading the forward transpose
-#pragma unroll
-  for (int n2 = 0; n2 < 16; ++n2) sm[(n2 * 16 + r) * 16 + col] = v[n2];   // r = k1
-  __syncthreads();
-#pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) v[k1] = sm[(r * 16 + k1) * 16 + col];   // now r = n2
-  dft16<-1>(v);                                                           // v[n1] = x[n2 + 16 n1]
+  fft_back<N>(sm, v, r, c, tw);
   if (ok) {
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) a[gcol + ncol * (r + 16 * n1)] = v[n1];
+    for (int n1 = 0; n1 < 16; ++n1) a[gcol + ncol * pos_in<N>(r, c, n1)] = v[n1];
   }
 }
 
-// ---- y-direction pass: in-place 256-point FFT along ky of the half spectrum (Nxh, 256, Nz) -------------------
-// Tiles of 16 columns.  Main tiles: 16 consecutive kx of one z-plane (256 contiguous bytes per ky).  The
-// Nxh % 16 left-over kx columns are tiled over the flattened (kx_left, z) index.
-template <int S>
-__global__ void __launch_bounds__(256) k_yfft256(cd* __restrict__ a, int Nxh, int Nz, const cd* __restrict__ tw256) {
-  OCN_SHARED double sm[16 * 16 * 16];
-  const int t = threadIdx.x;
-  const int col = t & 15, r = t >> 4;
-  const int nfull = Nxh / 16, left = Nxh - 16 * nfull;
-  const long plane = (long)Nxh * 256;
+// ---- y-direction pass: in-place N-point FFT along ky of the half spectrum (Nxh, N, Nz) -------------------------------
+// Tiles of C columns.  Main tiles: C consecutive kx of one z-plane (contiguous in memory for every ky).  The
+// Nxh % C left-over kx columns are tiled over the flattened (kx_left, z) index.
+template <int N, int S>
+__global__ void __launch_bounds__(256) k_yfft(cd* __restrict__ a, int Nxh, int Nz, const cd* __restrict__ tw) {
+  OCN_SHARED double sm[SMN];
+  constexpr int C = FftGeo<N>::C;
+  int r, c, col;
+  team_of<N>(threadIdx.x, r, c, col);
+  const int nfull = Nxh / C, left = Nxh - C * nfull;
+  const long plane = (long)Nxh * N;
   const long nmain = (long)nfull * Nz;
   long base;
   bool ok = true;
   if ((long)blockIdx.x < nmain) {
     const int tile = blockIdx.x % nfull, zz = blockIdx.x / nfull;
-    base = 16 * tile + col + plane * zz;
+    base = C * tile + col + plane * zz;
   } else {
-    const long c = ((long)blockIdx.x - nmain) * 16 + col;      // flattened (kx_left, z)
-    ok = left > 0 && c < (long)left * Nz;
-    const long zz = ok ? c / left : 0, kl = ok ? c - zz * left : 0;
-    base = 16 * nfull + kl + plane * zz;
+    const long cc = ((long)blockIdx.x - nmain) * C + col;      // flattened (kx_left, z)
+    ok = left > 0 && cc < (long)left * Nz;
+    const long zz = ok ? cc / left : 0, kl = ok ? cc - zz * left : 0;
+    base = C * nfull + kl + plane * zz;
   }
   cd v[16];
 #pragma unroll
-  for (int n1 = 0; n1 < 16; ++n1) v[n1] = ok ? a[base + (long)Nxh * (r + 16 * n1)] : cd{0, 0};
-  dft16<S>(v);
-#pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) {
-    cd w = tw256[(r * k1) & 255];
-    if (S < 0) w.y = -w.y;
-    v[k1] = cmul(v[k1], w);
-  }
-  transpose_halves(sm, v, [&](int k1) { return (k1 * 16 + r) * 16 + col; }, [&](int n2) { return (r * 16 + n2) * 16 + col; });
-  dft16<S>(v);                                                            // r = k1 now; v[k2] = X[k1 + 16 k2]
+  for (int n1 = 0; n1 < 16; ++n1) v[n1] = ok ? a[base + (long)Nxh * pos_in<N>(r, c, n1)] : cd{0, 0};
+  fft_fwd<N, S>(sm, v, r, c, tw);
   if (ok) {
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) a[base + (long)Nxh * (r + 16 * k2)] = v[k2];
+    for (int q = 0; q < 16; ++q) a[base + (long)Nxh * pos_out<N>(r, c, q)] = v[q];
   }
 }
 
 // ---- x-direction forward pass fused with the Poisson right-hand side ----------------------------------------------
 // rhs = div(U*) / dt (solve_for_pressure.jl:15-18) is formed on the fly from the predictor with periodic wrap
-// indexing and transformed along x (256 real points as a complex FFT with zero imaginary part); the half
-// spectrum kx = 0..128 is written once.  One workgroup = 16 consecutive x-lines (flattened j + Ny k).
-__global__ void __launch_bounds__(256) k_xfft_rhs256(GridDev g, const double* __restrict__ us, const double* __restrict__ vs,
-                                                     const double* __restrict__ ws, double rdt, int zwrap,
-                                                     cd* __restrict__ spec, const cd* __restrict__ tw256) {
-  OCN_SHARED double sm[16 * 16 * 16];
+// indexing and transformed along x (N real points as a complex FFT with zero imaginary part); the half
+// spectrum kx = 0..N/2 is written once.  One workgroup = C consecutive x-lines (flattened j + Ny k); here the
+// TRANSFORMED direction is the contiguous one, so the team index r runs fastest over the lanes: t = r' + RT * line
+// with r' = r (+ 16 h for N = 512).
+template <int N>
+__global__ void __launch_bounds__(256) k_xfft_rhs(GridDev g, const double* __restrict__ us, const double* __restrict__ vs,
+                                                  const double* __restrict__ ws, double rdt, int zwrap,
+                                                  cd* __restrict__ spec, const cd* __restrict__ tw) {
+  OCN_SHARED double sm[SMN];
+  constexpr int M = FftGeo<N>::M, C = FftGeo<N>::C;
   const int t = threadIdx.x;
-  const int r = t & 15, ln = t >> 4;              // r = x mod 16 (loads) / k1 (stores); ln = line inside the tile
-  const long L = (long)blockIdx.x * 16 + ln;      // line index j + Ny k
+  const int rr = t % M, ln = t / M;                 // rr: position inside the team; ln: line inside the tile
+  const int r = N == 512 ? rr & 15 : rr;
+  const int c = N == 512 ? ln + 8 * (rr >> 4) : ln;  // column slot (line + 8 half)
+  const long L = (long)blockIdx.x * C + ln;         // line index j + Ny k
   const long nlines = (long)g.Ny * g.Nz;
   const bool ok = L < nlines;
   const int k = ok ? (int)(L / g.Ny) : 0, j = ok ? (int)(L - (long)k * g.Ny) : 0;
@@ -197,31 +365,31 @@ __global__ void __launch_bounds__(256) k_xfft_rhs256(GridDev g, const double* __
   cd v[16];
 #pragma unroll
   for (int n1 = 0; n1 < 16; ++n1) {
-    const int i = r + 16 * n1;
+    const int i = pos_in<N>(r, c, n1);
     const int ie = (i + 1 == g.Nx) ? 0 : i + 1;
     double d = 0.0;
     if (ok) d = ((us[row + ie] - us[row + i]) * g.rdx + (vs[rown + i] - vs[row + i]) * g.rdy + (ws[rowt + i] - ws[row + i]) * rdz) * rdt;
     v[n1] = {d, 0.0};
   }
-  dft16<1>(v);
-#pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], tw256[(r * k1) & 255]);
-  transpose_halves(sm, v, [&](int k1) { return (k1 * 16 + r) * 16 + ln; }, [&](int n2) { return (r * 16 + n2) * 16 + ln; });
-  dft16<1>(v);                                    // v[k2] = X[k1 + 16 k2], k1 = r
+  fft_fwd<N, 1>(sm, v, r, c, tw);
   if (ok) {
-    cd* out = spec + L * 129;
+    cd* out = spec + L * (N / 2 + 1);
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) out[r + 16 * k2] = v[k2];
-    if (r == 0) out[128] = v[8];
+    for (int q = 0; q < 16; ++q) {
+      const int kx = pos_out<N>(r, c, q);
+      if (kx <= N / 2) out[kx] = v[q];
+    }
   }
 }
 
 // host side ---------------------------------------------------------------------------------------------------
 struct ZSolve {
-  cd* tw = nullptr;
+  cd* tw = nullptr;        // exp(-2 pi i m / 512), m = 0..511
   double* lxy = nullptr;
   long ncol = 0;
 };
+
+bool fft_size_ok(int n) { return n == 128 || n == 256 || n == 512; }
 
 void* zsolve_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::vector<double>& ly_local) {
   // lxy[kx + Nxh * ky]
@@ -231,15 +399,15 @@ void* zsolve_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std:
   std::vector<double> lxy(Nxh * Ny);
   for (size_t j = 0; j < Ny; ++j)
     for (size_t i = 0; i < Nxh; ++i) lxy[i + Nxh * j] = lx_half[i] + ly_local[j];
-  std::vector<cd> tw(256);
-  for (int m = 0; m < 256; ++m) tw[m] = {cos(2.0 * M_PI * m / 256.0), -sin(2.0 * M_PI * m / 256.0)};
-  if (hipMalloc((void**)&z->tw, sizeof(cd) * 256) != hipSuccess ||
+  std::vector<cd> tw(512);
+  for (int m = 0; m < 512; ++m) tw[m] = {cos(2.0 * M_PI * m / 512.0), -sin(2.0 * M_PI * m / 512.0)};
+  if (hipMalloc((void**)&z->tw, sizeof(cd) * 512) != hipSuccess ||
       hipMalloc((void**)&z->lxy, sizeof(double) * lxy.size()) != hipSuccess) {
     ocn_set_error(ctx, "zsolve: allocation failed");
     delete z;
     return nullptr;
   }
-  hipMemcpy(z->tw, tw.data(), sizeof(cd) * 256, hipMemcpyHostToDevice);
+  hipMemcpy(z->tw, tw.data(), sizeof(cd) * 512, hipMemcpyHostToDevice);
   hipMemcpy(z->lxy, lxy.data(), sizeof(double) * lxy.size(), hipMemcpyHostToDevice);
   return z;
 }
@@ -252,29 +420,55 @@ void zsolve_destroy(void* p) {
   delete z;
 }
 
+#define FFT_BY_N(N, CALL128, CALL256, CALL512) \
+  switch (N) { case 128: CALL128; break; case 256: CALL256; break; default: CALL512; break; }
+
 // forward / inverse y pass (in place), and the fused rhs + x pass; all unnormalised
-void yfft256_run(ocn_ctx* ctx, void* p, void* spec, int Nxh, int Nz, int inverse) {
+void yfft_run(ocn_ctx* ctx, void* p, void* spec, int Nxh, int Ny, int Nz, int inverse) {
   ZSolve* z = (ZSolve*)p;
-  const int nfull = Nxh / 16, left = Nxh - 16 * nfull;
-  const long nblk = (long)nfull * Nz + ((long)left * Nz + 15) / 16;
+  const int C = 256 / (Ny / 16);
+  const int nfull = Nxh / C, left = Nxh - C * nfull;
+  const long nblk = (long)nfull * Nz + ((long)left * Nz + C - 1) / C;
   dim3 b(256, 1, 1), g((unsigned)nblk, 1, 1);
-  if (inverse) ocn_launch_sync(k_yfft256<-1>, g, b, ctx->stream, (cd*)spec, Nxh, Nz, (const cd*)z->tw);
-  else ocn_launch_sync(k_yfft256<1>, g, b, ctx->stream, (cd*)spec, Nxh, Nz, (const cd*)z->tw);
+  cd* a = (cd*)spec;
+  const cd* tw = (const cd*)z->tw;
+  hipStream_t s = ctx->stream;
+  if (inverse) {
+    FFT_BY_N(Ny, ocn_launch_sync(k_yfft<128, -1>, g, b, s, a, Nxh, Nz, tw), ocn_launch_sync(k_yfft<256, -1>, g, b, s, a, Nxh, Nz, tw),
+             ocn_launch_sync(k_yfft<512, -1>, g, b, s, a, Nxh, Nz, tw))
+  } else {
+    FFT_BY_N(Ny, ocn_launch_sync(k_yfft<128, 1>, g, b, s, a, Nxh, Nz, tw), ocn_launch_sync(k_yfft<256, 1>, g, b, s, a, Nxh, Nz, tw),
+             ocn_launch_sync(k_yfft<512, 1>, g, b, s, a, Nxh, Nz, tw))
+  }
 }
 
-void xfft_rhs256_run(ocn_model* m, void* p, void* spec, double dt) {
+void xfft_rhs_run(ocn_model* m, void* p, void* spec, double dt) {
   ZSolve* z = (ZSolve*)p;
   const GridDev& g = m->gd;
   const long nlines = (long)g.Ny * g.Nz;
-  dim3 b(256, 1, 1), gr((unsigned)((nlines + 15) / 16), 1, 1);
-  ocn_launch_sync(k_xfft_rhs256, gr, b, m->ctx->stream, g, (const double*)m->us.interior(), (const double*)m->vs.interior(),
-                  (const double*)m->ws.interior(), 1.0 / dt, m->g->dist ? 0 : 1, (cd*)spec, (const cd*)z->tw);
+  const int C = 256 / (g.Nx / 16);
+  dim3 b(256, 1, 1), gr((unsigned)((nlines + C - 1) / C), 1, 1);
+  const double* us = m->us.interior();
+  const double* vs = m->vs.interior();
+  const double* ws = m->ws.interior();
+  const int zw = m->g->dist ? 0 : 1;
+  hipStream_t s = m->ctx->stream;
+  cd* sp = (cd*)spec;
+  const cd* tw = (const cd*)z->tw;
+  FFT_BY_N(g.Nx, ocn_launch_sync(k_xfft_rhs<128>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw),
+           ocn_launch_sync(k_xfft_rhs<256>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw),
+           ocn_launch_sync(k_xfft_rhs<512>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw))
 }
 
-// in place on the (ncol, 256) spectrum; `zero_col` < 0 when this rank does not own the mean mode
-void zsolve_run(ocn_ctx* ctx, void* p, void* spec, const double* lz, double norm, long zero_col) {
+// in place on the (ncol, Nz) spectrum; `zero_col` < 0 when this rank does not own the mean mode
+void zsolve_run(ocn_ctx* ctx, void* p, void* spec, int Nz, const double* lz, double norm, long zero_col) {
   ZSolve* z = (ZSolve*)p;
-  dim3 b(256, 1, 1), g((unsigned)((z->ncol + 15) / 16), 1, 1);
-  ocn_launch_sync(k_zsolve256, g, b, ctx->stream, (cd*)spec, z->ncol, (const double*)z->lxy, lz, (const cd*)z->tw, norm,
-                  zero_col);
+  const int C = 256 / (Nz / 16);
+  dim3 b(256, 1, 1), g((unsigned)((z->ncol + C - 1) / C), 1, 1);
+  cd* a = (cd*)spec;
+  const cd* tw = (const cd*)z->tw;
+  hipStream_t s = ctx->stream;
+  FFT_BY_N(Nz, ocn_launch_sync(k_zsolve<128>, g, b, s, a, z->ncol, (const double*)z->lxy, lz, tw, norm, zero_col),
+           ocn_launch_sync(k_zsolve<256>, g, b, s, a, z->ncol, (const double*)z->lxy, lz, tw, norm, zero_col),
+           ocn_launch_sync(k_zsolve<512>, g, b, s, a, z->ncol, (const double*)z->lxy, lz, tw, norm, zero_col))
 }

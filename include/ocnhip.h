@@ -151,6 +151,9 @@ void ocn_grid_destroy(ocn_grid* g);
 /* ---- model -------------------------------------------------------------------------------------- */
 int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out);
 void ocn_model_destroy(ocn_model* m);
+/* which kernels serve this model, and if not the fastest ones, why (e.g. "general kernels: parent arrays of 2 GiB or
+ * more exceed the tiled kernels' 32-bit byte offsets").  Writes at most n bytes incl. the terminating 0. */
+int ocn_model_path(const ocn_model* m, char* buf, size_t n);
 /* halo actually used (the model inflates it like nonhydrostatic_model.jl:140-148) */
 int ocn_model_halo(const ocn_model* m, int32_t H[3]);
 

@@ -154,3 +154,16 @@ def test_checkpoint_restart_is_bit_identical(ocn, backend, topo, stepper, N):
 @pytest.mark.parametrize("topo,stepper,N", CK + [((P, P, P), "AB2", (256, 16, 12))])
 def test_checkpoint_restart_is_bit_identical_gpu(ocn, topo, stepper, N):
     _checkpoint_roundtrip(ocn, topo, stepper, N)
+
+
+def test_model_reports_its_kernel_path(ocn, backend):
+    """falling off the tiled kernels is never silent: ocn_model_path names the path and the reason"""
+    if backend != "hostemu":
+        pytest.skip("host-emulation run")
+    g = ocn.RectilinearGrid(size=(12, 10, 8), extent=(1, 1, 1), topology=(P, P, P))
+    assert "all-in-one" in ocn.NonhydrostaticModel(g, advection=ocn.WENO5()).kernel_path
+    assert "advection scheme" in ocn.NonhydrostaticModel(g, advection=ocn.CenteredSecondOrder()).kernel_path
+    gb = ocn.RectilinearGrid(size=(12, 10, 8), extent=(1, 1, 1), topology=(P, P, B))
+    assert "tiled advection" in ocn.NonhydrostaticModel(gb, advection=ocn.WENO5(), coriolis=ocn.FPlane(1e-4)).kernel_path
+    gs = ocn.RectilinearGrid(size=(4, 10, 8), extent=(1, 1, 1), topology=(P, P, P))
+    assert "fewer than 6 cells" in ocn.NonhydrostaticModel(gs, advection=ocn.WENO5()).kernel_path
