@@ -542,7 +542,8 @@ static void tendencies_and_step(ocn_model* m, double dt, double cn, double cm, i
     return;
   }
   const bool tr3 = m->nt > 0 && fused_tracer3_ok(m);
-  launch_tendencies(m, true, tr3);             // closure, Coriolis, pressure gradient, boundary fluxes (+ tracer advection unless tiled)
+  launch_tendencies(m, true, tr3);             // closure, Coriolis, pressure gradient, boundary fluxes; tracers: everything but the
+                                               // boundary fluxes comes from the tiled tracer kernel when it applies
   launch_fused_bz(m, dt, cn, cm, use_m);       // + advection -> G^n; stepped velocities -> us, vs, ws
   if (tr3) launch_tracer3(m, dt, cn, cm, use_m, true);   // reads the old velocities: before the swap
   else launch_step(m, dt, cn, cm, use_m, true);

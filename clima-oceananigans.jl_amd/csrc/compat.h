@@ -51,6 +51,16 @@ __device__ __forceinline__ double ocn_shfl_next(double x) {
   b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x130, 0xf, 0xf, false);
   return b.d;
 }
+// value held by lane (lane ^ 16) of the wave (ds_bpermute_b32: LDS crossbar, no LDS storage, no barrier)
+__device__ __forceinline__ double ocn_shfl_xor16(double x) {
+  union { double d; int i[2]; } a, b;
+  a.d = x;
+  const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int addr = (lane ^ 16) << 2;
+  b.i[0] = __builtin_amdgcn_ds_bpermute(addr, a.i[0]);
+  b.i[1] = __builtin_amdgcn_ds_bpermute(addr, a.i[1]);
+  return b.d;
+}
 #define OCN_WAVE 64
 // a value that is the same in every lane of the wave, moved to a scalar register: branches on it are scalar branches
 // (s_setprio and the LDS-DMA base in M0 are scalar state -- behind a "divergent" branch they would execute regardless of EXEC)
@@ -151,6 +161,14 @@ static inline void ocn_glds16(const void* src_lane, void* dst_wave_base, int lan
   memcpy((char*)dst_wave_base + 16 * lane, src_lane, 16);
 }
 extern double g_emu_shfl[4096];
+static inline double ocn_shfl_xor16(double x) {
+  const unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+  g_emu_shfl[tid] = x;
+  g_emu_barrier.wait();
+  const double y = g_emu_shfl[tid ^ 16];
+  g_emu_barrier.wait();
+  return y;
+}
 static inline double ocn_shfl_next(double x) {
   const unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
   const unsigned n = blockDim.x * blockDim.y * blockDim.z;

@@ -592,18 +592,22 @@ __global__ void __launch_bounds__(256) k_tracer_step(GridDev g, TracerArgs a) {
 // the updated tracer (all-in-one periodic path); otherwise the caller fills halos.
 struct Tracer3Args {
   const double *u, *v, *w, *c, *gm;   // PARENT base pointers
+  const double* kap;                  // KV: the tracer's eddy diffusivity kappa_e (Center field, halos filled)
   double *gn, *cnew;
   unsigned org;
   double dt, cn, cm, kappa;
   int use_m, ntiles, zwrap;
 };
 
-template <int ADV, int BX, int BY, bool ZB, bool REST, bool IMG>
+// KV: variable diffusivity (AnisotropicMinimumDissipation): -kappa_face dc/dn with kappa_face the two-point average of kappa_e
+// across the face (closure_kernel_operators.jl:43-48, 82-90) rides in the three face fluxes; kappa_e's slab sits in LDS next
+// to the tracer's, its value one level down in a register.
+template <int ADV, int BX, int BY, bool ZB, bool REST, bool IMG, bool KV>
 __global__ void __launch_bounds__(BX* BY) k_tracer_step3(GridDev g, Tracer3Args a) {
   constexpr int T = BX * BY, NR = BY + 5, SX = BX + 6;
   constexpr int NG = (NR + BY - 1) / BY;
-  OCN_SHARED double slab2[2 * NR * SX];    // slab and flux exchange are both double buffered by level parity:
-  OCN_SHARED double fx[2 * 2 * T];         // ONE barrier per level (a level is only three reconstructions of work)
+  OCN_SHARED double slab2[(KV ? 4 : 2) * NR * SX];   // slab and flux exchange are both double buffered by level parity:
+  OCN_SHARED double fx[2 * 2 * T];                   // ONE barrier per level (a level is only three reconstructions of work)
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int tid = ty * BX + tx;
   const int i = tx;
@@ -636,7 +640,7 @@ __global__ void __launch_bounds__(BX* BY) k_tracer_step3(GridDev g, Tracer3Args 
     const bool full = col_ok && row_ok && !ghost;
     const unsigned cxy = a.org + (unsigned)(col_ok ? i : 0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
     const unsigned grow = a.org + (unsigned)(col_ok ? i : 0) * sxb;
-    double pf[NG];
+    double pf[NG], pfk[KV ? NG : 1];
     auto prefetch = [&](int k) {
 #pragma unroll
       for (int gq = 0; gq < NG; ++gq) {
@@ -644,7 +648,9 @@ __global__ void __launch_bounds__(BX* BY) k_tracer_step3(GridDev g, Tracer3Args 
         if (r < NR) {
           int jg = j0 - 3 + r;
           if (jg > g.Ny + 2) jg = g.Ny + 2;
-          pf[gq] = ldo(a.c, grow + (unsigned)(jg + 3) * syb - 3u * syb + (unsigned)k * szb);
+          const unsigned o = grow + (unsigned)(jg + 3) * syb - 3u * syb + (unsigned)k * szb;
+          pf[gq] = ldo(a.c, o);
+          if (KV) pfk[KV ? gq : 0] = ldo(a.kap, o);
         }
       }
     };
@@ -659,10 +665,18 @@ __global__ void __launch_bounds__(BX* BY) k_tracer_step3(GridDev g, Tracer3Args 
           row[tx + 3] = pf[gq];
           if (img_e) row[tx + 3 + g.Nx] = pf[gq];
           if (img_w) row[tx + 3 - g.Nx] = pf[gq];
+          if (KV) {
+            double* rk = row + 2 * NR * SX;
+            const double kv = pfk[KV ? gq : 0];
+            rk[tx + 3] = kv;
+            if (img_e) rk[tx + 3 + g.Nx] = kv;
+            if (img_w) rk[tx + 3 - g.Nx] = kv;
+          }
         }
       }
     };
 #define CS(d, e) S[(d) * SX + (e)]
+#define KS(d, e) S[2 * NR * SX + (d) * SX + (e)]
     double zc[6];
     {
       const unsigned c = cxy + (unsigned)k0 * szb;
@@ -671,6 +685,7 @@ __global__ void __launch_bounds__(BX* BY) k_tracer_step3(GridDev g, Tracer3Args 
     }
     double un = ldo(a.u, cxy + (unsigned)k0 * szb), vn = ldo(a.v, cxy + (unsigned)k0 * szb), wn = ldo(a.w, cxy + (unsigned)k0 * szb);
     double own_h = 0, own_b = 0;
+    double kdn = KV ? ldo(a.kap, cxy + (unsigned)k0 * szb - szb) : 0.0;   // kappa_e one level down
     prefetch(k0);
     commit(k0);
     __syncthreads();
@@ -699,7 +714,8 @@ __global__ void __launch_bounds__(BX* BY) k_tracer_step3(GridDev g, Tracer3Args 
       if (!last) {
         if (full) {
           double f = uw * rec(CS(3, 0), CS(3, 1), CS(3, 2), CS(3, 3), CS(3, 4), CS(3, 5), uw);
-          if (a.kappa != 0.0) f -= a.kappa * (CS(3, 3) - CS(3, 2)) * rdx;
+          if (KV) f -= 0.5 * (KS(3, 2) + KS(3, 3)) * (CS(3, 3) - CS(3, 2)) * rdx;
+          else if (a.kappa != 0.0) f -= a.kappa * (CS(3, 3) - CS(3, 2)) * rdx;
           fxx[tid] = f;
         }
         if (do_y) {
@@ -707,7 +723,8 @@ __global__ void __launch_bounds__(BX* BY) k_tracer_step3(GridDev g, Tracer3Args 
           if (wy && !in_rec(vs_ > 0.0, j + 1, g.Ny)) r = 0.5 * (CS(2, 3) + CS(3, 3));
           else r = rec(CS(0, 3), CS(1, 3), CS(2, 3), CS(3, 3), CS(4, 3), CS(5, 3), vs_);
           double f = vs_ * r;
-          if (a.kappa != 0.0) f -= a.kappa * (CS(3, 3) - CS(2, 3)) * rdy;
+          if (KV) f -= 0.5 * (KS(2, 3) + KS(3, 3)) * (CS(3, 3) - CS(2, 3)) * rdy;
+          else if (a.kappa != 0.0) f -= a.kappa * (CS(3, 3) - CS(2, 3)) * rdy;
           fxy[tid] = f;
         }
       }
@@ -718,7 +735,11 @@ __global__ void __launch_bounds__(BX* BY) k_tracer_step3(GridDev g, Tracer3Args 
         if (ZB && !in_rec(pos, k + 1, g.Nz)) r = 0.5 * (zc[2] + zc[3]);
         else r = recon5<ADV>(pos ? zc[0] : zc[5], pos ? zc[1] : zc[4], pos ? zc[2] : zc[3], pos ? zc[3] : zc[2], pos ? zc[4] : zc[1], pos);
         fb = wb * r;
-        if (a.kappa != 0.0) fb -= a.kappa * (zc[3] - zc[2]) * (ZB ? g_rdzf(g, k) : g.rdz);
+        if (KV) {
+          const double kc = KS(3, 3);
+          fb -= 0.5 * (kdn + kc) * (zc[3] - zc[2]) * (ZB ? g_rdzf(g, k) : g.rdz);
+          kdn = kc;
+        } else if (a.kappa != 0.0) fb -= a.kappa * (zc[3] - zc[2]) * (ZB ? g_rdzf(g, k) : g.rdz);
       }
       if (!last) commit(k + 1);            // the other slab buffer: last read in the previous level's flux stage
       __syncthreads();
@@ -746,6 +767,7 @@ __global__ void __launch_bounds__(BX* BY) k_tracer_step3(GridDev g, Tracer3Args 
     }
   }
 #undef CS
+#undef KS
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------
@@ -1031,18 +1053,24 @@ void launch_tracer3(ocn_model* m, double dt, double cn, double cm, int use_m, bo
     a.gm = m->Gm[3 + t].d;
     a.gn = m->Gn[3 + t].d;
     a.cnew = m->trs[t].d;
-    a.kappa = (!rest && m->d.closure == OCN_CLOSURE_SCALAR) ? m->d.kappa[t] : 0.0;
+    // the closure's tracer flux rides in the face fluxes: constant kappa (ScalarDiffusivity) or the eddy diffusivity field
+    const bool kv = m->d.closure == OCN_CLOSURE_AMD;
+    a.kappa = m->d.closure == OCN_CLOSURE_SCALAR ? m->d.kappa[t] : 0.0;
+    a.kap = kv ? m->kappa_e[t].d : nullptr;
 #ifdef OCN_HOST_EMU
 #define TR3_EMU16(ADVV, ZBV, RESTV, IMGV) \
-    if (bx == 16) ocn_launch_sync(k_tracer_step3<ADVV, 16, 4, ZBV, RESTV, IMGV>, grd, blk, s, m->gd, a); else
+    if (bx == 16) { if (kv) ocn_launch_sync(k_tracer_step3<ADVV, 16, 4, ZBV, RESTV, IMGV, true>, grd, blk, s, m->gd, a);  \
+                    else ocn_launch_sync(k_tracer_step3<ADVV, 16, 4, ZBV, RESTV, IMGV, false>, grd, blk, s, m->gd, a); } else
 #else
 #define TR3_EMU16(ADVV, ZBV, RESTV, IMGV)
 #endif
+#define TR3_BX(ADVV, ZBV, RESTV, IMGV, KVV)                                                                      \
+    if (bx == 256) ocn_launch_sync(k_tracer_step3<ADVV, 256, 4, ZBV, RESTV, IMGV, KVV>, grd, blk, s, m->gd, a);     \
+    else if (bx == 128) ocn_launch_sync(k_tracer_step3<ADVV, 128, 8, ZBV, RESTV, IMGV, KVV>, grd, blk, s, m->gd, a); \
+    else ocn_launch_sync(k_tracer_step3<ADVV, 64, 8, ZBV, RESTV, IMGV, KVV>, grd, blk, s, m->gd, a);
 #define TR3_SHAPES(ADVV, ZBV, RESTV, IMGV)                                                                 \
     TR3_EMU16(ADVV, ZBV, RESTV, IMGV)                                                                      \
-    if (bx == 256) ocn_launch_sync(k_tracer_step3<ADVV, 256, 4, ZBV, RESTV, IMGV>, grd, blk, s, m->gd, a);     \
-    else if (bx == 128) ocn_launch_sync(k_tracer_step3<ADVV, 128, 8, ZBV, RESTV, IMGV>, grd, blk, s, m->gd, a); \
-    else ocn_launch_sync(k_tracer_step3<ADVV, 64, 8, ZBV, RESTV, IMGV>, grd, blk, s, m->gd, a);
+    if (kv) { TR3_BX(ADVV, ZBV, RESTV, IMGV, true) } else { TR3_BX(ADVV, ZBV, RESTV, IMGV, false) }
 #define TR3_MODE(ADVV)                                 \
     if (!rest) { TR3_SHAPES(ADVV, false, false, true) } \
     else if (zb) { TR3_SHAPES(ADVV, true, true, false) } \
@@ -1054,6 +1082,7 @@ void launch_tracer3(ocn_model* m, double dt, double cn, double cm, int use_m, bo
     }
 #undef TR3_MODE
 #undef TR3_SHAPES
+#undef TR3_BX
   }
   for (int t = 0; t < m->nt; ++t) std::swap(m->tr[t].d, m->trs[t].d);
 }

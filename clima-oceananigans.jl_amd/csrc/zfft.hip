@@ -165,10 +165,15 @@ OCN_DEVFN void fft512_partner(double* sm, const cd* v, cd* p, int r, int c) {
 
 // forward / backward N-point transform of the team's points.  In: v[n1] = x[r + M' n1 (+ 256 h)] with M' = 8 (N = 128)
 // or 16; out: see the table above.  Unnormalised; S = +1: exp(-i ...), S = -1: exp(+i ...).
-template <int N, int S> OCN_DEVFN void fft_fwd(double* sm, cd* v, int r, int c, const cd* tw) {
+// XLANE: the x pass -- real input, and its thread layout puts the partner 16 lanes away in the same wave: the partner's
+// 16 real values come by ds_bpermute instead of five barriers around an LDS image
+template <int N, int S, bool XLANE = false> OCN_DEVFN void fft_fwd(double* sm, cd* v, int r, int c, const cd* tw) {
   if (N == 512) {
     cd p[16];
-    fft512_partner(sm, v, p, r, c);
+    if (XLANE) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) p[q] = cd{ocn_shfl_xor16(v[q].x), 0.0};
+    } else fft512_partner(sm, v, p, r, c);
     const int h = (c >> 3) & 1;
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
@@ -371,11 +376,14 @@ __global__ void __launch_bounds__(256) k_xfft_rhs(GridDev g, const double* __res
     if (ok) d = ((us[row + ie] - us[row + i]) * g.rdx + (vs[rown + i] - vs[row + i]) * g.rdy + (ws[rowt + i] - ws[row + i]) * rdz) * rdt;
     v[n1] = {d, 0.0};
   }
-  fft_fwd<N, 1>(sm, v, r, c, tw);
+  fft_fwd<N, 1, true>(sm, v, r, c, tw);
   if (ok) {
     cd* out = spec + L * (N / 2 + 1);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
+      // smallest wavenumber any thread holds in v[q]: registers that only hold kx > N/2 store nothing (folded at compile time)
+      const int kmin = N == 128 ? 8 * (q >> 3) + 16 * (q & 7) : N == 256 ? 16 * q : 32 * q;
+      if (kmin > N / 2) continue;
       const int kx = pos_out<N>(r, c, q);
       if (kx <= N / 2) out[kx] = v[q];
     }
