@@ -27,7 +27,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_FILE = "r01_traffic.json"
+TRAFFIC_FILE = "r02_traffic.json"
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 # algorithmic bytes per cell: whole AB2 step and per phase
 B_ALG_STEP = 336.0          # config 2 / 4: AB2, no tracers; +49 per passive tracer; RK3 = 3 stages
@@ -249,21 +249,18 @@ def main():
     ocn._lib.load()
 
     dist = None
+    real_stdout = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        # rendezvous / barriers / max-reduce only; the data path is RCCL inside the library.  gloo prints its connection
-        # banner on stdout: keep stdout for the one JSON line.
+        # rendezvous / barriers / max-reduce only; the data path is RCCL inside the library.  gloo prints a connection
+        # banner on stdout at its first collective: file descriptor 1 is parked on stderr for the whole run and the one
+        # JSON line goes to the saved descriptor.  No collective before the library has initialised the GPU (below): a
+        # torch-side GPU initialisation first would leave the library without a device.
         sys.stdout.flush()
-        saved = os.dup(1)
+        real_stdout = os.dup(1)
         os.dup2(2, 1)
-        try:
-            dist.init_process_group("gloo")
-            dist.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        dist.init_process_group("gloo")
 
     ndev = int(os.environ.get("OCNHIP_BENCH_NDEV", "0"))     # rehearsal on fewer GPUs than ranks (shm transport only)
     ctx = ocn.Context(0 if args.rehearse_hostemu else (local_rank % ndev if ndev else local_rank))
@@ -445,7 +442,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        if real_stdout is not None:
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
