@@ -248,16 +248,19 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
   // carried from the previous level: horizontal divergence without the north (and, on x-edge lanes, east) fluxes, bottom fluxes
   double hu = 0, hv = 0, hw = 0, bu = 0, bv = 0, bw = 0;
   __syncthreads();                          // a previous segment's readers are done with every LDS buffer
-  if (DMA) dma(k0, k0 & 1);
+  // buffer parity is counted from the first level of the march.  (A two-level form of the loop with compile-time parity
+  // was tried: 744 instead of 761 VALU instructions per level -- the register windows still rotate by v_mov -- at 128
+  // VGPRs with spills; not kept.)
+  if (DMA) dma(k0, 0);
   else {
     prefetch(k0);
-    commit(k0 & 1);
+    commit(0);
     prefetch(k0 + 1);                       // k1 > k0, and level k1 is staged too: its w feeds the last bottom fluxes
   }
   for (int k = k0; k <= k1; ++k) {
+    const int kb = (k - k0) & 1;
     const unsigned c = cxy + (unsigned)k * szb;
     const bool last = (k == k1);
-    const int kb = k & 1;
     __syncthreads();                        // the one barrier of the level (with DMA in flight it also waits for vmcnt(0))
     if (!last) {                            // stage level k+1 (up to k1) into the buffer level k-1 was read from
       if (DMA) dma(k + 1, kb ^ 1);

@@ -115,7 +115,7 @@ struct ocn_model {
   // the projection writes u = U* - dt grad p back into u, v, w, so their device pointers never change.
   bool pred_active = false;
   ocn_grid* own_grid = nullptr;   // private copy of the caller's grid when the advection scheme needs wider halos
-  int knob_fused_xt = 0, knob_no_dma = 0, knob_no_tracer3 = 0, knob_prio = 2;   // fused_read_knobs(), at creation
+  int knob_fused_xt = 0, knob_no_dma = 0, knob_no_tracer3 = 0, knob_prio = 0x20FF;   // fused_read_knobs(), at creation
 };
 inline Field& pred_u(ocn_model* m) { return m->pred_active ? m->us : m->u; }
 inline Field& pred_v(ocn_model* m) { return m->pred_active ? m->vs : m->v; }
