@@ -8,7 +8,7 @@ behaviour.  The Julia `ROCmGPU` shim a maintainer would add is in INTEGRATION.md
 All numerical work happens in libocnhip.so (hand-written HIP for gfx950 + hipFFT/rocFFT + RCCL).
 """
 from .api import (Context, RectilinearGrid, NonhydrostaticModel, Periodic, Bounded, Flat, Center, Face,  # noqa: F401
-                  WENO5, NoAdvection, CenteredSecondOrder, CenteredFourthOrder, UpwindBiasedFifthOrder, ScalarDiffusivity,
+                  WENO5, NoAdvection, CenteredSecondOrder, CenteredFourthOrder, UpwindBiasedFifthOrder, UpwindBiasedFirstOrder, UpwindBiasedThirdOrder, ScalarDiffusivity,
                   AnisotropicMinimumDissipation, FPlane, BuoyancyTracer, SeawaterBuoyancy,
                   FluxBC, ValueBC, GradientBC, time_step, set_model, update_state, OcnError)
 from . import _lib  # noqa: F401

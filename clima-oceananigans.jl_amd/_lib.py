@@ -14,7 +14,7 @@ MAX_TRACERS = 8
 # enums (include/ocnhip.h)
 PERIODIC, BOUNDED, FLAT = 0, 1, 2
 CENTER, FACE = 0, 1
-ADV_NONE, ADV_C2, ADV_C4, ADV_U5, ADV_WENO5_Z, ADV_WENO5_JS = range(6)
+ADV_NONE, ADV_C2, ADV_C4, ADV_U5, ADV_WENO5_Z, ADV_WENO5_JS, ADV_U1, ADV_U3 = range(8)
 STEPPER_AB2, STEPPER_RK3 = 0, 1
 CLOSURE_NONE, CLOSURE_SCALAR, CLOSURE_AMD = 0, 1, 2
 BUOYANCY_NONE, BUOYANCY_TRACER, BUOYANCY_LINEAR_TS = 0, 1, 2

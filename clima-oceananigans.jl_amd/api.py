@@ -33,6 +33,14 @@ class UpwindBiasedFifthOrder:
     code = L.ADV_U5
 
 
+class UpwindBiasedFirstOrder:
+    code = L.ADV_U1
+
+
+class UpwindBiasedThirdOrder:
+    code = L.ADV_U3
+
+
 class WENO5:
     """``WENO5(; zweno=true)`` (weno_fifth_order.jl:162-180); uniform coefficients."""
 

@@ -625,13 +625,13 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
   if (!g || !desc || !out) return OCN_EINVAL;
   ocn_ctx* ctx = g->ctx;
   if (desc->n_tracers < 0 || desc->n_tracers > OCN_MAX_TRACERS) return OCN_EINVAL;
-  if (desc->advection < OCN_ADV_NONE || desc->advection > OCN_ADV_WENO5_JS) return OCN_EINVAL;
+  if (desc->advection < OCN_ADV_NONE || desc->advection > OCN_ADV_U3) return OCN_EINVAL;
   if (desc->closure == OCN_CLOSURE_AMD && (g->topo[0] == OCN_FLAT || g->topo[1] == OCN_FLAT || g->topo[2] == OCN_FLAT)) {
     ocn_set_error(ctx, "AnisotropicMinimumDissipation on a grid with a Flat direction is outside the path");
     return OCN_EUNSUPPORTED;
   }
   // halo inflation (nonhydrostatic_model.jl:140-148; Advection.jl:40)
-  static const int buffer[6] = {0, 0, 1, 2, 2, 2};
+  static const int buffer[8] = {0, 0, 1, 2, 2, 2, 1, 1};   // boundary_buffer of NONE, C2, C4, U5, WENO5 (Z, JS), U1, U3
   // The reference builds a NEW grid with the wider halo (with_halo); so does this: the caller's grid, and any
   // model already living on it, keep their halos, spacing tables and layouts.
   int need = buffer[desc->advection] + 1;

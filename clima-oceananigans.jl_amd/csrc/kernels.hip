@@ -259,6 +259,8 @@ void launch_tendencies(ocn_model* m, bool skip_momentum_advection, bool skip_tra
     TEND_CASE(ADV_U5)
     TEND_CASE(ADV_WENO_Z)
     TEND_CASE(ADV_WENO_JS)
+    TEND_CASE(ADV_U1)
+    TEND_CASE(ADV_U3)
   }
 #undef TEND_CASE
 #undef TEND_LAUNCH

@@ -12,7 +12,7 @@
 #pragma once
 #include "compat.h"
 
-enum { ADV_NONE = 0, ADV_C2 = 1, ADV_C4 = 2, ADV_U5 = 3, ADV_WENO_Z = 4, ADV_WENO_JS = 5 };
+enum { ADV_NONE = 0, ADV_C2 = 1, ADV_C4 = 2, ADV_U5 = 3, ADV_WENO_Z = 4, ADV_WENO_JS = 5, ADV_U1 = 6, ADV_U3 = 7 };
 
 struct GridDev {
   int Nx, Ny, Nz, Hx, Hy, Hz;
@@ -129,8 +129,17 @@ OCN_DEVFN double recon_mem(const double* p, long s, double ut) {
 }
 
 // advective flux (per unit area) through the face between p[-s] and p[0]; ut = advecting velocity there
+// UpwindBiasedFirstOrder / ThirdOrder (upwind_biased_first_order.jl:21-35, upwind_biased_third_order.jl:21-35): value at the
+// face between p[-s] and p[0] from the upwind side
+template <int ADV>
+OCN_DEVFN double recon_low(const double* p, long s, bool pos) {
+  if (ADV == ADV_U1) return pos ? p[-s] : p[0];
+  return pos ? (2.0 * p[0] + 5.0 * p[-s] - p[-2 * s]) / 6.0 : (-p[s] + 5.0 * p[0] + 2.0 * p[-s]) / 6.0;
+}
+
 template <int ADV>
 OCN_DEVFN double adv_flux(const double* p, long s, double ut) {
+  if (ADV == ADV_U1 || ADV == ADV_U3) return ut * recon_low<ADV>(p, s, ut > 0.0);
   if (ADV == ADV_C4) return ut * sym4(p - s, s);
   if (ADV == ADV_C2) return ut * sym2(p - s, s);
   return ut * recon_mem<ADV>(p, s, ut);
@@ -145,7 +154,7 @@ OCN_DEVFN bool outside_right(int idx, int N, int nb) { return idx > nb - 1 && id
 // symmetric interpolation midway between p[0] and p[s] along a possibly Bounded direction
 template <int ADV>
 OCN_DEVFN double sym_b(const double* p, long s, bool bounded, int idx, int N, int nb) {
-  if (ADV == ADV_C2) return sym2(p, s);
+  if (ADV == ADV_C2 || ADV == ADV_U1 || ADV == ADV_U3) return sym2(p, s);   // U1 / U3: symmetric interpolation is the two-point one
   if (bounded && !outside_sym(idx, N, nb)) return sym2(p, s);
   return sym4(p, s);
 }
@@ -162,6 +171,7 @@ OCN_DEVFN double adv_flux_b(const double* p, long s, double ut, bool bounded, in
     bool ok = pos ? outside_left(idx, N, nb) : outside_right(idx, N, nb);
     if (!ok) return ut * sym2(p - s, s);
   }
+  if (ADV == ADV_U1 || ADV == ADV_U3) return ut * recon_low<ADV>(p, s, pos);
   return ut * recon_mem<ADV>(p, s, ut);
 }
 

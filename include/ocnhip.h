@@ -59,7 +59,8 @@ enum { OCN_PERIODIC = 0, OCN_BOUNDED = 1, OCN_FLAT = 2 };
 enum { OCN_CENTER = 0, OCN_FACE = 1 };
 /* advection schemes (Advection/: centered_second_order.jl, centered_fourth_order.jl,
  * upwind_biased_fifth_order.jl, weno_fifth_order.jl:162-180 with zweno = true / false) */
-enum { OCN_ADV_NONE = 0, OCN_ADV_C2 = 1, OCN_ADV_C4 = 2, OCN_ADV_U5 = 3, OCN_ADV_WENO5_Z = 4, OCN_ADV_WENO5_JS = 5 };
+enum { OCN_ADV_NONE = 0, OCN_ADV_C2 = 1, OCN_ADV_C4 = 2, OCN_ADV_U5 = 3, OCN_ADV_WENO5_Z = 4, OCN_ADV_WENO5_JS = 5,
+       OCN_ADV_U1 = 6, OCN_ADV_U3 = 7 };   /* upwind_biased_first_order.jl, upwind_biased_third_order.jl (boundary buffer 1) */
 /* time steppers (TimeSteppers/quasi_adams_bashforth_2.jl, runge_kutta_3.jl) */
 enum { OCN_STEPPER_AB2 = 0, OCN_STEPPER_RK3 = 1 };
 /* closures (TurbulenceClosures/turbulence_closure_implementations/{scalar_diffusivity,anisotropic_minimum_dissipation}.jl) */

@@ -26,7 +26,7 @@ Each function cites the reference file:line it restates (paths relative to
 from .grid import RectilinearGrid, Periodic, Bounded, Flat, Center, Face  # noqa: F401
 from .fields import Field, fill_halo_regions  # noqa: F401
 from .model import (NonhydrostaticModel, WENO5, CenteredSecondOrder, CenteredFourthOrder,  # noqa: F401
-                    UpwindBiasedFifthOrder, ScalarDiffusivity, FPlane, BuoyancyTracer,
+                    UpwindBiasedFifthOrder, UpwindBiasedFirstOrder, UpwindBiasedThirdOrder, ScalarDiffusivity, FPlane, BuoyancyTracer,
                     SeawaterBuoyancy, AnisotropicMinimumDissipation,
                     FluxBC, ValueBC, GradientBC, time_step, set_model)
 from . import poisson  # noqa: F401

@@ -35,6 +35,20 @@ class UpwindBiasedFifthOrder:
     kind = "upwind"
 
 
+class UpwindBiasedFirstOrder:
+    """upwind_biased_first_order.jl:6-35: boundary_buffer 1, two-point symmetric interpolation"""
+    buffer = 1
+    kind = "upwind"
+    sym2 = True
+
+
+class UpwindBiasedThirdOrder:
+    """upwind_biased_third_order.jl:6-35"""
+    buffer = 1
+    kind = "upwind"
+    sym2 = True
+
+
 class WENO5:
     """``WENO5()`` with no grid: uniform coefficients everywhere (weno_fifth_order.jl:186-191)."""
     buffer = 2
@@ -63,18 +77,22 @@ class Advection:
 
     def sym_C(self, d, f):
         """symmetric_interpolate_x^c: Face-located f -> Center (centered_fourth_order.jl:26,29,32)."""
-        if self.s.kind == "C2":
+        if self.s.kind == "C2" or getattr(self.s, "sym2", False):
             return self.o.iC(d, f)
         return self.o.iC(d, self._i3F(d, f))
 
     def sym_F(self, d, f):
-        if self.s.kind == "C2":
+        if self.s.kind == "C2" or getattr(self.s, "sym2", False):
             return self.o.iF(d, f)
         return self.o.iF(d, self._i3C(d, f))
 
     # ------------------------------------------------------------------ biased (face form) --------
     def _left_face(self, d, f):
         s = self.s
+        if isinstance(s, UpwindBiasedFirstOrder):
+            return lambda o: f(sh(o, d, -1))                                                   # c[i-1]
+        if isinstance(s, UpwindBiasedThirdOrder):
+            return lambda o: (2 * f(o) + 5 * f(sh(o, d, -1)) - f(sh(o, d, -2))) / 6             # upwind_biased_third_order.jl:21
         if isinstance(s, UpwindBiasedFifthOrder):
             return lambda o: (-3 * f(sh(o, d, 1)) + 27 * f(o) + 47 * f(sh(o, d, -1))
                               - 13 * f(sh(o, d, -2)) + 2 * f(sh(o, d, -3))) / 60
@@ -94,6 +112,10 @@ class Advection:
 
     def _right_face(self, d, f):
         s = self.s
+        if isinstance(s, UpwindBiasedFirstOrder):
+            return lambda o: f(o)                                                              # c[i]
+        if isinstance(s, UpwindBiasedThirdOrder):
+            return lambda o: (-f(sh(o, d, 1)) + 5 * f(o) + 2 * f(sh(o, d, -1))) / 6             # :29
         if isinstance(s, UpwindBiasedFifthOrder):
             return lambda o: (2 * f(sh(o, d, 2)) - 13 * f(sh(o, d, 1)) + 47 * f(o)
                               + 27 * f(sh(o, d, -1)) - 3 * f(sh(o, d, -2))) / 60

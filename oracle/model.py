@@ -19,7 +19,7 @@ from .grid import RectilinearGrid, Periodic, Bounded, Flat, Center, Face  # noqa
 from .fields import Field, fill_halo_regions, FluxBC, ValueBC, GradientBC, SIDES  # noqa: F401
 from .operators import Ops, sh
 from .advection import (Advection, WENO5, CenteredSecondOrder, CenteredFourthOrder,  # noqa: F401
-                        UpwindBiasedFifthOrder)
+                        UpwindBiasedFifthOrder, UpwindBiasedFirstOrder, UpwindBiasedThirdOrder)
 from .closures import ScalarDiffusivity, AnisotropicMinimumDissipation, Closure
 from .poisson import FFTBasedPoissonSolver, FourierTridiagonalPoissonSolver
 

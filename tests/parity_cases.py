@@ -13,6 +13,7 @@ P, B, F = "Periodic", "Bounded", "Flat"
 
 def _adv(mod, name):
     return {None: None, "WENO5": mod.WENO5(), "WENO5JS": mod.WENO5(zweno=False), "U5": mod.UpwindBiasedFifthOrder(),
+            "U1": mod.UpwindBiasedFirstOrder(), "U3": mod.UpwindBiasedThirdOrder(),
             "C4": mod.CenteredFourthOrder(), "C2": mod.CenteredSecondOrder()}[name]
 
 
@@ -26,6 +27,13 @@ CASES = {
                                   dt=3e-3, tracers=("a", "b2")),
     "ppp_u5_visc": dict(size=(10, 9, 8), topo=(P, P, P), extent=(1, 1, 1), adv="U5", stepper="AB2", steps=2, dt=2e-3,
                         tracers=("c",), closure=(1e-2, 2e-2)),
+    # UpwindBiasedFirstOrder / ThirdOrder (boundary buffer 1, halo 2): general kernels
+    "ppp_u3_tracer": dict(size=(9, 8, 10), topo=(P, P, P), extent=(1, 1, 1), adv="U3", stepper="AB2", steps=2, dt=2e-3,
+                          tracers=("c",), halo=(2, 2, 2)),
+    "ppb_u1_btracer": dict(size=(8, 9, 7), topo=(P, P, B), extent=(1, 1, 1), adv="U1", stepper="RK3", steps=2, dt=3e-3,
+                           tracers=("b",), buoyancy="b", halo=(2, 2, 2)),
+    "bbb_u3_walls": dict(size=(8, 7, 9), topo=(B, B, B), extent=(1, 1, 1), adv="U3", stepper="AB2", steps=2, dt=3e-3,
+                         tracers=("c",), closure=(1e-3, 1e-3), halo=(2, 2, 2)),
     "ppp_c4": dict(size=(8, 10, 12), topo=(P, P, P), extent=(1, 1, 1), adv="C4", stepper="RK3", steps=2, dt=2e-3),
     "ppp_c2_default": dict(size=(8, 8, 8), topo=(P, P, P), extent=(1, 1, 1), adv="C2", stepper="AB2", steps=2, dt=2e-3,
                            halo=(1, 1, 1)),

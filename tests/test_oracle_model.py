@@ -230,7 +230,8 @@ def _advect_1d(Nx, dt, scheme, axis, U=1.0, kap=1e-8, width=0.05):
 
 
 @pytest.mark.parametrize("scheme,order,tol", [(O.WENO5(), 5, 0.4), (O.UpwindBiasedFifthOrder(), 5, 0.2),
-                                              (O.CenteredFourthOrder(), 4, 0.06), (O.CenteredSecondOrder(), 2, 0.02)])
+                                              (O.CenteredFourthOrder(), 4, 0.06), (O.CenteredSecondOrder(), 2, 0.02),
+                                              (O.UpwindBiasedThirdOrder(), 3, 0.1), (O.UpwindBiasedFirstOrder(), 1, 0.2)])
 def test_advection_scheme_convergence(scheme, order, tol):
     U, kap = 1.0, 1e-8
     h = 2.5 / 512
