@@ -53,7 +53,6 @@ def cpu_baseline():
     """CPU restatement of the reference's CPU() path on a bounded sample of the same workload (config 2: triply periodic
     WENO5 AB2 + FFT Poisson), timed on this host: the C++/OpenMP restatement (oracle/cpu/ocn_cpu.cpp) with one thread
     at 128^3 and with every available core at 256^3, and the NumPy oracle at 64^3.  About 20 s in all."""
-    import ctypes as C
     import subprocess
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:    # a container's CPU share (cgroup v2 quota) is what this process can really use: more threads only thrash
@@ -73,25 +72,33 @@ def cpu_baseline():
         pass
     out = {"unit": "cell-updates/s", "kind": "port", "cpu_model": model, "host_cores": cores}
     lib = os.path.join(ROOT, "oracle", "cpu", "libocn_cpu.so")
+    # run in a child process: whatever happens to the baseline (a host without the library's ISA level, an out-of-memory
+    # kill), the bench line of the GPU path is still printed
+    child = r"""
+import ctypes as C, json, sys, numpy as np
+L = C.CDLL(sys.argv[1]); PD = C.POINTER(C.c_double)
+L.ocncpu_run.restype = C.c_int
+L.ocncpu_run.argtypes = [C.c_int] * 3 + [C.c_double] * 3 + [PD] * 4 + [C.c_double, C.c_int, C.c_int, PD]
+def run(n, threads, steps):
+    rng = np.random.default_rng(1)
+    a = [np.asfortranarray(rng.random((n, n, n)) - 0.5) for _ in range(3)]
+    secs = C.c_double()
+    rc = L.ocncpu_run(n, n, n, 1.0, 1.0, 1.0, a[0].ctypes.data_as(PD), a[1].ctypes.data_as(PD), a[2].ctypes.data_as(PD),
+                      None, 0.2 / n / 0.5, steps, threads, C.byref(secs))
+    assert rc == 0, rc
+    return n ** 3 * steps / secs.value
+cores = int(sys.argv[2])
+one = run(128, 1, 2)
+print(json.dumps({"one": one, "all": run(256, cores, 4) if cores > 1 else one}))
+"""
     try:
         if not os.path.exists(lib):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
-        L = C.CDLL(lib)
-        PD = C.POINTER(C.c_double)
-        L.ocncpu_run.restype = C.c_int
-        L.ocncpu_run.argtypes = [C.c_int] * 3 + [C.c_double] * 3 + [PD] * 4 + [C.c_double, C.c_int, C.c_int, PD]
-
-        def run(n, threads, steps):
-            rng = np.random.default_rng(1)
-            a = [np.asfortranarray(rng.random((n, n, n)) - 0.5) for _ in range(3)]
-            secs = C.c_double()
-            rc = L.ocncpu_run(n, n, n, 1.0, 1.0, 1.0, a[0].ctypes.data_as(PD), a[1].ctypes.data_as(PD), a[2].ctypes.data_as(PD),
-                              None, 0.2 / n / 0.5, steps, threads, C.byref(secs))
-            if rc:
-                raise RuntimeError(f"ocncpu_run returned {rc}")
-            return n ** 3 * steps / secs.value
-        one = run(128, 1, 2)
-        allc = run(256, cores, 4) if cores > 1 else one
+        r = subprocess.run([sys.executable, "-c", child, lib, str(cores)], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            raise RuntimeError(f"exit code {r.returncode}: {r.stderr[-200:]}")
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        one, allc = res["one"], res["all"]
         out.update({"value": allc, "cores": cores,
                     "sample": f"4 AB2 WENO5 steps at 256^3 (the whole workload), C++/OpenMP restatement, {cores} threads",
                     "single_core": {"value": one, "cores": 1, "sample": "2 steps at 128^3, same code, 1 thread"}})
