@@ -257,6 +257,7 @@ def main():
 
     dist = None
     real_stdout = None
+    transport = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
@@ -274,7 +275,7 @@ def main():
     if world > 1:
         from importlib import import_module
         par = import_module("ocnhip.parallel")
-        par.init_comm(ctx, dist, rank, world)
+        transport = par.init_comm(ctx, dist, rank, world, allow_fallback=True)
     # global grid: the library cuts triply periodic grids into z-slabs (Nz / world levels per rank) and
     # (Periodic, Periodic, Bounded) grids into y-slabs
     if args.size:
@@ -425,7 +426,7 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": ("rehearsal on the host emulation of the kernels: plumbing check, NOT a measurement" if args.rehearse_hostemu else
                      "synthetic; REHEARSAL: ranks share GPUs and exchange through host shared memory -- not a scaling measurement"
-                     if world > 1 and os.environ.get("OCNHIP_TRANSPORT") == "shm" else "synthetic"),
+                     if world > 1 and transport and transport.startswith("shm") else "synthetic"),
             "config": {"workload": (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} "
                                     + ("triply-periodic" if args.topology.upper() == "PPP" else f"topology {args.topology.upper()}")
                                     + " RectilinearGrid, "
@@ -437,7 +438,7 @@ def main():
                        (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} (Periodic,Periodic,Bounded) stretched z, WENO5, RK3, T+S, "
                         "FPlane, linear EOS, AMD, flux/gradient BCs, Fourier-tridiagonal Poisson (BASELINE config 3)"),
                        "decomposition": f"{'y' if args.config == 3 else 'z'}-slabs x{world}", "dt": dt, "init": args.init,
-                       "local_size": list(n), "transport": ("shm" if args.rehearse_hostemu else os.environ.get("OCNHIP_TRANSPORT", "rccl")) if world > 1 else None},
+                       "local_size": list(n), "transport": transport},
             "roofline": roofline,
             "step_roofline": {"alg_bytes_per_cell_update": b_alg, "frac_of_hbm_peak": step_frac,
                               "measured_copy_rate_GBps": copy_rate / 1e9 if copy_rate else None,

@@ -100,8 +100,11 @@ template <int N> struct FftGeo {
 };
 
 // all threads of the workgroup take part (barriers inside)
-template <int N, int S> OCN_DEVFN void fft_stage2(double* sm, cd* v, int r, int c, const cd* tw) {
+// XL: the x pass, whose lanes run over r first (the transformed direction is the contiguous one): image [k1][c][r] with an
+// odd k1 stride, conflict-free for its writes (r consecutive) and its reads (k1 = r consecutive: stride 257 words)
+template <int N, int S, bool XL = false> OCN_DEVFN void fft_stage2(double* sm, cd* v, int r, int c, const cd* tw) {
   typedef FftGeo<N> G;
+  constexpr int KX = G::RS * G::CS + 1;
   constexpr int TS = 512 / (N == 512 ? 256 : N);     // table stride of the inner transform's roots
   // twiddles W^(r k1) of the inner transform (n2 = r)
 #pragma unroll
@@ -111,10 +114,12 @@ template <int N, int S> OCN_DEVFN void fft_stage2(double* sm, cd* v, int r, int 
     v[k1] = cmul(v[k1], w);
   }
   // transpose: element (k1, n2 = r) -> the thread(s) that own k1
-  auto wi = [&](int k1) { return k1 * G::K1S + r * G::CS + c; };
+  auto wi = [&](int k1) { return XL ? k1 * KX + c * G::RS + r : k1 * G::K1S + r * G::CS + c; };
   if (N == 128) {
     // thread r takes k1 = r and r + 8: reads n2 = 0..7 of each
-    auto ri = [&](int q) { return (r + 8 * (q >> 3)) * G::K1S + (q & 7) * G::CS + c; };
+    auto ri = [&](int q) {
+      return XL ? (r + 8 * (q >> 3)) * KX + c * G::RS + (q & 7) : (r + 8 * (q >> 3)) * G::K1S + (q & 7) * G::CS + c;
+    };
 #pragma unroll
     for (int q = 0; q < 16; ++q) sm[wi(q)] = v[q].x;
     __syncthreads();
@@ -129,7 +134,7 @@ template <int N, int S> OCN_DEVFN void fft_stage2(double* sm, cd* v, int r, int 
     dft8<S>(v);
     dft8<S>(v + 8);
   } else {
-    auto ri = [&](int n2) { return r * G::K1S + n2 * G::CS + c; };
+    auto ri = [&](int n2) { return XL ? r * KX + c * G::RS + n2 : r * G::K1S + n2 * G::CS + c; };
 #pragma unroll
     for (int q = 0; q < 16; ++q) sm[wi(q)] = v[q].x;
     __syncthreads();
@@ -186,7 +191,7 @@ template <int N, int S, bool XLANE = false> OCN_DEVFN void fft_fwd(double* sm, c
     }
   }
   dft16<S>(v);
-  fft_stage2<N, S>(sm, v, r, c, tw);
+  fft_stage2<N, S, XLANE>(sm, v, r, c, tw);
 }
 
 // the same network run backwards: from the spectral layout of fft_fwd<N, +1> back to v[n1] = x[r + M' n1 (+ 256 h)],

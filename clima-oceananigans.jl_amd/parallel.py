@@ -9,8 +9,7 @@ import ctypes as C
 from ._lib import check
 
 
-def init_comm(ctx, dist, rank, world):
-    """ocn_comm_init with a unique id created on rank 0 and broadcast over the (CPU) process group."""
+def _broadcast_id(ctx, dist, rank):
     import torch
     buf = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
@@ -18,8 +17,33 @@ def init_comm(ctx, dist, rank, world):
         check(ctx.lib.ocn_comm_unique_id(raw))
         buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
     dist.broadcast(buf, src=0)
-    raw = (C.c_char * 128).from_buffer_copy(bytes(buf.numpy().tobytes()))
+    return (C.c_char * 128).from_buffer_copy(bytes(buf.numpy().tobytes()))
+
+
+def init_comm(ctx, dist, rank, world, allow_fallback=False):
+    """ocn_comm_init with a unique id created on rank 0 and broadcast over the (CPU) process group.
+
+    Returns the transport in use: "rccl", "shm" (asked for with OCNHIP_TRANSPORT=shm, or the host-emulation build) or, with
+    ``allow_fallback``, "shm (fallback: <RCCL error>)" when the RCCL communicator could not be created on some rank -- every
+    rank then switches to the host shared-memory transport together, so that a node whose RCCL set-up is broken still
+    produces (slow, clearly labelled) numbers instead of none."""
+    import os
+    import torch
+    raw = _broadcast_id(ctx, dist, rank)
+    is_shm = bytes(raw.raw[:4]) == b"SHM:"
+    rc = ctx.lib.ocn_comm_init(ctx.h, int(rank), int(world), raw)
+    if not allow_fallback or is_shm:
+        check(rc, ctx.h)
+        return "shm" if is_shm else "rccl"
+    worst = torch.tensor([rc], dtype=torch.int64)
+    dist.all_reduce(worst, op=dist.ReduceOp.MIN)          # error codes are negative
+    if int(worst[0]) == 0:
+        return "rccl"
+    why = ctx.lib.ocn_last_error(ctx.h).decode(errors="replace") if rc else "another rank failed"
+    os.environ["OCNHIP_TRANSPORT"] = "shm"
+    raw = _broadcast_id(ctx, dist, rank)
     check(ctx.lib.ocn_comm_init(ctx.h, int(rank), int(world), raw), ctx.h)
+    return f"shm (fallback: {why})"
 
 
 def init_comm_self(ctx):
