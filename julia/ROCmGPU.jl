@@ -69,7 +69,9 @@ end
 
 # Field data alias the library's parent arrays (same layout as Grids/new_data.jl:33-61).  With walls or slices in
 # x / y the allocation is pitched: ocn_field_layout gives element strides and the origin of the logical parent.
-# G^n / G^- / fast-path tracers rotate buffers: call this again after every time_step! for those fields.
+# u, v, w, both pressures, nu_e and kappa_e keep their device pointers for the life of the model (alias once, at model
+# construction); G^n / G^- and, on the tiled kernels' paths, the tracers are double buffered: call this again after every
+# time_step! for those fields (include/ocnhip.h, "pointer stability"; tests/test_model_contracts.py).
 function alias_field_data(model_handle, field_id, grid, loc)
     p = ccall((:ocn_field_device_ptr, libocnhip), Ptr{Float64}, (Ptr{Cvoid}, Cint), model_handle, field_id)
     st = zeros(Int64, 3); org = Ref(Int64(0))
@@ -124,7 +126,17 @@ function arch_array(::CPU, a::OffsetArray{T, 3, <:ROCArray}) where T
     return OffsetArray(host, a.offsets...)
 end
 
-# Distributed: MultiArch(ROCmGPU(); ranks=(1, 1, R)) -> ocn_comm_init(ctx, rank, R, id) with the ncclUniqueId
-# broadcast over MPI (Distributed/multi_architectures.jl:20-47); everything else is unchanged.
+# Which kernels serve a model (and why not the fastest ones): ocn_model_path(handle, buf, n) -> String, for `show(model)`.
+kernel_path(model::RM) = (buf = Vector{UInt8}(undef, 256);
+                          check(ccall((:ocn_model_path, libocnhip), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Csize_t), handle(model), buf, 256));
+                          unsafe_string(pointer(buf)))
+
+# Checkpoint / restart (OutputWriters/checkpointer.jl:158-265): download the parent arrays of u, v, w, tracers, G^n, G^- and
+# the clock; restore with ocn_field_upload + ocn_set_clock(time, iteration, previous_dt) + update_state!.  Continuing from
+# the restored state is bit-identical to the uninterrupted run (tests/test_model_contracts.py, all four stepper / topology pairs).
+
+# Distributed: MultiArch(ROCmGPU(); ranks=(1, 1, R)) -> ocn_comm_init(ctx, rank, R, id) with the 128-byte id of
+# ocn_comm_unique_id broadcast over MPI (Distributed/multi_architectures.jl:20-47); everything else is unchanged.
+# advection = nothing -> OCN_ADV_NONE; UpwindBiasedFirstOrder / ThirdOrder -> OCN_ADV_U1 / OCN_ADV_U3.
 
 end # module
