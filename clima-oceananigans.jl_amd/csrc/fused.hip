@@ -457,6 +457,180 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
 #undef SLB
 }
 
+// ---- k_rest4: the non-advective momentum terms of the "rest + tiled advection" models, tiled like k_tend4 ------------------
+// closure stress divergence  2 d_j (nu Sigma_ij)  with a constant nu (ScalarDiffusivity) or the eddy viscosity field of
+// AnisotropicMinimumDissipation interpolated to the stress locations (closure_kernel_operators.jl:22-41,72-90,
+// velocity_tracer_gradients.jl), Coriolis on the f-plane (f_plane.jl:42-44) and the hydrostatic pressure gradient
+// (nonhydrostatic_tendency_kernel_functions.jl:44-106).  k_tend_uvw<ADV_NONE> evaluates every stress twice (once per cell
+// on either side) from ~60 cached loads per thread; here every thread forms the six stresses at the WEST / SOUTH / BOTTOM
+// of its cell once -- tau11 at centre i-1, tau22 at centre j-1, tau33 at centre k-1, tau12 at the (x-face, y-face) corner,
+// tau13 at (x-face, z-face), tau23 at (y-face, z-face); tau12 serves u's south and v's west flux, tau13 u's bottom and w's
+// west, tau23 v's bottom and w's south -- east values come by lane shift, north values through LDS, top values are the next
+// level's bottom values.  Slab: u, v, w, nu_e with one halo row / column, both buffers, staged by LDS DMA (complete rows
+// only: the x-tiled and wall-in-x models keep the general kernel).  Output: G^n = these terms (the flux-boundary kernels and
+// k_tend4<REST> add theirs afterwards).
+struct RestArgs {
+  const double *u, *v, *w, *nue, *pH;   // PARENT bases (nue / pH may be null)
+  double *gu, *gv, *gw;
+  unsigned org;
+  double nu, f;                         // constant viscosity (nue == null), Coriolis parameter
+  int closure, coriolis, ntiles;
+};
+
+template <int BX, int BY, bool ZB>
+__global__ void __launch_bounds__(BX* BY) k_rest4(GridDev g, RestArgs a) {
+  constexpr int T = BX * BY, NR = BY + 1, SX = BX + 6;      // rows j0-1 .. j0+BY-1; columns -3 .. Nx+2 (the parent row)
+  constexpr int WV = BX < OCN_WAVE ? BX : OCN_WAVE, NW = BX / WV, NWV = T / WV;
+  constexpr int SLAB = 4 * NR * SX;
+  OCN_SHARED double lds[2 * SLAB + 6 * T + 6 * BY * NW] __attribute__((aligned(16)));
+  double* const fyb = lds + 2 * SLAB;
+  double* const fxe = fyb + 6 * T;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tid = ty * BX + tx;
+  const int lane = tid % WV;
+  const int wave = OCN_UNIFORM(tid / WV);
+  const unsigned sxb = 8u, syb = (unsigned)g.sy * 8u, szb = (unsigned)g.sz * 8u;
+  const double rdx = g.rdx, rdy = g.rdy;
+  const bool ghost = (ty == BY - 1);
+  const int nid_n = (ty + 1 < BY ? ty + 1 : ty) * BX + tx;
+  const bool xedge = (tx % WV == WV - 1) || (tx + 1 >= g.Nx);
+  const int txe = (tx + 1 >= g.Nx) ? 0 : tx + 1;
+  const int eidx = ty * NW + txe / WV;
+  const bool amd = a.nue != nullptr;
+  const int nseg = gridDim.x, per = nseg / 8;
+  const long seg = (nseg % 8 == 0) ? (long)(blockIdx.x % 8) * per + blockIdx.x / 8 : (long)blockIdx.x;
+  const long total = (long)a.ntiles * g.Nz;
+  long lo = seg * total / nseg;
+  const long hi = (seg + 1) * total / nseg;
+  const int PR = (g.Nx + 6) / 2;
+  while (lo < hi) {
+    const int tile = (int)(lo / g.Nz);
+    const int k0 = (int)(lo - (long)tile * g.Nz);
+    const int k1 = (k0 + (hi - lo) < g.Nz) ? (int)(k0 + (hi - lo)) : g.Nz;
+    lo += k1 - k0;
+    const int j0 = tile * (BY - 1);
+    const int j = j0 + ty;
+    const bool ocol = tx < g.Nx;
+    const bool do_y = ocol && j <= g.Ny;              // forms the south-face stresses
+    const bool full = ocol && j < g.Ny && !ghost;
+    const unsigned cxy = a.org + (unsigned)(ocol ? tx : 0) * sxb + (unsigned)(j <= g.Ny ? j : 0) * syb;
+    auto dma = [&](int k, int buf) {                  // rows j0-1 .. of level k, every field; wave w takes (field, row) pairs
+      const long src0 = (long)a.org + ((long)(j0 - 1) * g.sy + (long)k * g.sz - 3) * 8;
+      const int nf = amd ? 4 : 3;
+      for (int fr = wave; fr < nf * NR; fr += NWV) {
+        const int f = fr / NR, r = fr - f * NR;
+        const double* base = f == 0 ? a.u : f == 1 ? a.v : f == 2 ? a.w : a.nue;
+        const unsigned so = (unsigned)(src0 + (long)r * g.sy * 8);
+        char* dst = (char*)(lds + buf * SLAB + fr * SX);
+        for (int q0 = 0; q0 < PR; q0 += WV)
+          if (q0 + lane < PR) ocn_glds16((const char*)base + (so + 16u * (unsigned)(q0 + lane)), dst + 16 * q0, lane);
+      }
+    };
+    // element (field f, row offset d in {-1, 0, +1}, column offset e) of the level's slab, relative to this thread's cell
+#define RS(f, d, e) S[(f) * NR * SX + ((d) + 1) * SX + (e) + 3]
+    // carried from the level below: own u, v, w, nu and nu of the west / south neighbours; horizontal part + bottom stresses
+    const unsigned cb = cxy + (unsigned)k0 * szb - szb;
+    double up = ldo(a.u, cb), vp = ldo(a.v, cb), wp = ldo(a.w, cb);
+    double ncp = amd ? ldo(a.nue, cb) : a.nu, nwp = amd ? ldo(a.nue, cb - sxb) : a.nu, nsp = amd ? ldo(a.nue, cb - syb) : a.nu;
+    double hu = 0, hv = 0, hw = 0, bu = 0, bv = 0, bw = 0;
+    __syncthreads();
+    dma(k0, 0);
+    for (int k = k0; k <= k1; ++k) {
+      const int kb = (k - k0) & 1;
+      const bool last = (k == k1);
+      const unsigned c = cxy + (unsigned)k * szb;
+      __syncthreads();
+      if (!last) dma(k + 1, kb ^ 1);
+      const double* S = lds + kb * SLAB + ty * SX + tx;
+      // hydrostatic pressure of this cell and its west / south neighbours (level k), issued early
+      double p0 = 0, pw = 0, ps = 0;
+      if (a.pH && full && !last) {
+        p0 = ldo(a.pH, c);
+        pw = ldo(a.pH, c - sxb);
+        ps = ldo(a.pH, c - syb);
+      }
+      if (full && k > k0) {                           // complete level k-1's horizontal part with the north / x-edge values
+        const double* fyp = fyb + (kb ^ 1) * 3 * T;
+        const double rdy2 = rdy + rdy, rdx2 = rdx + rdx;       // the stress divergence carries a factor 2
+        hu = fma(fyp[0 * T + nid_n], rdy2, hu);
+        hv = fma(fyp[1 * T + nid_n], rdy2, hv);
+        hw = fma(fyp[2 * T + nid_n], rdy2, hw);
+        if (xedge) {
+          const double* fxp = fxe + (kb ^ 1) * 3 * BY * NW;
+          hu = fma(fxp[0 * BY * NW + eidx], rdx2, hu);
+          hv = fma(fxp[1 * BY * NW + eidx], rdx2, hv);
+          hw = fma(fxp[2 * BY * NW + eidx], rdx2, hw);
+        }
+      }
+      const double rzf = ZB ? g_rdzf(g, k) : g.rdz;   // 1 / dz at face k
+      const double uc = RS(0, 0, 0), vc = RS(1, 0, 0), wc = RS(2, 0, 0);
+      const double nc = amd ? RS(3, 0, 0) : a.nu, nw = amd ? RS(3, 0, -1) : a.nu, ns = amd ? RS(3, -1, 0) : a.nu;
+      // stresses nu * S at the west / south / bottom of this cell (level k)
+      double t11 = 0, t12 = 0, t13 = 0, t22 = 0, t23 = 0, t33 = 0;
+      if (a.closure != OCN_CLOSURE_NONE && do_y) {
+        const double nsw = amd ? RS(3, -1, -1) : a.nu;
+        t12 = 0.25 * ((nsw + ns) + (nw + nc)) * (0.5 * ((uc - RS(0, -1, 0)) * rdy + (vc - RS(1, 0, -1)) * rdx));     // (x-face i, y-face j)
+        t22 = ns * ((vc - RS(1, -1, 0)) * rdy);                                                                   // centre j-1
+        t23 = 0.25 * ((nsp + ncp) + (ns + nc)) * (0.5 * ((vc - vp) * rzf + (wc - RS(2, -1, 0)) * rdy));             // (y-face j, z-face k)
+        if (full) {
+          t11 = nw * ((uc - RS(0, 0, -1)) * rdx);                                                                  // centre i-1
+          t13 = 0.25 * ((nwp + ncp) + (nw + nc)) * (0.5 * ((uc - up) * rzf + (wc - RS(2, 0, -1)) * rdx));           // (x-face i, z-face k)
+          t33 = ncp * ((wc - wp) * (ZB ? g_rdzc(g, k - 1) : g.rdz));                                               // centre k-1
+        }
+      }
+      if (!last && do_y) {
+        double* fyn = fyb + kb * 3 * T;
+        fyn[0 * T + tid] = t12;
+        fyn[1 * T + tid] = t22;
+        fyn[2 * T + tid] = t23;
+      }
+      double e0 = 0, e1 = 0, e2 = 0;
+      if (!last) {
+        e0 = ocn_shfl_next(t11);
+        e1 = ocn_shfl_next(t12);
+        e2 = ocn_shfl_next(t13);
+        if (tx % WV == 0 && full) {
+          double* fxn = fxe + kb * 3 * BY * NW + ty * NW + tx / WV;
+          fxn[0 * BY * NW] = t11;
+          fxn[1 * BY * NW] = t12;
+          fxn[2 * BY * NW] = t13;
+        }
+      }
+      if (full) {
+        if (k > k0) {                                 // level k-1: z differences with this level's bottom stresses on top
+          const unsigned cm1 = c - szb;
+          const double rzc = ZB ? g_rdzc(g, k - 1) : g.rdz, rzfm = ZB ? g_rdzf(g, k - 1) : g.rdz;
+          sto(a.gu, cm1, hu + 2.0 * ((t13 - bu) * rzc));
+          sto(a.gv, cm1, hv + 2.0 * ((t23 - bv) * rzc));
+          sto(a.gw, cm1, hw + 2.0 * ((t33 - bw) * rzfm));   // w at face k-1: tau33 at centre k-1 (here) minus centre k-2 (carried)
+        }
+        if (!last) {
+          // level k: 2 [(east - west) / dx - south / dy] now (north / dy, x-edge east / dx after the next barrier), plus the
+          // pointwise terms
+          double cu = 0, cv = 0;
+          if (a.coriolis) {
+            cu = a.f * (0.5 * (0.5 * (RS(1, 0, -1) + vc) + 0.5 * (RS(1, 1, -1) + RS(1, 1, 0))));
+            cv = -a.f * (0.5 * (0.5 * (RS(0, -1, 0) + RS(0, -1, 1)) + 0.5 * (uc + RS(0, 0, 1))));
+          }
+          if (a.pH) {
+            cu -= (p0 - pw) * rdx;
+            cv -= (p0 - ps) * rdy;
+          }
+          hu = cu + 2.0 * fma(xedge ? -t11 : e0 - t11, rdx, -t12 * rdy);
+          hv = cv + 2.0 * fma(xedge ? -t12 : e1 - t12, rdx, -t22 * rdy);
+          hw = 2.0 * fma(xedge ? -t13 : e2 - t13, rdx, -t23 * rdy);
+          bu = t13;
+          bv = t23;
+          bw = t33;
+        }
+      }
+      up = uc; vp = vc; wp = wc;
+      ncp = nc; nwp = nw; nsp = ns;
+    }
+  }
+#undef RS
+}
+
 // ---- Poisson right-hand side with wrap indexing (no halo fill of the predictor) ----------------------
 __global__ void k_rhs_wrap(GridDev g, const double* __restrict__ us, const double* __restrict__ vs,
                            const double* __restrict__ ws, double rdt, int zwrap, double* __restrict__ rhs) {
@@ -798,10 +972,12 @@ bool fused_available(const ocn_model* m) {
   return true;
 }
 
+bool rest4_ok(const ocn_model* m);
 void fused_describe(const ocn_model* m, char* buf, size_t n) {
   const char* why = tiled_blocker(m);
   if (m->fast_path) snprintf(buf, n, "all-in-one periodic path: k_tend4 + fused Poisson passes + k_project");
-  else if (m->bz_fast) snprintf(buf, n, "tiled advection + update (k_tend4, REST) on top of the general kernels' other terms");
+  else if (m->bz_fast) snprintf(buf, n, "tiled advection + update (k_tend4, REST) on top of the %s other terms",
+                                rest4_ok(m) ? "tiled kernel's (k_rest4)" : "general kernels'");
   else if (why) snprintf(buf, n, "general kernels: %s", why);
   else if (m->g->topo[0] == OCN_FLAT || m->g->topo[1] == OCN_FLAT) snprintf(buf, n, "general kernels: Flat x / y slices are outside the tiled kernels");
   else snprintf(buf, n, "general kernels (tiled path disabled or not applicable to this topology / decomposition)");
@@ -972,6 +1148,55 @@ void launch_fused_bz(ocn_model* m, double dt, double cn, double cm, int use_m) {
 }
 #undef FUSED_BY_SCHEME
 #undef FUSED_LAUNCH
+
+// the non-advective momentum terms of the tiled "rest" models by k_rest4 (complete rows, LDS-DMA layout); false: not applicable
+bool rest4_ok(const ocn_model* m) {
+  const GridDev& gd = m->gd;
+  if (!m->bz_fast || gd.Nx > 256 || gd.xb || m->knob_no_dma) return false;
+  return gd.Hx == 3 && gd.Nx % 2 == 0 && gd.sy % 2 == 0 && gd.sz % 2 == 0 && gd.sy == gd.Nx + 6;
+}
+
+bool launch_rest4(ocn_model* m) {
+  const GridDev& gd = m->gd;
+  if (!rest4_ok(m)) return false;
+  ProfScope ps(m->ctx, "rest_terms");
+  RestArgs a;
+  a.u = m->u.d; a.v = m->v.d; a.w = m->w.d;
+  a.nue = m->nu_e.present ? m->nu_e.d : nullptr;
+  a.pH = (m->pHY.present) ? m->pHY.d : nullptr;
+  a.gu = m->Gn[0].d; a.gv = m->Gn[1].d; a.gw = m->Gn[2].d;
+  a.org = (unsigned)((m->u.Hx + m->u.Hy * m->u.sy + m->u.Hz * m->u.sz) * sizeof(double));
+  a.nu = m->d.nu;
+  a.f = m->d.f;
+  a.closure = m->d.closure;
+  a.coriolis = m->d.coriolis_fplane;
+  int bx = gd.Nx <= 64 ? 64 : gd.Nx <= 128 ? 128 : 256;
+  int by = bx == 256 ? 4 : 8;
+#ifdef OCN_HOST_EMU
+  if (gd.Nx <= 16) {
+    bx = 16;
+    by = 4;
+  }
+#endif
+  a.ntiles = (gd.Ny + by - 2) / (by - 1);
+  int nseg = fused_cu_count(m);
+  const long total = (long)a.ntiles * gd.Nz;
+  if (nseg > total / 4) nseg = (int)(total / 4 > 8 ? total / 4 : 8);
+  nseg = ((nseg + 7) / 8) * 8;
+#ifdef OCN_HOST_EMU
+  nseg = total >= 3 ? 3 : 1;
+#endif
+  const dim3 blk(bx, by, 1), grd(nseg, 1, 1);
+  hipStream_t s = m->ctx->stream;
+  const bool zb = m->g->topo[2] == OCN_BOUNDED;
+#define REST4(BXV, BYV) { if (zb) ocn_launch_sync(k_rest4<BXV, BYV, true>, grd, blk, s, gd, a); else ocn_launch_sync(k_rest4<BXV, BYV, false>, grd, blk, s, gd, a); }
+#ifdef OCN_HOST_EMU
+  if (bx == 16) REST4(16, 4) else
+#endif
+  if (bx == 256) REST4(256, 4) else if (bx == 128) REST4(128, 8) else REST4(64, 8)
+#undef REST4
+  return true;
+}
 
 void launch_rhs_wrap(ocn_model* m, double dt, double* rhs) {
   ProfScope ps(m->ctx, "rhs");

@@ -150,6 +150,7 @@ void fused_describe(const ocn_model* m, char* buf, size_t n);
 bool fused_available(const ocn_model* m);
 bool fused_bz_available(const ocn_model* m);
 void launch_fused_bz(ocn_model* m, double dt, double cn, double cm, int use_m);
+bool launch_rest4(ocn_model* m);
 bool fused_tracer3_ok(const ocn_model* m);
 void launch_tracer3(ocn_model* m, double dt, double cn, double cm, int use_m, bool rest);
 void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m);
