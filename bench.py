@@ -180,7 +180,7 @@ def spawn_ranks(args):
         import torch
         have = torch.cuda.device_count()          # does not initialise the GPU
         ndev = int(os.environ.get("OCNHIP_BENCH_NDEV", "0"))
-        if have < n and not (ndev and os.environ.get("OCNHIP_TRANSPORT") == "shm"):
+        if have < n and not ndev:
             raise SystemExit(f"bench.py: --gpus {n} but this node shows {have} GPU(s); nothing was measured "
                              "(rehearse ranks on fewer GPUs with OCNHIP_TRANSPORT=shm OCNHIP_BENCH_NDEV=<gpus>)")
     s = socket.socket()

@@ -272,6 +272,10 @@ int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* id128) {
     return shm_init(ctx, nm, rank, nranks);
   }
 #ifndef OCN_HOST_EMU
+  if (getenv("OCNHIP_FAKE_RCCL_FAIL")) {   // tests of the callers' fallback (parallel.init_comm): behave like a node whose RCCL cannot start
+    ocn_set_error(ctx, "ncclCommInitRank failed: simulated (OCNHIP_FAKE_RCCL_FAIL)");
+    return OCN_EHIP;
+  }
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   ncclComm_t comm;

@@ -1,4 +1,6 @@
-"""world_size-2 `gloo` tests (CPU): (a) the rendezvous the multi-GPU bench uses -- RCCL-id broadcast through
+"""(Superseded as the multi-process check by tests/test_distributed_procs.py, which steps the LIBRARY on 2 - 3 processes; kept as an
+independent NumPy cross-check of the slab algorithms.)
+world_size-2 `gloo` tests (CPU): (a) the rendezvous the multi-GPU bench uses -- RCCL-id broadcast through
 torch.distributed into ocn_comm_init; (b) the z-slab algorithm of csrc/comm.hip + poisson.hip restated with
 NumPy + gloo collectives (halo exchange of contiguous planes, ky-block all-to-all, z-FFT, and back) against
 the single-domain oracle.  The device kernels of the same algorithm are covered by test_distributed_hostemu.py."""

@@ -93,6 +93,21 @@ def test_bench_refuses_missing_gpus():
     assert "n_gpus" not in out.stdout
 
 
+@pytest.mark.gpu
+def test_bench_falls_back_to_shm_when_rccl_cannot_start():
+    """parallel.init_comm(allow_fallback=True): if the RCCL communicator cannot be created on some rank, every rank switches to
+    the host shared-memory transport together and the bench line says so (simulated failure; two ranks on the one GPU)."""
+    env = dict(os.environ, OCNHIP_FAKE_RCCL_FAIL="1", OCNHIP_BENCH_NDEV="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OCNHIP_LIB", "OCNHIP_TRANSPORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "64", "64",
+                          "64", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["transport"].startswith("shm (fallback:")
+    assert "REHEARSAL" in rec["data"] and rec["max_abs_divergence"] < 1e-10
+
+
 GPU_CASES = [("zslab_ab2", {}), ("zslab_rk3_tracer", {"OCNHIP_DIST_SOLVER": "transpose"}), ("zslab_wide", {}),
              ("yslab_amd", {}), ("poisson", {})]
 
