@@ -80,6 +80,7 @@ def load():
         "ocn_model_destroy": (None, [P]),
         "ocn_model_halo": (I, [P, C.POINTER(C.c_int32 * 3)]),
         "ocn_model_path": (I, [P, C.c_char_p, C.c_size_t]),
+        "ocn_model_graph_replays": (I, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
         "ocn_field_shape": (I, [P, I, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32 * 3)]),
         "ocn_field_device_ptr": (P, [P, I]),
         "ocn_field_layout": (I, [P, I, C.POINTER(C.c_int64 * 3), C.POINTER(C.c_int64)]),

@@ -355,6 +355,13 @@ class NonhydrostaticModel:
         check(self.lib.ocn_model_path(self.h, buf, 256), self.ctx.h)
         return buf.value.decode()
 
+    @property
+    def graph_replays(self):
+        """(steps replayed from a hipGraph so far, whether this model may use step graphs)"""
+        n, act = C.c_int64(0), C.c_int32(0)
+        check(self.lib.ocn_model_graph_replays(self.h, C.byref(n), C.byref(act)), self.ctx.h)
+        return n.value, bool(act.value)
+
     def prognostic(self):
         d = {"u": self.u, "v": self.v, "w": self.w}
         d.update(self.tracers)

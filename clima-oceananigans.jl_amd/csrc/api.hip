@@ -9,7 +9,10 @@ thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 emu_barrier g_emu_barrier;
 double g_emu_shfl[4096];
 std::recursive_mutex g_emu_launch_mutex;
+#else
+thread_local int g_ocn_dry = 0;
 #endif
+thread_local int g_ocn_capturing = 0, g_ocn_capture_poison = 0;
 
 static char g_last_error[512] = {0};
 
@@ -502,6 +505,7 @@ static int materialize_gn(ocn_model* m) {
 }
 
 static int zero_Gm(ocn_model* m) {
+  if (g_ocn_dry) return OCN_OK;
   for (int f = 0; f < 3 + m->nt; ++f)
     OCN_HIP_CHECK(m->ctx, hipMemsetAsync(m->Gm[f].d, 0, m->Gm[f].n * sizeof(double), m->ctx->stream));
   return OCN_OK;
@@ -618,6 +622,128 @@ static int time_step_rk3(ocn_model* m, double dt) {
   }
   return OCN_OK;
 }
+
+// ---- whole-step hipGraphs ----------------------------------------------------------------------------------------
+// A small model's step is a train of ~40-60 short launches and the host cannot issue them as fast as the GPU retires them
+// (config 1, 16^3: 0.15 ms / step, all of it launch latency).  The general path therefore records the launches of one whole
+// step into a hipGraph the SECOND time it meets the same (dt, stepper state, buffer rotation) and replays that graph from
+// then on; the host-side part of the step (clock, G^n / G^- rotation, flags) runs again with every launch skipped
+// (compat.h g_ocn_dry).  The first meeting of a key always runs launch by launch, so lazily built tables exist before a
+// capture.  A capture that fails (or meets a call that must not be captured) restores the stepper state, steps normally
+// and switches graphs off for the model.  Not used by the all-in-one periodic path (7 long launches), by slab models
+// (the exchange is host-driven), under the phase profiler, or in the host emulation.
+struct StepState {
+  Field u, v, w, us, vs, ws, tr[OCN_MAX_TRACERS], trs[OCN_MAX_TRACERS], Gn[OCN_NF], Gm[OCN_NF];
+  double time, previous_dt;
+  int64_t iteration;
+  int stage;
+  bool gn_alias_gm, pred_active;
+};
+static void step_state_save(const ocn_model* m, StepState& s) {
+  s.u = m->u; s.v = m->v; s.w = m->w; s.us = m->us; s.vs = m->vs; s.ws = m->ws;
+  for (int t = 0; t < OCN_MAX_TRACERS; ++t) { s.tr[t] = m->tr[t]; s.trs[t] = m->trs[t]; }
+  for (int f = 0; f < OCN_NF; ++f) { s.Gn[f] = m->Gn[f]; s.Gm[f] = m->Gm[f]; }
+  s.time = m->time; s.previous_dt = m->previous_dt; s.iteration = m->iteration; s.stage = m->stage;
+  s.gn_alias_gm = m->gn_alias_gm; s.pred_active = m->pred_active;
+}
+static void step_state_restore(ocn_model* m, const StepState& s) {
+  m->u = s.u; m->v = s.v; m->w = s.w; m->us = s.us; m->vs = s.vs; m->ws = s.ws;
+  for (int t = 0; t < OCN_MAX_TRACERS; ++t) { m->tr[t] = s.tr[t]; m->trs[t] = s.trs[t]; }
+  for (int f = 0; f < OCN_NF; ++f) { m->Gn[f] = s.Gn[f]; m->Gm[f] = s.Gm[f]; }
+  m->time = s.time; m->previous_dt = s.previous_dt; m->iteration = s.iteration; m->stage = s.stage;
+  m->gn_alias_gm = s.gn_alias_gm; m->pred_active = s.pred_active;
+}
+
+static int step_plain(ocn_model* m, double dt, int force_euler) {
+  if (m->d.stepper == OCN_STEPPER_AB2) return time_step_ab2(m, dt, force_euler);
+  return time_step_rk3(m, dt);
+}
+
+static bool graph_eligible(const ocn_model* m) {
+#ifdef OCN_HOST_EMU
+  (void)m;
+  return false;
+#else
+  return m->knob_graph && !m->graph_off && !m->fast_path && !m->ctx->profiling && m->ctx->nranks == 1 && !m->g->dist &&
+         !m->g->dist_y;
+#endif
+}
+
+#ifndef OCN_HOST_EMU
+static uint64_t step_key(const ocn_model* m, double dt, int force_euler) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+  uint64_t b;
+  memcpy(&b, &dt, 8);
+  mix(b);
+  mix(m->d.stepper == OCN_STEPPER_AB2 && (force_euler || dt != m->previous_dt));
+  mix(m->iteration == 0);
+  mix(m->gn_alias_gm);
+  mix(m->pred_active);
+  auto fp = [&](const Field& f) { mix((uint64_t)(uintptr_t)f.d); };
+  fp(m->u); fp(m->v); fp(m->w); fp(m->us); fp(m->vs); fp(m->ws);
+  for (int t = 0; t < m->nt; ++t) { fp(m->tr[t]); fp(m->trs[t]); }
+  for (int f = 0; f < 3 + m->nt; ++f) { fp(m->Gn[f]); fp(m->Gm[f]); }
+  return h;
+}
+
+static int step_graphed(ocn_model* m, double dt, int force_euler) {
+  const uint64_t key = step_key(m, dt, force_euler);
+  int at = -1;
+  for (size_t i = 0; i < m->graphs.size(); ++i)
+    if (m->graphs[i].key == key) at = (int)i;
+  if (at < 0) {
+    if (m->graphs.size() >= 16) {   // an adaptive dt makes a new key every step: forget the ones that never came back
+      std::vector<ocn_model::StepGraph> keep;
+      for (auto& e : m->graphs)
+        if (e.exec) keep.push_back(e);
+      m->graphs.swap(keep);
+    }
+    if (m->graphs.size() < 16) m->graphs.push_back({key, 1, nullptr});
+    return step_plain(m, dt, force_euler);
+  }
+  hipStream_t st = m->ctx->stream;
+  if (m->graphs[at].exec) {
+    OCN_HIP_CHECK(m->ctx, hipGraphLaunch((hipGraphExec_t)m->graphs[at].exec, st));
+    g_ocn_dry = 1;
+    int rc = step_plain(m, dt, force_euler);
+    g_ocn_dry = 0;
+    m->graph_replays += 1;
+    return rc;
+  }
+  StepState saved;
+  step_state_save(m, saved);
+  auto give_up = [&](const char* why) {
+    (void)hipGetLastError();
+    step_state_restore(m, saved);
+    m->graph_off = true;
+    if (getenv("OCNHIP_DEBUG")) fprintf(stderr, "[ocnhip] step graphs off: %s\n", why);
+    return step_plain(m, dt, force_euler);
+  };
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return give_up("hipStreamBeginCapture");
+  g_ocn_capturing = 1;
+  g_ocn_capture_poison = 0;
+  int rc = step_plain(m, dt, force_euler);
+  g_ocn_capturing = 0;
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &graph);
+  if (rc != OCN_OK || e != hipSuccess || !graph || g_ocn_capture_poison) {
+    if (graph) hipGraphDestroy(graph);
+    return give_up(g_ocn_capture_poison ? "a call that cannot be captured" : "capture failed");
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess || !exec) return give_up("hipGraphInstantiate");
+  if (hipGraphLaunch(exec, st) != hipSuccess) {
+    hipGraphExecDestroy(exec);
+    return give_up("hipGraphLaunch");
+  }
+  m->graphs[at].exec = exec;
+  m->graph_replays += 1;
+  return OCN_OK;
+}
+#endif
 
 extern "C" {
 
@@ -766,6 +892,10 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
 void ocn_model_destroy(ocn_model* m) {
   if (!m) return;
   hipStreamSynchronize(m->ctx->stream);
+#ifndef OCN_HOST_EMU
+  for (auto& e : m->graphs)
+    if (e.exec) hipGraphExecDestroy((hipGraphExec_t)e.exec);
+#endif
   Field* all[] = {&m->u, &m->v, &m->w, &m->pHY, &m->pNHS, &m->nu_e, &m->us, &m->vs, &m->ws};
   for (Field* f : all) hipFree(f->d);
   for (int t = 0; t < OCN_MAX_TRACERS; ++t) {
@@ -791,6 +921,13 @@ void ocn_model_destroy(ocn_model* m) {
 int ocn_model_path(const ocn_model* m, char* buf, size_t n) {
   if (!m || !buf || n == 0) return OCN_EINVAL;
   fused_describe(m, buf, n);
+  return OCN_OK;
+}
+
+int ocn_model_graph_replays(const ocn_model* m, int64_t* replays, int32_t* active) {
+  if (!m) return OCN_EINVAL;
+  if (replays) *replays = m->graph_replays;
+  if (active) *active = graph_eligible(m) ? 1 : 0;
   return OCN_OK;
 }
 
@@ -996,8 +1133,10 @@ int ocn_set_epilogue(ocn_model* m, int enforce_incompressibility) {
 int ocn_time_step(ocn_model* m, double dt, int force_euler) {
   if (!m) return OCN_EINVAL;
   ProfScope ps(m->ctx, "time_step");
-  if (m->d.stepper == OCN_STEPPER_AB2) return time_step_ab2(m, dt, force_euler);
-  return time_step_rk3(m, dt);
+#ifndef OCN_HOST_EMU
+  if (graph_eligible(m)) return step_graphed(m, dt, force_euler);
+#endif
+  return step_plain(m, dt, force_euler);
 }
 
 int ocn_clock(const ocn_model* m, double* time, int64_t* iteration, int32_t* stage) {

@@ -23,13 +23,18 @@
 
 #define OCN_DEVFN __device__ __forceinline__
 
+// g_ocn_dry: a time step is being REPLAYED from a hipGraph (api.hip): the host-side bookkeeping of the step runs again
+// (clock, buffer rotations), every launch and stream operation is skipped
+extern thread_local int g_ocn_dry;
 template <class K, class... A>
 static inline void ocn_launch(K kern, dim3 grid, dim3 block, hipStream_t s, A... args) {
+  if (g_ocn_dry) return;
   hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
 }
 // kernels that use __shared__ / __syncthreads go through the same call on the GPU
 template <class K, class... A>
 static inline void ocn_launch_sync(K kern, dim3 grid, dim3 block, hipStream_t s, A... args) {
+  if (g_ocn_dry) return;
   hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
 }
 #define OCN_SHARED __shared__
@@ -79,6 +84,7 @@ struct dim3 {
   dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
 };
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+#define g_ocn_dry 0   /* no graphs in the host emulation */
 extern std::recursive_mutex g_emu_launch_mutex;   // one emulated kernel at a time (static "LDS" arrays are shared)
 
 #define __global__

@@ -1011,11 +1011,13 @@ struct FusedShape {
 //                         one-chunk form
 //   OCNHIP_NO_TRACER3=1   column tracer kernel instead of the tiled one (tests)
 //   OCNHIP_PRIO=code      wave-priority code (see prio_start; 0 = hardware default)
+//   OCNHIP_NO_GRAPH=1     general path: issue every launch of a step from the host instead of replaying a hipGraph
 void fused_read_knobs(ocn_model* m) {
   auto env = [](const char* n, int def) { const char* e = getenv(n); return e ? atoi(e) : def; };
   m->knob_fused_xt = env("OCNHIP_FUSED_XT", 0);
   m->knob_no_dma = env("OCNHIP_NO_LDS_DMA", 0);
   m->knob_no_tracer3 = env("OCNHIP_NO_TRACER3", 0);
+  m->knob_graph = env("OCNHIP_NO_GRAPH", 0) ? 0 : 1;   // whole-step hipGraphs of the general path (api.hip step_graphed)
   // default 0x20FF: every row at priority 3 until the middle of its flux stage, then only the last output row keeps 2
   // (256^3: 0.575 ms against 0.590 with the hardware's age order; ten codes tried, all within 0.575 - 0.613)
   { const char* e = getenv("OCNHIP_PRIO"); m->knob_prio = e ? (int)strtol(e, nullptr, 0) : 0x20FF; }

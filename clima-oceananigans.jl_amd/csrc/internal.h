@@ -116,7 +116,14 @@ struct ocn_model {
   bool pred_active = false;
   ocn_grid* own_grid = nullptr;   // private copy of the caller's grid when the advection scheme needs wider halos
   int knob_fused_xt = 0, knob_no_dma = 0, knob_no_tracer3 = 0, knob_prio = 0x20FF;   // fused_read_knobs(), at creation
+  // whole-step hipGraphs of the general path (api.hip step_graphed): one entry per distinct (dt, stepper state, buffer rotation)
+  struct StepGraph { uint64_t key; int seen; void* exec; };
+  std::vector<StepGraph> graphs;
+  int knob_graph = 1;        // OCNHIP_NO_GRAPH=1 clears it (model creation)
+  bool graph_off = false;    // a capture failed: this model steps launch by launch from then on
+  int64_t graph_replays = 0;
 };
+extern thread_local int g_ocn_capturing, g_ocn_capture_poison;   // a library call that cannot be captured sets the poison flag
 inline Field& pred_u(ocn_model* m) { return m->pred_active ? m->us : m->u; }
 inline Field& pred_v(ocn_model* m) { return m->pred_active ? m->vs : m->v; }
 inline Field& pred_w(ocn_model* m) { return m->pred_active ? m->ws : m->w; }

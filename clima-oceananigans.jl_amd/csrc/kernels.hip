@@ -241,7 +241,7 @@ void launch_tendencies(ocn_model* m, bool skip_momentum_advection, bool skip_tra
   if (skip_momentum_advection) { if (!launch_rest4(m)) ocn_launch(k_tend_uvw<ADV_NONE, W>, gr, b, s, g, ph, u, v, w, Gu, Gv, Gw); }  \
   else ocn_launch(k_tend_uvw<A, W>, gr, b, s, g, ph, u, v, w, Gu, Gv, Gw);      \
   for (int t = 0; t < m->nt; ++t) {                                             \
-    if (skip_tracer_advection) hipMemsetAsync(m->Gn[3 + t].d, 0, m->Gn[3 + t].n * sizeof(double), s);  /* advection AND closure flux come from the tiled tracer kernel; boundary fluxes are added below */ \
+    if (skip_tracer_advection) { if (!g_ocn_dry) hipMemsetAsync(m->Gn[3 + t].d, 0, m->Gn[3 + t].n * sizeof(double), s); }  /* advection AND closure flux come from the tiled tracer kernel; boundary fluxes are added below */ \
     else { TEND_TRACER(A, W, t) }                                               \
   }
 #define TEND_CASE(A)                \

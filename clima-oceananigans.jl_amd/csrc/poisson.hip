@@ -12,6 +12,13 @@
 // Fourier-x/y + tridiagonal-z algorithm: on a regular grid it solves exactly the same discrete system
 // as the reference's cosine-transform path (same operator, same zero-mean gauge), without a DCT.
 #include "internal.h"
+#ifndef OCN_HOST_EMU
+// transform launches are skipped while a step is replayed from a hipGraph (compat.h g_ocn_dry)
+#define dry_hipfftExecD2Z(...) (g_ocn_dry ? HIPFFT_SUCCESS : hipfftExecD2Z(__VA_ARGS__))
+#define dry_hipfftExecZ2D(...) (g_ocn_dry ? HIPFFT_SUCCESS : hipfftExecZ2D(__VA_ARGS__))
+#define dry_hipfftExecZ2Z(...) (g_ocn_dry ? HIPFFT_SUCCESS : hipfftExecZ2Z(__VA_ARGS__))
+#endif
+
 
 #ifndef OCN_HOST_EMU
 #include <rocblas/rocblas.h>
@@ -613,6 +620,10 @@ static void emu_x_c2r(const double2_* in, double* out, int Nx, int Nxh, size_t l
 static int walls_gemm(ocn_model* m, bool transB, int M, int N, int K, const double* A, int lda, long sA, const double* B,
                       int ldb, double* C, int ldc, long sC, int batch) {
 #ifndef OCN_HOST_EMU
+  if (g_ocn_capturing) {   // the BLAS call is kept out of stream capture: the step that wanted a graph is run again without one
+    g_ocn_capture_poison = 1;
+    return OCN_OK;
+  }
   const double one = 1.0, zero = 0.0;
   rocblas_status st = rocblas_dgemm_strided_batched(
       (rocblas_handle)m->solver->blas, rocblas_operation_none, transB ? rocblas_operation_transpose : rocblas_operation_none,
@@ -725,7 +736,7 @@ static int run_walls(ocn_model* m) {
     }
     if (xper) {
 #ifndef OCN_HOST_EMU
-      if (hipfftExecD2Z(s->wxf, real, (hipfftDoubleComplex*)cur) != HIPFFT_SUCCESS) {
+      if (dry_hipfftExecD2Z(s->wxf, real, (hipfftDoubleComplex*)cur) != HIPFFT_SUCCESS) {
         ocn_set_error(m->ctx, "hipfftExecD2Z failed");
         return OCN_EHIP;
       }
@@ -751,7 +762,7 @@ static int run_walls(ocn_model* m) {
     } else {
       if (zper) {
 #ifndef OCN_HOST_EMU
-        if (hipfftExecZ2Z(s->wz, (hipfftDoubleComplex*)cur, (hipfftDoubleComplex*)cur, HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
+        if (dry_hipfftExecZ2Z(s->wz, (hipfftDoubleComplex*)cur, (hipfftDoubleComplex*)cur, HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
           ocn_set_error(m->ctx, "hipfftExecZ2Z failed");
           return OCN_EHIP;
         }
@@ -768,7 +779,7 @@ static int run_walls(ocn_model* m) {
                  (const double*)s->ly, (const double*)(zper ? s->lz : nullptr), norm, cur);
       if (zper) {
 #ifndef OCN_HOST_EMU
-        if (hipfftExecZ2Z(s->wz, (hipfftDoubleComplex*)cur, (hipfftDoubleComplex*)cur, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) {
+        if (dry_hipfftExecZ2Z(s->wz, (hipfftDoubleComplex*)cur, (hipfftDoubleComplex*)cur, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) {
           ocn_set_error(m->ctx, "hipfftExecZ2Z failed");
           return OCN_EHIP;
         }
@@ -796,7 +807,7 @@ static int run_walls(ocn_model* m) {
     real = more ? s->ra : s->rhs;
     if (xper) {
 #ifndef OCN_HOST_EMU
-      if (hipfftExecZ2D(s->wxi, (hipfftDoubleComplex*)cur, real) != HIPFFT_SUCCESS) {
+      if (dry_hipfftExecZ2D(s->wxi, (hipfftDoubleComplex*)cur, real) != HIPFFT_SUCCESS) {
         ocn_set_error(m->ctx, "hipfftExecZ2D failed");
         return OCN_EHIP;
       }
@@ -890,7 +901,7 @@ static int yslab_create(ocn_model* m, PoissonSolver* s) {
 static int yslab_yfft(ocn_model* m, int sign) {
   PoissonSolver* s = m->solver;
 #ifndef OCN_HOST_EMU
-  if (hipfftExecZ2Z(s->yfft, (hipfftDoubleComplex*)s->yT, (hipfftDoubleComplex*)s->yT, sign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD) !=
+  if (dry_hipfftExecZ2Z(s->yfft, (hipfftDoubleComplex*)s->yT, (hipfftDoubleComplex*)s->yT, sign < 0 ? HIPFFT_FORWARD : HIPFFT_BACKWARD) !=
       HIPFFT_SUCCESS) {
     ocn_set_error(m->ctx, "hipfftExecZ2Z failed");
     return OCN_EHIP;
@@ -915,7 +926,7 @@ static int run_yslab(ocn_model* m) {
   {
     ProfScope ps(m->ctx, "fft_forward");
 #ifndef OCN_HOST_EMU
-    if (hipfftExecD2Z(s->wxf, s->rhs, (hipfftDoubleComplex*)s->spec) != HIPFFT_SUCCESS) {
+    if (dry_hipfftExecD2Z(s->wxf, s->rhs, (hipfftDoubleComplex*)s->spec) != HIPFFT_SUCCESS) {
       ocn_set_error(m->ctx, "hipfftExecD2Z failed");
       return OCN_EHIP;
     }
@@ -945,7 +956,7 @@ static int run_yslab(ocn_model* m) {
     ProfScope ps(m->ctx, "fft_backward");
     ocn_launch(k_yslab_pack, gp, b, st, Nxh, Nyl, Nz, w, R, s->spec, s->yrecv, 1);
 #ifndef OCN_HOST_EMU
-    if (hipfftExecZ2D(s->wxi, (hipfftDoubleComplex*)s->spec, s->rhs) != HIPFFT_SUCCESS) {
+    if (dry_hipfftExecZ2D(s->wxi, (hipfftDoubleComplex*)s->spec, s->rhs) != HIPFFT_SUCCESS) {
       ocn_set_error(m->ctx, "hipfftExecZ2D failed");
       return OCN_EHIP;
     }
@@ -964,7 +975,7 @@ static int run_solver(ocn_model* m) {
   {
     ProfScope ps(m->ctx, "fft_forward");
 #ifndef OCN_HOST_EMU
-    if (hipfftExecD2Z(s->fwd, s->rhs, (hipfftDoubleComplex*)s->spec) != HIPFFT_SUCCESS) {
+    if (dry_hipfftExecD2Z(s->fwd, s->rhs, (hipfftDoubleComplex*)s->spec) != HIPFFT_SUCCESS) {
       ocn_set_error(m->ctx, "hipfftExecD2Z failed");
       return OCN_EHIP;
     }
@@ -992,7 +1003,7 @@ static int run_solver(ocn_model* m) {
     {
       ProfScope ps(m->ctx, "spectral_solve");
 #ifndef OCN_HOST_EMU
-      if (hipfftExecZ2Z(s->zplan, (hipfftDoubleComplex*)s->tb, (hipfftDoubleComplex*)s->tb, HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
+      if (dry_hipfftExecZ2Z(s->zplan, (hipfftDoubleComplex*)s->tb, (hipfftDoubleComplex*)s->tb, HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
         ocn_set_error(m->ctx, "hipfftExecZ2Z failed");
         return OCN_EHIP;
       }
@@ -1004,7 +1015,7 @@ static int run_solver(ocn_model* m) {
       ocn_launch(k_scale_spectrum_slab, gr, b, st, s->Nxh, s->Nyl, s->Nzg, s->rank * s->Nyl, (const double*)s->lx,
                  (const double*)s->ly, (const double*)s->lz, norm, s->tb);
 #ifndef OCN_HOST_EMU
-      if (hipfftExecZ2Z(s->zplan, (hipfftDoubleComplex*)s->tb, (hipfftDoubleComplex*)s->tb, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) {
+      if (dry_hipfftExecZ2Z(s->zplan, (hipfftDoubleComplex*)s->tb, (hipfftDoubleComplex*)s->tb, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) {
         ocn_set_error(m->ctx, "hipfftExecZ2Z failed");
         return OCN_EHIP;
       }
@@ -1039,7 +1050,7 @@ static int run_solver(ocn_model* m) {
   {
     ProfScope ps(m->ctx, "fft_backward");
 #ifndef OCN_HOST_EMU
-    if (hipfftExecZ2D(s->inv, (hipfftDoubleComplex*)s->spec, s->rhs) != HIPFFT_SUCCESS) {
+    if (dry_hipfftExecZ2D(s->inv, (hipfftDoubleComplex*)s->spec, s->rhs) != HIPFFT_SUCCESS) {
       ocn_set_error(m->ctx, "hipfftExecZ2D failed");
       return OCN_EHIP;
     }
@@ -1097,7 +1108,7 @@ int poisson_run_from_predictor(ocn_model* m, double dt) {
     ProfScope ps(m->ctx, "fft_backward");
     yfft_run(m->ctx, s->tw, s->spec, s->Nxh, s->Ny, s->Nz, 1);
 #ifndef OCN_HOST_EMU
-    if (hipfftExecZ2D(s->xinv, (hipfftDoubleComplex*)s->spec, s->rhs) != HIPFFT_SUCCESS) {
+    if (dry_hipfftExecZ2D(s->xinv, (hipfftDoubleComplex*)s->spec, s->rhs) != HIPFFT_SUCCESS) {
       ocn_set_error(m->ctx, "hipfftExecZ2D (x inverse) failed");
       return OCN_EHIP;
     }
