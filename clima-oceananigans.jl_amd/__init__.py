@@ -10,7 +10,7 @@ All numerical work happens in libocnhip.so (hand-written HIP for gfx950 + hipFFT
 from .api import (Context, RectilinearGrid, NonhydrostaticModel, Periodic, Bounded, Flat, Center, Face,  # noqa: F401
                   WENO5, NoAdvection, CenteredSecondOrder, CenteredFourthOrder, UpwindBiasedFifthOrder, UpwindBiasedFirstOrder, UpwindBiasedThirdOrder, ScalarDiffusivity,
                   AnisotropicMinimumDissipation, FPlane, BuoyancyTracer, SeawaterBuoyancy,
-                  FluxBC, ValueBC, GradientBC, time_step, set_model, update_state, OcnError)
+                  FluxBC, ValueBC, GradientBC, Field, CenterField, time_step, set_model, update_state, OcnError)
 from . import _lib  # noqa: F401
 
 __all__ = ["Context", "RectilinearGrid", "NonhydrostaticModel", "time_step", "set_model"]

@@ -39,7 +39,8 @@ class ModelDesc(C.Structure):
     _fields_ = [("advection", C.c_int32), ("stepper", C.c_int32), ("chi", C.c_double),
                 ("n_tracers", C.c_int32), ("closure", C.c_int32), ("nu", C.c_double),
                 ("kappa", C.c_double * MAX_TRACERS), ("amd_Cnu", C.c_double),
-                ("amd_Ckappa", C.c_double * MAX_TRACERS), ("coriolis_fplane", C.c_int32), ("f", C.c_double),
+                ("amd_Ckappa", C.c_double * MAX_TRACERS), ("amd_Cb", C.c_double), ("amd_has_Cb", C.c_int32),
+                ("coriolis_fplane", C.c_int32), ("f", C.c_double),
                 ("buoyancy", C.c_int32), ("b_index", C.c_int32), ("T_index", C.c_int32), ("S_index", C.c_int32),
                 ("g", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
                 ("bcs", (BC * 6) * (3 + MAX_TRACERS))]
@@ -50,6 +51,9 @@ class OcnError(RuntimeError):
 
 
 _lib = None
+
+
+ABI_VERSION = 2   # OCN_ABI_VERSION of include/ocnhip.h
 
 
 def lib_path():
@@ -81,6 +85,13 @@ def load():
         "ocn_model_halo": (I, [P, C.POINTER(C.c_int32 * 3)]),
         "ocn_model_path": (I, [P, C.c_char_p, C.c_size_t]),
         "ocn_model_graph_replays": (I, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+        "ocn_field_create": (I, [P, I, I, I, C.POINTER(P)]),
+        "ocn_field_destroy": (None, [P]),
+        "ocn_field_parent_shape": (I, [P, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32 * 3)]),
+        "ocn_field_parent_layout": (I, [P, C.POINTER(C.c_int64 * 3), C.POINTER(C.c_int64)]),
+        "ocn_field_parent_ptr": (P, [P]),
+        "ocn_field_parent_upload": (I, [P, PD]),
+        "ocn_field_parent_download": (I, [P, PD]),
         "ocn_field_shape": (I, [P, I, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32 * 3)]),
         "ocn_field_device_ptr": (P, [P, I]),
         "ocn_field_layout": (I, [P, I, C.POINTER(C.c_int64 * 3), C.POINTER(C.c_int64)]),
@@ -114,6 +125,8 @@ def load():
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = the library does not export what the header declares
         fn.restype, fn.argtypes = res, args
+    if L.ocn_abi_version() != ABI_VERSION:   # the structs above are laid out for exactly this version of include/ocnhip.h
+        raise OcnError(f"{path} reports ABI version {L.ocn_abi_version()}, this binding is written for {ABI_VERSION}: rebuild")
     _lib = L
     _lib._signatures = sig
     return _lib

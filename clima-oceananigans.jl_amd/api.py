@@ -58,9 +58,12 @@ class ScalarDiffusivity:
 
 
 class AnisotropicMinimumDissipation:
-    def __init__(self, C=1 / 12, Cnu=None, Ckappa=None):
+    """``AnisotropicMinimumDissipation(; C=1/12, Cν, Cκ, Cb=nothing)`` (anisotropic_minimum_dissipation.jl:110-119)."""
+
+    def __init__(self, C=1 / 12, Cnu=None, Ckappa=None, Cb=None):
         self.Cnu = C if Cnu is None else Cnu
         self.Ckappa = C if Ckappa is None else Ckappa
+        self.Cb = Cb
 
 
 class FPlane:
@@ -252,6 +255,53 @@ class FieldView:
         return tuple(st), org.value
 
 
+class Field:
+    """``Field{LX, LY, LZ}(grid)`` / ``CenterField(grid)``: a stand-alone, zero-filled parent array on the device, halos
+    included (Fields/field.jl:16-30, Grids/new_data.jl:16-61).  ``loc``: three of ``Center`` / ``Face``."""
+
+    def __init__(self, loc, grid):
+        self.grid, self.loc = grid, tuple(loc)
+        self.lib, self.ctx = grid.ctx.lib, grid.ctx
+        self.h = C.c_void_p()
+        code = [L.FACE if l in (Face, "Face") else L.CENTER for l in self.loc]
+        check(self.lib.ocn_field_create(grid.h, code[0], code[1], code[2], C.byref(self.h)), self.ctx.h)
+        t, i, h = (C.c_int32 * 3)(), (C.c_int32 * 3)(), (C.c_int32 * 3)()
+        check(self.lib.ocn_field_parent_shape(self.h, C.byref(t), C.byref(i), C.byref(h)), self.ctx.h)
+        self.total, self.size, self.halo = tuple(t), tuple(i), tuple(h)
+
+    def parent(self):
+        a = np.zeros(self.total, dtype=np.float64, order="F")
+        check(self.lib.ocn_field_parent_download(self.h, a.ctypes.data_as(C.POINTER(C.c_double))), self.ctx.h)
+        return a
+
+    def set_parent(self, a):
+        a = np.asfortranarray(a, dtype=np.float64)
+        assert a.shape == self.total
+        check(self.lib.ocn_field_parent_upload(self.h, a.ctypes.data_as(C.POINTER(C.c_double))), self.ctx.h)
+
+    @property
+    def device_ptr(self):
+        return self.lib.ocn_field_parent_ptr(self.h)
+
+    @property
+    def layout(self):
+        st, org = (C.c_int64 * 3)(), C.c_int64()
+        check(self.lib.ocn_field_parent_layout(self.h, C.byref(st), C.byref(org)), self.ctx.h)
+        return tuple(st), org.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.ocn_field_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def CenterField(grid):
+    return Field((Center, Center, Center), grid)
+
+
 class NonhydrostaticModel:
     """``NonhydrostaticModel(; grid, advection, buoyancy, coriolis, closure, boundary_conditions, tracers,
     timestepper)`` (Models/NonhydrostaticModels/nonhydrostatic_model.jl:102-203)."""
@@ -282,6 +332,8 @@ class NonhydrostaticModel:
                 d.kappa[i] = float(closure.kappa[n] if isinstance(closure.kappa, dict) else closure.kappa)
         elif isinstance(closure, AnisotropicMinimumDissipation):
             d.closure, d.amd_Cnu = L.CLOSURE_AMD, float(closure.Cnu)
+            if closure.Cb is not None:
+                d.amd_Cb, d.amd_has_Cb = float(closure.Cb), 1
             for i, n in enumerate(self.tracer_names):
                 d.amd_Ckappa[i] = float(closure.Ckappa[n] if isinstance(closure.Ckappa, dict) else closure.Ckappa)
         else:

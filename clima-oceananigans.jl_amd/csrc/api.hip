@@ -336,8 +336,7 @@ void ocn_grid_destroy(ocn_grid* g) {
 double* Field::interior() const { return d + Hx + Hy * sy + Hz * sz; }
 static bool field_dense(const Field& f) { return f.P[0] == f.T[0] && f.P[1] == f.T[1] && f.P[2] == f.T[2]; }
 
-static int field_alloc(ocn_model* m, Field& f, int lx, int ly, int lz) {
-  ocn_grid* g = m->g;
+static int field_alloc(ocn_ctx* ctx, ocn_grid* g, Field& f, int lx, int ly, int lz) {
   f.loc[0] = lx; f.loc[1] = ly; f.loc[2] = lz;
   for (int d = 0; d < 3; ++d) {
     int loc = f.loc[d];
@@ -357,12 +356,13 @@ static int field_alloc(ocn_model* m, Field& f, int lx, int ly, int lz) {
   f.sy = f.P[0];
   f.sz = (long)f.P[0] * f.P[1];
   f.Hx = g->PH[0]; f.Hy = g->PH[1]; f.Hz = g->PH[2];
-  OCN_HIP_CHECK(m->ctx, hipMalloc((void**)&f.d, f.n * sizeof(double)));
-  OCN_HIP_CHECK(m->ctx, hipMemsetAsync(f.d, 0, f.n * sizeof(double), m->ctx->stream));
+  OCN_HIP_CHECK(ctx, hipMalloc((void**)&f.d, f.n * sizeof(double)));
+  OCN_HIP_CHECK(ctx, hipMemsetAsync(f.d, 0, f.n * sizeof(double), ctx->stream));
   f.present = true;
   for (int s = 0; s < 6; ++s) f.bc[s] = BCdev{OCN_BC_NONE, 0.0, nullptr};
   return OCN_OK;
 }
+static int field_alloc(ocn_model* m, Field& f, int lx, int ly, int lz) { return field_alloc(m->ctx, m->g, f, lx, ly, lz); }
 
 // default boundary conditions (BoundaryConditions/field_boundary_conditions.jl:13-35)
 static void default_bcs(ocn_model* m, Field& f, bool auxiliary) {
@@ -756,6 +756,14 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
     ocn_set_error(ctx, "AnisotropicMinimumDissipation on a grid with a Flat direction is outside the path");
     return OCN_EUNSUPPORTED;
   }
+  if (desc->closure == OCN_CLOSURE_AMD && desc->amd_has_Cb) {
+    auto ok = [&](int i) { return i >= 0 && i < desc->n_tracers; };
+    if ((desc->buoyancy == OCN_BUOYANCY_TRACER && !ok(desc->b_index)) ||
+        (desc->buoyancy == OCN_BUOYANCY_LINEAR_TS && !(ok(desc->T_index) && ok(desc->S_index)))) {
+      ocn_set_error(ctx, "AMD buoyancy modification needs the buoyancy model's tracers");
+      return OCN_EINVAL;
+    }
+  }
   // halo inflation (nonhydrostatic_model.jl:140-148; Advection.jl:40)
   static const int buffer[8] = {0, 0, 1, 2, 2, 2, 1, 1};   // boundary_buffer of NONE, C2, C4, U5, WENO5 (Z, JS), U1, U3
   // The reference builds a NEW grid with the wider halo (with_halo); so does this: the caller's grid, and any
@@ -988,36 +996,110 @@ int ocn_field_layout(const ocn_model* m, int field_id, int64_t strides[3], int64
   return OCN_OK;
 }
 
+static int parent_upload(ocn_ctx* ctx, Field* f, const double* host) {
+  OCN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (field_dense(*f)) {
+    OCN_HIP_CHECK(ctx, hipMemcpy(f->d, host, f->n * sizeof(double), hipMemcpyHostToDevice));
+    return OCN_OK;
+  }
+  std::vector<double> phys(f->n);
+  OCN_HIP_CHECK(ctx, hipMemcpy(phys.data(), f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
+  const int lo[3] = {0, 0, 0};
+  host_scatter(*f, host, lo, f->T, phys);
+  OCN_HIP_CHECK(ctx, hipMemcpy(f->d, phys.data(), f->n * sizeof(double), hipMemcpyHostToDevice));
+  return OCN_OK;
+}
+static int parent_download(ocn_ctx* ctx, const Field* f, double* host) {
+  OCN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (field_dense(*f)) {
+    OCN_HIP_CHECK(ctx, hipMemcpy(host, f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
+    return OCN_OK;
+  }
+  std::vector<double> phys(f->n);
+  OCN_HIP_CHECK(ctx, hipMemcpy(phys.data(), f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
+  const int lo[3] = {0, 0, 0};
+  host_gather(*f, phys, lo, f->T, host);
+  return OCN_OK;
+}
+
 int ocn_field_upload(ocn_model* m, int field_id, const double* host) {
   if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF && materialize_gn(m)) return OCN_EHIP;
   Field* f = model_field(m, field_id);
   if (!f || !host) return OCN_EINVAL;
-  OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));
-  if (field_dense(*f)) {
-    OCN_HIP_CHECK(m->ctx, hipMemcpy(f->d, host, f->n * sizeof(double), hipMemcpyHostToDevice));
-    return OCN_OK;
-  }
-  std::vector<double> phys(f->n);
-  OCN_HIP_CHECK(m->ctx, hipMemcpy(phys.data(), f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
-  const int lo[3] = {0, 0, 0};
-  host_scatter(*f, host, lo, f->T, phys);
-  OCN_HIP_CHECK(m->ctx, hipMemcpy(f->d, phys.data(), f->n * sizeof(double), hipMemcpyHostToDevice));
-  return OCN_OK;
+  return parent_upload(m->ctx, f, host);
 }
 
 int ocn_field_download(const ocn_model* m, int field_id, double* host) {
   Field* f = model_field(const_cast<ocn_model*>(m), field_id);
   if (!f || !host) return OCN_EINVAL;
-  OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));
-  if (field_dense(*f)) {
-    OCN_HIP_CHECK(m->ctx, hipMemcpy(host, f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
-    return OCN_OK;
+  return parent_download(m->ctx, f, host);
+}
+
+// ---- stand-alone fields: Field{LX, LY, LZ}(grid) / zeros(FT, arch, N...) of the reference (Fields/field.jl:16-30,
+// Grids/new_data.jl:16-61, Grids/zeros.jl:7): a zero-filled parent array, halos included, laid out exactly as the
+// model's own fields on that grid.  The shim's arch_array / CenterField() allocate through these.
+struct ocn_field {
+  ocn_grid* g;
+  Field f;
+};
+
+int ocn_field_create(ocn_grid* g, int locx, int locy, int locz, ocn_field** out) {
+  if (!g || !out) return OCN_EINVAL;
+  const int loc[3] = {locx, locy, locz};
+  for (int d = 0; d < 3; ++d)
+    if (loc[d] != OCN_CENTER && loc[d] != OCN_FACE) {
+      ocn_set_error(g->ctx, "ocn_field_create: location %d along dimension %d is neither OCN_CENTER nor OCN_FACE", loc[d], d);
+      return OCN_EINVAL;
+    }
+  ocn_field* h = new ocn_field;
+  h->g = g;
+  int rc = field_alloc(g->ctx, g, h->f, locx, locy, locz);
+  if (rc) {
+    delete h;
+    return rc;
   }
-  std::vector<double> phys(f->n);
-  OCN_HIP_CHECK(m->ctx, hipMemcpy(phys.data(), f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
-  const int lo[3] = {0, 0, 0};
-  host_gather(*f, phys, lo, f->T, host);
+  *out = h;
   return OCN_OK;
+}
+
+void ocn_field_destroy(ocn_field* f) {
+  if (!f) return;
+  hipStreamSynchronize(f->g->ctx->stream);
+  hipFree(f->f.d);
+  delete f;
+}
+
+int ocn_field_parent_shape(const ocn_field* f, int32_t total[3], int32_t interior[3], int32_t halo[3]) {
+  if (!f) return OCN_EINVAL;
+  for (int d = 0; d < 3; ++d) {
+    if (total) total[d] = f->f.T[d];
+    if (halo) halo[d] = f->g->H[d];
+    if (interior) interior[d] = f->g->N[d] + ((f->f.loc[d] == OCN_FACE && f->g->topo[d] == OCN_BOUNDED) ? 1 : 0);
+  }
+  return OCN_OK;
+}
+
+int ocn_field_parent_layout(const ocn_field* f, int64_t strides[3], int64_t* origin) {
+  if (!f) return OCN_EINVAL;
+  if (strides) {
+    strides[0] = 1;
+    strides[1] = f->f.sy;
+    strides[2] = f->f.sz;
+  }
+  if (origin) *origin = f->f.off[0] + (int64_t)f->f.off[1] * f->f.sy;
+  return OCN_OK;
+}
+
+void* ocn_field_parent_ptr(ocn_field* f) { return f ? f->f.d : nullptr; }
+
+int ocn_field_parent_upload(ocn_field* f, const double* host) {
+  if (!f || !host) return OCN_EINVAL;
+  return parent_upload(f->g->ctx, &f->f, host);
+}
+
+int ocn_field_parent_download(const ocn_field* f, double* host) {
+  if (!f || !host) return OCN_EINVAL;
+  return parent_download(f->g->ctx, &f->f, host);
 }
 
 int ocn_field_set_interior(ocn_model* m, int field_id, const double* host) {

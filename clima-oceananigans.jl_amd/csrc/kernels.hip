@@ -718,6 +718,10 @@ struct AmdTracers {
   double* kap[OCN_MAX_TRACERS];
   double Ck[OCN_MAX_TRACERS];
   int n;
+  // buoyancy modification of nu_e (:142-154,299-312): b = q[b0] (BuoyancyTracer) or Cg (cb0 q[b0] - cb1 q[b1])
+  // (LinearEquationOfState: g (alpha T - beta S)); has_Cb = 0 leaves the term out (Cb = nothing)
+  int has_Cb, lin, b0, b1;
+  double Cb, Cg, cb0, cb1;
 };
 
 // nu_e and every kappa_e in one pass: the interpolated velocity gradients are shared by all predictors
@@ -769,7 +773,22 @@ __global__ void k_amd_all(AmdCtx a, double Cnu, double* __restrict__ nu, AmdTrac
                       2 * xz_dzu * yz_dzv * amd_Ixy(a, c, k, S12) +
                       2 * dzw * amd_Ixz(a, c, k, [&](long p, int kk) { return ndzu(p, kk) * S13(p, kk); }) +
                       2 * dzw * amd_Iyz(a, c, k, [&](long p, int kk) { return ndzv(p, kk) * S23(p, kk); });
-    nus = -Cnu * d2 * (r1 + r2 + r3) / q;
+    double Cb_zeta = 0.0;
+    if (T.has_Cb) {
+      const double* __restrict__ qa = T.q[T.b0];
+      const double* __restrict__ qb = T.q[T.b1];
+      // the reference's association: g * (alpha T - beta S)  (linear_equation_of_state.jl:69-71); lin = 0: b itself
+      auto bp = [&](long p) { return T.lin ? T.Cg * (T.cb0 * qa[p] - T.cb1 * qb[p]) : qa[p]; };
+      const double bc = bp(c);
+      const double bxm = (bc - bp(c - 1)) * a.rdx, bxp = (bp(c + 1) - bc) * a.rdx;            // d_x b at fcc i, i+1
+      const double bym = (bc - bp(c - sy)) * a.rdy, byp = (bp(c + sy) - bc) * a.rdy;          // d_y b at cfc j, j+1
+      const double bzm = (bc - bp(c - sz)) * a.rdzf[k + a.Hz], bzp = (bp(c + sz) - bc) * a.rdzf[k + 1 + a.Hz];   // ccf k, k+1
+      const double wx_bx = xz_dxw * a.Dx * (0.5 * (bxm + bxp));
+      const double wy_by = yz_dyw * a.Dy * (0.5 * (bym + byp));
+      const double wz_bz = dzw * amd_Dz(a, k) * (0.5 * (bzm + bzp));
+      Cb_zeta = T.Cb * (wx_bx + wy_by + wz_bz) / amd_Dz(a, k);
+    }
+    nus = -Cnu * d2 * ((r1 + r2 + r3) - Cb_zeta) / q;
   }
   nu[c] = fmax(0.0, nus);
   if (T.n == 0) return;
@@ -845,6 +864,21 @@ void launch_amd(ocn_model* m) {
     T.q[t] = m->tr[t].interior();
     T.kap[t] = m->kappa_e[t].interior();
     T.Ck[t] = m->d.amd_Ckappa[t];
+  }
+  T.has_Cb = T.lin = 0; T.b0 = T.b1 = 0; T.Cb = T.Cg = T.cb0 = T.cb1 = 0.0;
+  if (m->d.amd_has_Cb && m->d.buoyancy != OCN_BUOYANCY_NONE) {
+    T.has_Cb = 1;
+    T.Cb = m->d.amd_Cb;
+    if (m->d.buoyancy == OCN_BUOYANCY_TRACER) {
+      T.b0 = T.b1 = m->d.b_index;
+    } else {
+      T.lin = 1;
+      T.b0 = m->d.T_index;
+      T.b1 = m->d.S_index;
+      T.Cg = m->d.g;
+      T.cb0 = m->d.alpha;
+      T.cb1 = m->d.beta;
+    }
   }
   ocn_launch(k_amd_all, gr, b, m->ctx->stream, a, m->d.amd_Cnu, m->nu_e.interior(), T);
 }

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OCN_ABI_VERSION 1
+#define OCN_ABI_VERSION 2
 
 /* error codes */
 enum {
@@ -90,6 +90,7 @@ enum {
 typedef struct ocn_ctx ocn_ctx;
 typedef struct ocn_grid ocn_grid;
 typedef struct ocn_model ocn_model;
+typedef struct ocn_field ocn_field;   /* a stand-alone field on a grid (ocn_field_create) */
 
 /* RectilinearGrid(size=, halo=, topology=, x=, y=, z=)  -- Grids/rectilinear_grid.jl:249-279.
  * x and y must be regular (extent given); z is regular when z_faces == NULL, otherwise z_faces
@@ -129,6 +130,8 @@ typedef struct ocn_model_desc {
   double kappa[OCN_MAX_TRACERS]; /* ScalarDiffusivity kappa per tracer */
   double amd_Cnu;      /* AMD Poincare constants                      */
   double amd_Ckappa[OCN_MAX_TRACERS];
+  double amd_Cb;       /* AMD buoyancy-modification multiplier (anisotropic_minimum_dissipation.jl:142-154,299-312) */
+  int32_t amd_has_Cb;  /* 0: Cb = nothing (the default; the term is skipped), 1: amd_Cb is used */
   int32_t coriolis_fplane; /* 0 / 1 */
   double f;            /* FPlane f (Coriolis/f_plane.jl:42-44)         */
   int32_t buoyancy;    /* OCN_BUOYANCY_*                              */
@@ -162,6 +165,18 @@ int ocn_model_path(const ocn_model* m, char* buf, size_t n);
 int ocn_model_graph_replays(const ocn_model* m, int64_t* replays, int32_t* active);
 /* halo actually used (the model inflates it like nonhydrostatic_model.jl:140-148) */
 int ocn_model_halo(const ocn_model* m, int32_t H[3]);
+
+/* ---- stand-alone fields: Field{LX,LY,LZ}(grid) / zeros(FT, arch, N...) (Fields/field.jl:16-30, Grids/new_data.jl:16-61,
+ * Grids/zeros.jl:7).  A zero-filled parent array, halos included, with the layout a model's own field of that location has
+ * on this grid (ocn_field_parent_layout reports strides / origin; dense column-major on (Periodic, Periodic, *) grids).
+ * loc*: OCN_CENTER / OCN_FACE.  The grid must outlive the field. */
+int ocn_field_create(ocn_grid* g, int locx, int locy, int locz, ocn_field** out);
+void ocn_field_destroy(ocn_field* f);
+int ocn_field_parent_shape(const ocn_field* f, int32_t total[3], int32_t interior[3], int32_t halo[3]);
+int ocn_field_parent_layout(const ocn_field* f, int64_t strides[3], int64_t* origin);
+void* ocn_field_parent_ptr(ocn_field* f);                                  /* Julia unsafe_wrap / torch from_blob */
+int ocn_field_parent_upload(ocn_field* f, const double* host_parent);      /* logical parent array, column-major  */
+int ocn_field_parent_download(const ocn_field* f, double* host_parent);
 
 /* ---- fields: parent arrays incl. halos (Fields/field.jl:16-30; OutputWriters/fetch_output.jl:26) - */
 int ocn_field_shape(const ocn_model* m, int field_id, int32_t total[3], int32_t interior[3], int32_t halo[3]);

@@ -4,7 +4,7 @@ Restates ``TurbulenceClosures/turbulence_closure_implementations/anisotropic_min
 (predictors), ``:213-226`` (filter widths: twice the *centre* spacing evaluated at the calling index, at
 every location), ``:229-340`` ("the 30 terms") and ``velocity_tracer_gradients.jl:126-250`` (normalised
 gradients; note ``norm_dx_u = dx_u`` etc. are NOT normalised, and ``cy_uy`` uses ``I_xz`` on ``norm_dy_w``
-``:326`` -- reproduced as written).  ``Cb = nothing`` (no buoyancy modification).
+``:326`` -- reproduced as written).  The buoyancy modification ``Cb`` follows ``:142-154,297-312``.
 """
 import numpy as np
 
@@ -77,8 +77,18 @@ def calculate_amd_diffusivities(cl):
     d2 = 3 / (1 / Dx(Z3) ** 2 + 1 / Dy(Z3) ** 2 + 1 / Dz(Z3) ** 2)
     q = q_term(Z3)
     r = r_term(Z3)
+    Cb_zeta = 0.0
+    if getattr(c, "Cb", None) is not None and m.buoyancy is not None:
+        # Cb_norm_w_i_b_i (:299-312) / Delta_z: the buoyancy perturbation's gradients interpolated to ccc, against the
+        # w gradients normalised as above
+        bfun = m.buoyancy.perturbation(m.tracers)   # offset -> array, like every other operand here
+        o = Z3
+        wx_bx = Ixz(n_dxw)(o) * Dx(o) * o_.iC(0, o_.ddF(0, bfun))(o)
+        wy_by = Iyz(n_dyw)(o) * Dy(o) * o_.iC(1, o_.ddF(1, bfun))(o)
+        wz_bz = n_dzw(o) * Dz(o) * o_.iC(2, o_.ddF(2, bfun))(o)
+        Cb_zeta = c.Cb * (wx_bx + wy_by + wz_bz) / Dz(o)
     with np.errstate(divide="ignore", invalid="ignore"):
-        nu = np.where(q == 0, 0.0, -c.Cnu * d2 * r / q)
+        nu = np.where(q == 0, 0.0, -c.Cnu * d2 * (r - Cb_zeta) / q)
     cl.nu_e()[...] = np.maximum(0.0, nu)
 
     for n, cf in m.tracers.items():

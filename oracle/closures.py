@@ -25,12 +25,13 @@ class ScalarDiffusivity:
 
 
 class AnisotropicMinimumDissipation:
-    """anisotropic_minimum_dissipation.jl:51-59 (C = 1/12, Cb = nothing)."""
+    """anisotropic_minimum_dissipation.jl:51-59,110-119 (C = 1/12; Cb = nothing switches the buoyancy modification off)."""
     required_halo = 1
 
-    def __init__(self, C=1 / 12, Cnu=None, Ckappa=None):
+    def __init__(self, C=1 / 12, Cnu=None, Ckappa=None, Cb=None):
         self.Cnu = C if Cnu is None else Cnu
         self.Ckappa = C if Ckappa is None else Ckappa
+        self.Cb = Cb
 
 
 class Closure:

@@ -81,6 +81,14 @@ CASES = {
                             coriolis=1e-2, buoyancy="TS",
                             bcs={"u": {"top": ("flux", -1e-2)}, "T": {"top": ("flux", 2e-3), "bottom": ("gradient", 0.01)},
                                  "S": {"top": ("flux", -1e-3)}}),
+    # AMD with the buoyancy modification term (Cb = 1 of Abkar et al.; anisotropic_minimum_dissipation.jl:142-154,299-312)
+    "ppb_amd_cb_seawater": dict(size=(8, 7, 8), topo=(P, P, B), xy=((0, 2), (0, 2)),
+                                zfaces=[-1.0, -0.8, -0.62, -0.46, -0.32, -0.2, -0.1, -0.04, 0.0],
+                                adv="WENO5", stepper="RK3", steps=2, dt=2e-3, tracers=("T", "S"), closure="amd", amd_Cb=1.0,
+                                coriolis=1e-2, buoyancy="TS",
+                                bcs={"T": {"top": ("flux", 2e-3), "bottom": ("gradient", 0.01)}}),
+    "ppb_amd_cb_btracer": dict(size=(8, 6, 7), topo=(P, P, B), extent=(1, 1, 1), adv="C2", stepper="AB2", steps=2,
+                               dt=2e-3, tracers=("b",), closure="amd", amd_Cb=0.7, buoyancy="b"),
     "ppb_amd_regular_c2": dict(size=(8, 6, 7), topo=(P, P, B), extent=(1, 1, 1), adv="C2", stepper="AB2", steps=2,
                                dt=2e-3, tracers=("b",), closure="amd", buoyancy="b"),
     # Bounded / Flat x and y: walls, cosine-transform topologies, 2-D slices
@@ -159,7 +167,7 @@ def build(mod, cfg, rng_seed=1234):
     g = mod.RectilinearGrid(size=cfg["size"], topology=cfg["topo"], **kw)
     mk = {}
     if cfg.get("closure") == "amd":
-        mk["closure"] = mod.AnisotropicMinimumDissipation()
+        mk["closure"] = mod.AnisotropicMinimumDissipation(**({"Cb": cfg["amd_Cb"]} if "amd_Cb" in cfg else {}))
     elif cfg.get("closure"):
         mk["closure"] = mod.ScalarDiffusivity(nu=cfg["closure"][0], kappa=cfg["closure"][1])
     if cfg.get("coriolis"):

@@ -167,3 +167,49 @@ def test_model_reports_its_kernel_path(ocn, backend):
     assert "tiled advection" in ocn.NonhydrostaticModel(gb, advection=ocn.WENO5(), coriolis=ocn.FPlane(1e-4)).kernel_path
     gs = ocn.RectilinearGrid(size=(4, 10, 8), extent=(1, 1, 1), topology=(P, P, P))
     assert "fewer than 6 cells" in ocn.NonhydrostaticModel(gs, advection=ocn.WENO5()).kernel_path
+
+
+# ---- stand-alone fields (ocn_field_create: Field{LX,LY,LZ}(grid), Fields/field.jl:16-30, Grids/new_data.jl:16-61) ---------
+def _standalone_fields(ocn):
+    rng = np.random.default_rng(5)
+    for topo, N, H in [((P, P, P), (7, 6, 5), (3, 3, 3)), ((P, P, B), (8, 5, 6), (2, 1, 3)), ((B, B, B), (5, 6, 4), (1, 2, 1)),
+                       ((P, "Flat", B), (6, 7), (2, 2))]:
+        g = ocn.RectilinearGrid(size=N, extent=tuple(1.0 for _ in N), topology=topo, halo=H)
+        N3 = [g.Nx, g.Ny, g.Nz]
+        H3, it = [], 0
+        for t in topo:
+            H3.append(0 if t == "Flat" else H[it])
+            it += 0 if t == "Flat" else 1
+        for loc in [("Center",) * 3, ("Face", "Center", "Center"), ("Center", "Face", "Center"), ("Center", "Center", "Face"),
+                    ("Face", "Face", "Face")]:
+            f = ocn.Field(loc, g)
+            # total_size of new_data: N + 2H, one more for a Face location along a Bounded direction, N alone when Flat
+            want = tuple(N3[d] if topo[d] == "Flat" else N3[d] + 2 * H3[d] + (1 if loc[d] == "Face" and topo[d] == B else 0)
+                         for d in range(3))
+            assert f.total == want and f.halo == tuple(H3)
+            assert not f.parent().any()                       # zeros(FT, arch, N...)
+            a = rng.random(f.total)
+            f.set_parent(a)
+            assert np.array_equal(f.parent(), a)              # parent array incl. halos round-trips bit for bit
+            assert f.device_ptr
+            # the layout equals the layout of a model's own field of the same location on this grid
+            m = ocn.NonhydrostaticModel(g, advection=ocn.CenteredSecondOrder(), tracers=("c",))
+            if tuple(m.halo) == tuple(H3):
+                twin = {("Face", "Center", "Center"): m.u, ("Center", "Face", "Center"): m.v, ("Center", "Center", "Face"): m.w,
+                        ("Center",) * 3: m.tracers["c"]}.get(loc)
+                if twin is not None:
+                    assert twin.total == f.total and twin.layout == f.layout
+    import ctypes
+    h = ctypes.c_void_p()
+    assert ocn._lib.load().ocn_field_create(g.h, 0, 0, 7, ctypes.byref(h)) != 0     # a location that is neither Center nor Face
+
+
+def test_standalone_fields(ocn, backend):
+    if backend != "hostemu":
+        pytest.skip("host-emulation run")
+    _standalone_fields(ocn)
+
+
+@pytest.mark.gpu
+def test_standalone_fields_gpu(ocn):
+    _standalone_fields(ocn)

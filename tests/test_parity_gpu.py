@@ -322,8 +322,8 @@ def test_step_graph_replay_is_bitwise_the_launch_train(ocn, name, monkeypatch):
         res.append((fields_of(m, False), m.time, m.iteration, replays, active))
     (fa, ta, ia, ra, acta), (fb, tb, ib, rb, actb) = res
     assert rb == 0 and not actb
-    if name == "bbb_weno_walls":
-        assert ra == 0 and not acta      # poisoned capture: graphs switched off for this model
+    if "Bounded" in cfg["topo"][:2]:
+        assert ra == 0 and not acta      # poisoned capture (BLAS cosine transforms): graphs switched off for this model
     else:
         assert acta and ra >= 4
     assert ta == tb and ia == ib
