@@ -1017,6 +1017,7 @@ void fused_read_knobs(ocn_model* m) {
   m->knob_fused_xt = env("OCNHIP_FUSED_XT", 0);
   m->knob_no_dma = env("OCNHIP_NO_LDS_DMA", 0);
   m->knob_no_tracer3 = env("OCNHIP_NO_TRACER3", 0);
+  m->knob_xfft_team = env("OCNHIP_XFFT_TEAM", 0);
   m->knob_graph = env("OCNHIP_NO_GRAPH", 0) ? 0 : 1;   // whole-step hipGraphs of the general path (api.hip step_graphed)
   // default 0x20FF: every row at priority 3 until the middle of its flux stage, then only the last output row keeps 2
   // (256^3: 0.575 ms against 0.590 with the hardware's age order; ten codes tried, all within 0.575 - 0.613)

@@ -119,6 +119,7 @@ struct ocn_model {
   // whole-step hipGraphs of the general path (api.hip step_graphed): one entry per distinct (dt, stepper state, buffer rotation)
   struct StepGraph { uint64_t key; int seen; void* exec; };
   std::vector<StepGraph> graphs;
+  int knob_xfft_team = 0;    // OCNHIP_XFFT_TEAM=1: the fused rhs + x transform loads in team order (the older variant; tests)
   int knob_graph = 1;        // OCNHIP_NO_GRAPH=1 clears it (model creation)
   bool graph_off = false;    // a capture failed: this model steps launch by launch from then on
   int64_t graph_replays = 0;

@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(256) k_yfft(cd* __restrict__ a, int Nxh, int N
 // spectrum kx = 0..N/2 is written once.  One workgroup = C consecutive x-lines (flattened j + Ny k); here the
 // TRANSFORMED direction is the contiguous one, so the team index r runs fastest over the lanes: t = r' + RT * line
 // with r' = r (+ 16 h for N = 512).
-template <int N>
+template <int N, bool CO>
 __global__ void __launch_bounds__(256) k_xfft_rhs(GridDev g, const double* __restrict__ us, const double* __restrict__ vs,
                                                   const double* __restrict__ ws, double rdt, int zwrap,
                                                   cd* __restrict__ spec, const cd* __restrict__ tw) {
@@ -366,20 +366,51 @@ __global__ void __launch_bounds__(256) k_xfft_rhs(GridDev g, const double* __res
   const long L = (long)blockIdx.x * C + ln;         // line index j + Ny k
   const long nlines = (long)g.Ny * g.Nz;
   const bool ok = L < nlines;
-  const int k = ok ? (int)(L / g.Ny) : 0, j = ok ? (int)(L - (long)k * g.Ny) : 0;
   const long sy = g.sy, sz = g.sz;
-  const long row = j * sy + k * sz;
-  const long rown = ((j + 1 == g.Ny) ? 0 : j + 1) * sy + k * sz;
-  const long rowt = (zwrap && k + 1 == g.Nz) ? j * sy : j * sy + (k + 1) * sz;
   const double rdz = 1.0 / g.dz;
   cd v[16];
+  if (CO) {
+    // The divergence is formed in the order of the memory: a wave reads 64 consecutive cells of a line (the team order
+    // r + 16 n1 of the transform makes every load instruction touch four lines in 128-byte pieces, which held this kernel
+    // at 3.6 TB/s where k_rhs + a separate transform ran at 5), lands in LDS, and the teams pick their points up there.
+    constexpr int LP = N + 16;                       // line pitch in LDS: consecutive lines start on different bank halves
+    static_assert(C * LP <= SMN, "divergence tile must fit the transform's LDS buffer");
+    constexpr int PER = C * N / 256;                 // cells per thread
+    const long L0 = (long)blockIdx.x * C;
+    int j0 = (int)(L0 % g.Ny), k0 = (int)(L0 / g.Ny);
 #pragma unroll
-  for (int n1 = 0; n1 < 16; ++n1) {
-    const int i = pos_in<N>(r, c, n1);
-    const int ie = (i + 1 == g.Nx) ? 0 : i + 1;
-    double d = 0.0;
-    if (ok) d = ((us[row + ie] - us[row + i]) * g.rdx + (vs[rown + i] - vs[row + i]) * g.rdy + (ws[rowt + i] - ws[row + i]) * rdz) * rdt;
-    v[n1] = {d, 0.0};
+    for (int m = 0; m < PER; ++m) {
+      const int e = t + 256 * m;
+      const int l2 = e / N, i = e - l2 * N;          // N is a power of two: shifts; l2 is wave-uniform
+      int j = j0 + l2, k = k0;
+      while (j >= g.Ny) { j -= g.Ny; ++k; }
+      double d = 0.0;
+      if (k < g.Nz) {
+        const long row = j * sy + k * sz;
+        const long rown = ((j + 1 == g.Ny) ? 0 : j + 1) * sy + k * sz;
+        const long rowt = (zwrap && k + 1 == g.Nz) ? j * sy : j * sy + (k + 1) * sz;
+        const int ie = (i + 1 == g.Nx) ? 0 : i + 1;
+        d = ((us[row + ie] - us[row + i]) * g.rdx + (vs[rown + i] - vs[row + i]) * g.rdy + (ws[rowt + i] - ws[row + i]) * rdz) * rdt;
+      }
+      sm[l2 * LP + i] = d;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = {sm[ln * LP + pos_in<N>(r, c, n1)], 0.0};
+    __syncthreads();                                 // the transform reuses the buffer
+  } else {
+    const int k = ok ? (int)(L / g.Ny) : 0, j = ok ? (int)(L - (long)k * g.Ny) : 0;
+    const long row = j * sy + k * sz;
+    const long rown = ((j + 1 == g.Ny) ? 0 : j + 1) * sy + k * sz;
+    const long rowt = (zwrap && k + 1 == g.Nz) ? j * sy : j * sy + (k + 1) * sz;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int i = pos_in<N>(r, c, n1);
+      const int ie = (i + 1 == g.Nx) ? 0 : i + 1;
+      double d = 0.0;
+      if (ok) d = ((us[row + ie] - us[row + i]) * g.rdx + (vs[rown + i] - vs[row + i]) * g.rdy + (ws[rowt + i] - ws[row + i]) * rdz) * rdt;
+      v[n1] = {d, 0.0};
+    }
   }
   fft_fwd<N, 1, true>(sm, v, r, c, tw);
   if (ok) {
@@ -468,9 +499,15 @@ void xfft_rhs_run(ocn_model* m, void* p, void* spec, double dt) {
   hipStream_t s = m->ctx->stream;
   cd* sp = (cd*)spec;
   const cd* tw = (const cd*)z->tw;
-  FFT_BY_N(g.Nx, ocn_launch_sync(k_xfft_rhs<128>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw),
-           ocn_launch_sync(k_xfft_rhs<256>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw),
-           ocn_launch_sync(k_xfft_rhs<512>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw))
+  if (m->knob_xfft_team) {
+    FFT_BY_N(g.Nx, ocn_launch_sync(k_xfft_rhs<128, false>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw),
+             ocn_launch_sync(k_xfft_rhs<256, false>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw),
+             ocn_launch_sync(k_xfft_rhs<512, false>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw))
+  } else {
+    FFT_BY_N(g.Nx, ocn_launch_sync(k_xfft_rhs<128, true>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw),
+             ocn_launch_sync(k_xfft_rhs<256, true>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw),
+             ocn_launch_sync(k_xfft_rhs<512, true>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw))
+  }
 }
 
 // in place on the (ncol, Nz) spectrum; `zero_col` < 0 when this rank does not own the mean mode
