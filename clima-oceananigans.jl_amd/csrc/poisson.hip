@@ -470,72 +470,103 @@ __global__ void k_tridiag_setup(GridDev g, int Nxh, int Ny, int Nz, const double
 // Thomas sweeps down z for each (i,j) column of the spectrum with the precomputed factors; in place on `a`.
 __global__ void k_tridiag(GridDev g, int Nxh, int Ny, int Nz, double norm, double2_* __restrict__ a,
                           const double* __restrict__ t, const double* __restrict__ rb, const int* __restrict__ kbr,
-                          int owns_mean) {
+                          int owns_mean, double* __restrict__ mean_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= Nxh || j >= Ny) return;
   const size_t ncol = (size_t)Nxh * Ny, col = i + (size_t)Nxh * j;
-  constexpr int PF = 8;               // loads run PF levels ahead of the recurrence that consumes them
+  // Both sweeps are serial in k and there are only Nxh Ny / 64 waves: the kernel is bound by memory latency.  Loads run in
+  // chunks of PF levels, and the NEXT chunk is requested before the current one is consumed (the array is updated in place,
+  // so the order is written out by hand: the compiler will not move a load of `a` above a store to it).
+  constexpr int PF = 8;
   const int kbreak = kbr[col];
   double2_ f = a[col];
   double r0 = rb[col];
   double2_ prev = {f.x * norm * r0, f.y * norm * r0};
   a[col] = prev;
-  for (int k0 = 1; k0 < Nz; k0 += PF) {
-    double2_ fb[PF];
-    double rbb[PF];
+  {
+    double2_ fA[PF], fB[PF];
+    double rA[PF], rB[PF];
+    auto fetch = [&](double2_* fb, double* rbb, int k0) {
 #pragma unroll
-    for (int q = 0; q < PF; ++q)
-      if (k0 + q < Nz) {
-        fb[q] = a[col + ncol * (k0 + q)];
-        rbb[q] = rb[col + ncol * (k0 + q)];
+      for (int q = 0; q < PF; ++q)
+        if (k0 + q < Nz) {
+          fb[q] = a[col + ncol * (k0 + q)];
+          rbb[q] = rb[col + ncol * (k0 + q)];
+        }
+    };
+    auto sweep = [&](const double2_* fb, const double* rbb, int k0) {
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        const int k = k0 + q;
+        if (k >= Nz) break;
+        const double off = g_rdzf(g, k);
+        // rb is 0 from the break level on: those levels hold the deterministic stand-in 0, like the stale storage they replace
+        double2_ cur = {(fb[q].x * norm - off * prev.x) * rbb[q], (fb[q].y * norm - off * prev.y) * rbb[q]};
+        a[col + ncol * k] = cur;
+        prev = cur;
       }
-#pragma unroll
-    for (int q = 0; q < PF; ++q) {
-      const int k = k0 + q;
-      if (k >= Nz) break;
-      const double off = g_rdzf(g, k);
-      // rb is 0 from the break level on: those levels hold the deterministic stand-in 0, like the stale storage they replace
-      double2_ cur = {(fb[q].x * norm - off * prev.x) * rbb[q], (fb[q].y * norm - off * prev.y) * rbb[q]};
-      a[col + ncol * k] = cur;
-      prev = cur;
+    };
+    fetch(fA, rA, 1);
+    for (int k0 = 1; k0 < Nz; k0 += 2 * PF) {
+      fetch(fB, rB, k0 + PF);
+      sweep(fA, rA, k0);
+      fetch(fA, rA, k0 + 2 * PF);
+      sweep(fB, rB, k0 + PF);
     }
   }
   (void)kbreak;
-  double2_ nxt = a[col + ncol * (Nz - 1)];
+  double2_ nxt = prev;                 // level Nz - 1, as stored
   double sx = nxt.x, sy_ = nxt.y;
-  for (int k0 = Nz - 2; k0 >= 0; k0 -= PF) {
-    double tb[PF];
-    double2_ ab[PF];
+  {
+    double tA[PF], tB[PF];
+    double2_ aA[PF], aB[PF];
+    auto fetch = [&](double* tb, double2_* ab, int k0) {
 #pragma unroll
-    for (int q = 0; q < PF; ++q)
-      if (k0 - q >= 0) {
-        tb[q] = t[col + ncol * (k0 - q + 1)];
-        ab[q] = a[col + ncol * (k0 - q)];
+      for (int q = 0; q < PF; ++q)
+        if (k0 - q >= 0) {
+          tb[q] = t[col + ncol * (k0 - q + 1)];
+          ab[q] = a[col + ncol * (k0 - q)];
+        }
+    };
+    auto sweep = [&](const double* tb, const double2_* ab, int k0) {
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        const int k = k0 - q;
+        if (k < 0) break;
+        double2_ cur = ab[q];
+        cur.x -= tb[q] * nxt.x;
+        cur.y -= tb[q] * nxt.y;
+        a[col + ncol * k] = cur;
+        nxt = cur;
+        sx += cur.x;
+        sy_ += cur.y;
       }
-#pragma unroll
-    for (int q = 0; q < PF; ++q) {
-      const int k = k0 - q;
-      if (k < 0) break;
-      double2_ cur = ab[q];
-      cur.x -= tb[q] * nxt.x;
-      cur.y -= tb[q] * nxt.y;
-      a[col + ncol * k] = cur;
-      nxt = cur;
-      sx += cur.x;
-      sy_ += cur.y;
+    };
+    // the forward sweep's last stores and these loads touch the same array: levels Nz-2 ... are read back after they were written
+    fetch(tA, aA, Nz - 2);
+    for (int k0 = Nz - 2; k0 >= 0; k0 -= 2 * PF) {
+      fetch(tB, aB, k0 - PF);
+      sweep(tA, aA, k0);
+      fetch(tA, aA, k0 - 2 * PF);
+      sweep(tB, aB, k0 - PF);
     }
   }
+  // phi .-= mean(phi) (fourier_tridiagonal_poisson_solver.jl:95) acts on the horizontal-mean mode only: its column mean is
+  // handed to k_tridiag_mean (one thread walking Nz levels here kept the whole GPU waiting for it)
   if (owns_mean && i == 0 && j == 0) {
-    // phi .-= mean(phi) (fourier_tridiagonal_poisson_solver.jl:95), done on the horizontal-mean mode
-    double mx = sx / Nz, my = sy_ / Nz;
-    for (int k = 0; k < Nz; ++k) {
-      double2_ cur = a[col + ncol * k];
-      cur.x -= mx;
-      cur.y -= my;
-      a[col + ncol * k] = cur;
-    }
+    mean_out[0] = sx / Nz;
+    mean_out[1] = sy_ / Nz;
   }
+}
+
+__global__ void k_tridiag_mean(double2_* __restrict__ a, size_t ncol, int Nz, const double* __restrict__ mean) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Nz) return;
+  double2_ cur = a[ncol * k];
+  cur.x -= mean[0];
+  cur.y -= mean[1];
+  a[ncol * k] = cur;
 }
 
 // launch: factors are built on first use (the model's GridDev -- halo, spacings -- is final by then)
@@ -551,7 +582,8 @@ static void tridiag_run(ocn_model* m, PoissonSolver* s, int Nc0, int Nc1, const 
     s->tri_ready = true;
   }
   ocn_launch(k_tridiag, gr, b, st, m->gd, Nc0, Nc1, s->Nz, norm, data, (const double*)s->tscr, (const double*)(s->tscr + nc),
-             (const int*)s->tri_kbr, owns_mean);
+             (const int*)s->tri_kbr, owns_mean, m->d_red + 2);
+  if (owns_mean) ocn_launch(k_tridiag_mean, dim3((s->Nz + 63) / 64, 1, 1), dim3(64, 1, 1), st, data, (size_t)Nc0 * Nc1, s->Nz, (const double*)(m->d_red + 2));
 }
 
 // ---- a Bounded or Flat x / y direction (kind 4) ----------------------------------------------------------------

@@ -63,9 +63,76 @@ function ocn_grid(arch::ROCmGPU, grid::RectilinearGrid)
     return h[]
 end
 
-# `ocn_model_desc` is filled from model.advection / closure / coriolis / buoyancy / boundary_conditions;
-# forcings, Stokes drift, background fields and function-valued BCs are rejected here (not representable).
-# ... (field-by-field, as clima-oceananigans.jl_amd/api.py does for the Python mirror)
+# `ocn_model_desc` (include/ocnhip.h; OCN_ABI_VERSION 2), field by field.  isbits, so it crosses ccall by reference.
+const MAXTR = 8
+struct BC; kind::Int32; value::Float64; array::Ptr{Float64}; end                       # ocn_bc
+struct ModelDesc
+    advection::Int32; stepper::Int32; chi::Float64; n_tracers::Int32; closure::Int32
+    nu::Float64; kappa::NTuple{MAXTR, Float64}
+    amd_Cnu::Float64; amd_Ckappa::NTuple{MAXTR, Float64}; amd_Cb::Float64; amd_has_Cb::Int32
+    coriolis_fplane::Int32; f::Float64
+    buoyancy::Int32; b_index::Int32; T_index::Int32; S_index::Int32; g::Float64; alpha::Float64; beta::Float64
+    bcs::NTuple{3 + MAXTR, NTuple{6, BC}}                                               # [u, v, w, tracers...][west .. top]
+end
+
+adv_code(::Nothing) = Int32(0); adv_code(::CenteredSecondOrder) = Int32(1); adv_code(::CenteredFourthOrder) = Int32(2)
+adv_code(::UpwindBiasedFifthOrder) = Int32(3); adv_code(a::WENO5) = a isa WENO5{<:Any, <:Any, <:Any, <:Any, <:Any, true} ? Int32(4) : Int32(5)  # zweno / JS
+adv_code(::UpwindBiasedFirstOrder) = Int32(6); adv_code(::UpwindBiasedThirdOrder) = Int32(7)
+
+# one side of one field: BoundaryCondition{Flux | Value | Gradient | Open | Periodic, Nothing | Number | Array}
+function bc_of(bc, keep)
+    cls = bc.classification
+    kind = cls isa Periodic ? 1 : cls isa Flux ? (bc.condition === nothing ? 2 : 3) : cls isa Value ? 4 : cls isa Gradient ? 5 :
+           cls isa Open ? 6 : 0
+    c = bc.condition
+    c isa Function && error("function boundary conditions cannot cross the C ABI")     # ContinuousBoundaryFunction etc.
+    c isa AbstractArray && (a = collect(Float64, c); push!(keep, a); return BC(kind, 0.0, pointer(a)))
+    return BC(kind, c === nothing ? 0.0 : Float64(c), C_NULL)
+end
+
+function ocn_model(arch::ROCmGPU, gridh, m)                                             # m: the fields NonhydrostaticModel(...) assembled
+    isempty(m.forcing) && m.stokes_drift === nothing && isempty(m.background_fields) ||
+        error("forcings, Stokes drift and background fields are Julia closures: outside the C ABI")
+    names = keys(m.tracers); nt = length(names)
+    pad(t) = ntuple(i -> i <= length(t) ? Float64(t[i]) : 0.0, MAXTR)
+    cl = m.closure
+    closure, nu, kap, Cnu, Ck, Cb, hasCb = Int32(0), 0.0, pad(()), 0.0, pad(()), 0.0, Int32(0)
+    if cl isa ScalarDiffusivity
+        closure, nu, kap = Int32(1), cl.ν, pad(values(cl.κ))
+    elseif cl isa AnisotropicMinimumDissipation
+        closure, Cnu, Ck = Int32(2), cl.Cν, pad(values(cl.Cκ))
+        cl.Cb === nothing || ((Cb, hasCb) = (Float64(cl.Cb), Int32(1)))
+    elseif cl !== nothing
+        error("closure $(typeof(cl)) is outside the path")
+    end
+    idx(n) = Int32(something(findfirst(==(n), names), 0) - 1)
+    b = m.buoyancy === nothing ? nothing : m.buoyancy.model
+    buoy, g, α, β = b === nothing ? (Int32(0), 0.0, 0.0, 0.0) : b isa BuoyancyTracer ? (Int32(1), 0.0, 0.0, 0.0) :
+                    (Int32(2), b.gravitational_acceleration, b.equation_of_state.thermal_expansion, b.equation_of_state.haline_contraction)
+    keep = Any[]                                                                        # host arrays stay alive across the call
+    sides(f) = (bcs = f.boundary_conditions; ntuple(s -> bc_of((bcs.west, bcs.east, bcs.south, bcs.north, bcs.bottom, bcs.top)[s], keep), 6))
+    none = ntuple(_ -> BC(0, 0.0, C_NULL), 6)
+    fields = (m.velocities.u, m.velocities.v, m.velocities.w, values(m.tracers)...)
+    desc = ModelDesc(adv_code(m.advection), m.timestepper isa RungeKutta3TimeStepper ? 1 : 0,
+                     m.timestepper isa QuasiAdamsBashforth2TimeStepper ? m.timestepper.χ : 0.1, nt, closure, nu, kap, Cnu, Ck, Cb, hasCb,
+                     m.coriolis === nothing ? 0 : 1, m.coriolis === nothing ? 0.0 : m.coriolis.f,
+                     buoy, idx(:b), idx(:T), idx(:S), g, α, β,
+                     ntuple(i -> i <= length(fields) ? sides(fields[i]) : none, 3 + MAXTR))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve keep check(ccall((:ocn_model_create, libocnhip), Cint, (Ptr{Cvoid}, Ref{ModelDesc}, Ref{Ptr{Cvoid}}), gridh, desc, h), arch.ctx)
+    return h[]
+end
+
+# Stand-alone fields -- Field{LX, LY, LZ}(grid), CenterField(grid), zeros(FT, ::ROCmGPU, N...) (Fields/field.jl:16-30,
+# Grids/zeros.jl:7): ocn_field_create gives a zero-filled parent array with the layout of the model's own fields.
+loc_code(::Type{Center}) = Int32(0); loc_code(::Type{Face}) = Int32(1)
+function new_field_data(gridh, grid, loc, ctx)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ocn_field_create, libocnhip), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), gridh, loc_code.(loc)..., h), ctx)
+    p = ccall((:ocn_field_parent_ptr, libocnhip), Ptr{Float64}, (Ptr{Cvoid},), h[])
+    T = Oceananigans.Grids.total_size(loc, grid)      # dense on (Periodic, Periodic, *) grids; ocn_field_parent_layout otherwise, as in alias_field_data
+    return Oceananigans.Grids.offset_data(unsafe_wrap(ROCArray, p, T), grid, loc), h[]   # keep h: ocn_field_destroy in the finalizer
+end
 
 # Field data alias the library's parent arrays (same layout as Grids/new_data.jl:33-61).  With walls or slices in
 # x / y the allocation is pitched: ocn_field_layout gives element strides and the origin of the logical parent.
@@ -137,6 +204,11 @@ kernel_path(model::RM) = (buf = Vector{UInt8}(undef, 256);
 
 # Distributed: MultiArch(ROCmGPU(); ranks=(1, 1, R)) -> ocn_comm_init(ctx, rank, R, id) with the 128-byte id of
 # ocn_comm_unique_id broadcast over MPI (Distributed/multi_architectures.jl:20-47); everything else is unchanged.
-# advection = nothing -> OCN_ADV_NONE; UpwindBiasedFirstOrder / ThirdOrder -> OCN_ADV_U1 / OCN_ADV_U3.
+# Launch-bound models (config 1) are replayed from hipGraphs inside ocn_time_step; ocn_model_graph_replays(handle, n, active)
+# reports it.  The library reports OCN_ABI_VERSION through ocn_abi_version(): __init__ compares it with 2.
+function __init__()
+    v = ccall((:ocn_abi_version, libocnhip), Cint, ())
+    v == 2 || error("libocnhip reports ABI version $v; this shim is written for 2")
+end
 
 end # module
