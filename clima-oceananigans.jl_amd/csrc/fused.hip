@@ -774,6 +774,8 @@ struct Tracer3Args {
   unsigned org;
   double dt, cn, cm, kappa;
   int use_m, ntiles, zwrap;
+  int rest_shell;   // REST: 1 = only the first and last level of G^n hold anything (boundary fluxes of a Bounded z; no walls in
+                    // x / y): the other levels are neither zeroed by the caller nor read here
 };
 
 // KV: variable diffusivity (AnisotropicMinimumDissipation): -kappa_face dc/dn with kappa_face the two-point average of kappa_e
@@ -882,7 +884,7 @@ __global__ void __launch_bounds__(BX* BY) k_tracer_step3(GridDev g, Tracer3Args 
       double gmv = 0, rest = 0;
       if (full && k > k0) {
         if (a.use_m) gmv = ldo(a.gm, c - szb);
-        if (REST) rest = ldo(a.gn, c - szb);
+        if (REST && (!a.rest_shell || k - 1 == 0 || k == g.Nz)) rest = ldo(a.gn, c - szb);   // uniform over the workgroup
       }
       auto rec = [&](double m3, double m2, double m1, double c0, double c1, double c2, double ut) {
         bool pos = ut > 0.0;
@@ -1247,6 +1249,10 @@ int fused_exchange_phi(ocn_model* m, const double* phi) {
   return comm_exchange(c, s, q);
 }
 
+// G^n of a tracer arrives holding only boundary fluxes when the tiled kernel carries advection and closure; without walls in
+// x / y those live in the first and last level, so only these two planes are cleared and read (kernels.hip launch_tendencies)
+bool tracer_rest_shell(const ocn_model* m) { return !m->gd.xb && !m->gd.yb; }
+
 bool fused_tracer3_ok(const ocn_model* m) {
   return m->gd.Nx <= 256 && !m->gd.xb && !m->knob_no_tracer3;
 }
@@ -1269,6 +1275,7 @@ void launch_tracer3(ocn_model* m, double dt, double cn, double cm, int use_m, bo
   a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
   a.ntiles = (gd.Ny + by - 2) / (by - 1);
   a.zwrap = (m->g->dist || m->g->topo[2] != OCN_PERIODIC) ? 0 : 1;
+  a.rest_shell = (rest && tracer_rest_shell(m)) ? 1 : 0;
   int nseg = fused_cu_count(m);
   const long total = (long)a.ntiles * gd.Nz;
   if (nseg > total / 4) nseg = (int)(total / 4 > 8 ? total / 4 : 8);

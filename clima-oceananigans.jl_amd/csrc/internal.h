@@ -160,6 +160,7 @@ bool fused_bz_available(const ocn_model* m);
 void launch_fused_bz(ocn_model* m, double dt, double cn, double cm, int use_m);
 bool launch_rest4(ocn_model* m);
 bool fused_tracer3_ok(const ocn_model* m);
+bool tracer_rest_shell(const ocn_model* m);
 void launch_tracer3(ocn_model* m, double dt, double cn, double cm, int use_m, bool rest);
 void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m);
 void launch_rhs_wrap(ocn_model* m, double dt, double* rhs);

@@ -217,6 +217,21 @@ __global__ void k_apply_flux(GridDev g, double* __restrict__ G, int dim, int zlo
   }
 }
 
+// G^n of tracer t before the boundary fluxes are added, when everything else comes from the tiled tracer kernel: zero where
+// that kernel will read it -- the whole array with walls in x / y, else the first and last level only (fused.hip rest_shell)
+static void tracer_gn_clear(ocn_model* m, int t) {
+  if (g_ocn_dry) return;
+  Field& G = m->Gn[3 + t];
+  hipStream_t s = m->ctx->stream;
+  if (!tracer_rest_shell(m)) {
+    hipMemsetAsync(G.d, 0, G.n * sizeof(double), s);
+    return;
+  }
+  const size_t plane = (size_t)G.sz * sizeof(double);
+  hipMemsetAsync(G.d + (size_t)G.Hz * G.sz, 0, plane, s);
+  if (m->gd.Nz > 1) hipMemsetAsync(G.d + (size_t)(G.Hz + m->gd.Nz - 1) * G.sz, 0, plane, s);
+}
+
 void launch_tendencies(ocn_model* m, bool skip_momentum_advection, bool skip_tracer_advection) {
   ProfScope ps(m->ctx, "tendencies");
   const GridDev& g = m->gd;
@@ -241,7 +256,7 @@ void launch_tendencies(ocn_model* m, bool skip_momentum_advection, bool skip_tra
   if (skip_momentum_advection) { if (!launch_rest4(m)) ocn_launch(k_tend_uvw<ADV_NONE, W>, gr, b, s, g, ph, u, v, w, Gu, Gv, Gw); }  \
   else ocn_launch(k_tend_uvw<A, W>, gr, b, s, g, ph, u, v, w, Gu, Gv, Gw);      \
   for (int t = 0; t < m->nt; ++t) {                                             \
-    if (skip_tracer_advection) { if (!g_ocn_dry) hipMemsetAsync(m->Gn[3 + t].d, 0, m->Gn[3 + t].n * sizeof(double), s); }  /* advection AND closure flux come from the tiled tracer kernel; boundary fluxes are added below */ \
+    if (skip_tracer_advection) { tracer_gn_clear(m, t); }  /* advection AND closure flux come from the tiled tracer kernel; boundary fluxes are added below */ \
     else { TEND_TRACER(A, W, t) }                                               \
   }
 #define TEND_CASE(A)                \
@@ -583,6 +598,7 @@ void launch_pcorrect(ocn_model* m, double dt) {
 }
 
 // ---- hydrostatic pressure anomaly (update_hydrostatic_pressure.jl:10-18) ---------------------------------------
+template <int CH>   // levels whose buoyancies are in flight together
 __global__ void k_hydrostatic(GridDev g, Phys ph, const double* __restrict__ b0, const double* __restrict__ T,
                               const double* __restrict__ S, double* __restrict__ pH) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -599,7 +615,6 @@ __global__ void k_hydrostatic(GridDev g, Phys ph, const double* __restrict__ b0,
   double acc = 0;
   // the recurrence is serial in k, the loads are not: eight levels' buoyancies are fetched before they are summed, so a
   // column pays one memory latency per eight levels instead of one per level (0.080 -> see profiles at 256x256x128)
-  constexpr int CH = 8;
   for (int k1 = Nz - 1; k1 >= 0; k1 -= CH) {
     double bk[CH];
 #pragma unroll
@@ -630,7 +645,10 @@ void launch_hydrostatic(ocn_model* m) {
   const double* T = m->d.T_index >= 0 ? m->tr[m->d.T_index].interior() : nullptr;
   const double* S = m->d.S_index >= 0 ? m->tr[m->d.S_index].interior() : nullptr;
   dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
-  ocn_launch(k_hydrostatic, gr, b, m->ctx->stream, g, ph, b0, T, S, m->pHY.interior());
+  static const int ch = getenv("OCNHIP_HYDRO_CH") ? atoi(getenv("OCNHIP_HYDRO_CH")) : 8;
+  if (ch == 16) ocn_launch(k_hydrostatic<16>, gr, b, m->ctx->stream, g, ph, b0, T, S, m->pHY.interior());
+  else if (ch == 32) ocn_launch(k_hydrostatic<32>, gr, b, m->ctx->stream, g, ph, b0, T, S, m->pHY.interior());
+  else ocn_launch(k_hydrostatic<8>, gr, b, m->ctx->stream, g, ph, b0, T, S, m->pHY.interior());
 }
 
 // ---- compact (Nx,Ny,Nz) array -> field interior (copy_real_component!, fft_based_poisson_solver.jl:122-125) --
@@ -726,6 +744,7 @@ struct AmdTracers {
 
 // nu_e and every kappa_e in one pass: the interpolated velocity gradients are shared by all predictors
 // (calc_nu / calc_kappa, anisotropic_minimum_dissipation.jl:138-178).
+template <int NT>   // NT >= 0: tracer count known at compile time (the loop unrolls, its loads can be issued early); -1: any
 __global__ void k_amd_all(AmdCtx a, double Cnu, double* __restrict__ nu, AmdTracers T) {
   const GridDev& g = a.g;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -791,9 +810,11 @@ __global__ void k_amd_all(AmdCtx a, double Cnu, double* __restrict__ nu, AmdTrac
     nus = -Cnu * d2 * ((r1 + r2 + r3) - Cb_zeta) / q;
   }
   nu[c] = fmax(0.0, nus);
-  if (T.n == 0) return;
+  const int nt = NT >= 0 ? NT : T.n;
+  if (nt == 0) return;
   const double xz_dyw = amd_Ixz(a, c, k, ndyw);   // cy_uy interpolates norm_dy_w with I_xz, as written (:326)
-  for (int t = 0; t < T.n; ++t) {
+#pragma unroll
+  for (int t = 0; t < nt; ++t) {
     const double* __restrict__ q_ = T.q[t];
     // normalised tracer gradients at fcc / cfc / ccf
     auto nx = [&](long p) { return a.Dx * ((q_[p] - q_[p - 1]) * a.rdx); };
@@ -880,5 +901,7 @@ void launch_amd(ocn_model* m) {
       T.cb1 = m->d.beta;
     }
   }
-  ocn_launch(k_amd_all, gr, b, m->ctx->stream, a, m->d.amd_Cnu, m->nu_e.interior(), T);
+  if (m->nt == 1) ocn_launch(k_amd_all<1>, gr, b, m->ctx->stream, a, m->d.amd_Cnu, m->nu_e.interior(), T);
+  else if (m->nt == 2) ocn_launch(k_amd_all<2>, gr, b, m->ctx->stream, a, m->d.amd_Cnu, m->nu_e.interior(), T);
+  else ocn_launch(k_amd_all<-1>, gr, b, m->ctx->stream, a, m->d.amd_Cnu, m->nu_e.interior(), T);
 }
