@@ -86,6 +86,8 @@ void ocn_destroy(ocn_ctx* ctx) {
 
 int ocn_sync(ocn_ctx* ctx) {
   if (!ctx) return OCN_EINVAL;
+  for (ocn_model* m : ctx->models)   // exchanges still travelling on the communication stream belong to the step too
+    if (halo_settle(m)) return OCN_EHIP;
   OCN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   OCN_HIP_CHECK(ctx, hipGetLastError());
   return OCN_OK;
@@ -415,6 +417,7 @@ static void fill_order(const ocn_grid* g, int order[3]) {
 
 static int fill_fields(ocn_model* m, Field** fs, int n) {
   if (n == 0) return OCN_OK;
+  if (halo_settle(m)) return OCN_EHIP;
   ProfScope ps(m->ctx, "fill_halos");
   FieldPtrs F;
   F.n = n;
@@ -462,6 +465,7 @@ static int fill_velocities_tracers(ocn_model* m, bool tracers) {
 
 static int update_state(ocn_model* m) {
   // update_nonhydrostatic_model_state.jl:14-37
+  if (halo_settle(m)) return OCN_EHIP;
   int rc = fill_velocities_tracers(m, true);
   if (rc) return rc;
   if (m->d.closure == OCN_CLOSURE_AMD) {
@@ -512,9 +516,43 @@ static int zero_Gm(ocn_model* m) {
 }
 
 // one fused (sub)step of the fast path: tendencies + update, rhs, solve, projection + halo images
+// An exchange started by the previous (sub)step may still be in flight: everybody who reads z halos waits for it here.
+int halo_settle(ocn_model* m) {
+  if (m->halo_inflight) OCN_HIP_CHECK(m->ctx, hipStreamWaitEvent(m->ctx->stream, m->ctx->ev_halo, 0));
+  if (m->halo2_inflight) OCN_HIP_CHECK(m->ctx, hipStreamWaitEvent(m->ctx->stream, m->ctx->ev_halo2, 0));
+  m->halo_inflight = m->halo2_inflight = false;
+  return OCN_OK;
+}
+
+static int overlap_streams(ocn_ctx* c) {
+  if (c->overlap_ready) return OCN_OK;
+  OCN_HIP_CHECK(c, hipStreamCreate(&c->comm_stream));
+  OCN_HIP_CHECK(c, hipEventCreate(&c->ev_main));
+  OCN_HIP_CHECK(c, hipEventCreate(&c->ev_halo));
+  OCN_HIP_CHECK(c, hipEventCreate(&c->ev_halo2));
+  c->overlap_ready = true;
+  return OCN_OK;
+}
+
 static int fused_substep(ocn_model* m, double dt_full, double cn, double cm, int use_m, double dt_stage, bool swap) {
-  launch_fused_tend_step(m, dt_full, cn, cm, use_m);
+  const int Hz = m->gd.Hz, Nz = m->gd.Nz;
+  if (m->halo_inflight && Nz > 2 * Hz + 2) {
+    // z-slabs: the halo planes of u, v, w are still on their way (started after the last projection).  The interior levels
+    // touch none of them; the first and last Hz levels follow once the planes have landed.
+    launch_fused_tend_step(m, dt_full, cn, cm, use_m, Hz, Nz - Hz);
+    OCN_HIP_CHECK(m->ctx, hipStreamWaitEvent(m->ctx->stream, m->ctx->ev_halo, 0));
+    m->halo_inflight = false;
+    launch_fused_tend_step(m, dt_full, cn, cm, use_m, 0, Hz, Nz - Hz, Nz);   // both ends in one launch
+  } else {
+    int rc0 = halo_settle(m);
+    if (rc0) return rc0;
+    launch_fused_tend_step(m, dt_full, cn, cm, use_m);
+  }
   launch_tracer_steps(m, dt_full, cn, cm, use_m);                  // passive tracers: old velocities, own update
+  if (m->halo2_inflight) {   // pNHS planes: one exchange of a communicator at a time -- the next one (w* below) waits for them
+    OCN_HIP_CHECK(m->ctx, hipStreamWaitEvent(m->ctx->stream, m->ctx->ev_halo2, 0));
+    m->halo2_inflight = false;
+  }
   int rc = OCN_OK;
   if (m->g->dist && (rc = fused_exchange_ws(m))) return rc;        // w* of the level above the slab
   if (poisson_custom_xy(m)) {
@@ -527,10 +565,29 @@ static int fused_substep(ocn_model* m, double dt_full, double cn, double cm, int
   if (m->g->dist && (rc = fused_exchange_phi(m, poisson_rhs_buffer(m->solver)))) return rc;   // p below the slab
   launch_project(m, dt_stage, poisson_rhs_buffer(m->solver));
   if (m->g->dist) {
-    Field* fs[4 + OCN_MAX_TRACERS] = {&m->u, &m->v, &m->w, &m->pNHS};
-    int nf = 4;
-    for (int t = 0; t < m->nt; ++t) fs[nf++] = &m->tr[t];
-    if ((rc = comm_halo_exchange_z(m, fs, nf))) return rc;
+    ocn_ctx* c = m->ctx;
+    const bool want = m->knob_overlap >= 0 ? m->knob_overlap != 0 : c->nranks > 1;   // a forced one-rank slab run copies on the device: nothing to hide
+    if (want && comm_can_overlap(c) && Nz > 2 * Hz + 2 && overlap_streams(c) == OCN_OK) {
+      // The halo planes travel on the communication stream while this stream goes on with the interior levels of the next
+      // tendency kernel: what the next (sub)step needs first (u, v, w, tracers) in one group, pNHS (read by nobody until
+      // output) behind it.  Only one exchange of the communicator is ever in flight: every later one waits for both events.
+      Field* fa[3 + OCN_MAX_TRACERS] = {&m->u, &m->v, &m->w};
+      int na = 3;
+      for (int t = 0; t < m->nt; ++t) fa[na++] = &m->tr[t];
+      Field* fb[1] = {&m->pNHS};
+      OCN_HIP_CHECK(c, hipEventRecord(c->ev_main, c->stream));
+      OCN_HIP_CHECK(c, hipStreamWaitEvent(c->comm_stream, c->ev_main, 0));
+      if ((rc = comm_halo_exchange_z(m, fa, na, c->comm_stream))) return rc;
+      OCN_HIP_CHECK(c, hipEventRecord(c->ev_halo, c->comm_stream));
+      if ((rc = comm_halo_exchange_z(m, fb, 1, c->comm_stream))) return rc;
+      OCN_HIP_CHECK(c, hipEventRecord(c->ev_halo2, c->comm_stream));
+      m->halo_inflight = m->halo2_inflight = true;
+    } else {
+      Field* fs[4 + OCN_MAX_TRACERS] = {&m->u, &m->v, &m->w, &m->pNHS};
+      int nf = 4;
+      for (int t = 0; t < m->nt; ++t) fs[nf++] = &m->tr[t];
+      if ((rc = comm_halo_exchange_z(m, fs, nf))) return rc;
+    }
   }
   if (swap)
     for (int f = 0; f < 3 + m->nt; ++f) std::swap(m->Gn[f], m->Gm[f]);   // store_tendencies! as a pointer swap
@@ -893,13 +950,20 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
     return OCN_EHIP;
   }
   update_state(m);  // nonhydrostatic_model.jl:200
+  ctx->models.push_back(m);
   *out = m;
   return OCN_OK;
 }
 
 void ocn_model_destroy(ocn_model* m) {
   if (!m) return;
+  if (m->ctx->overlap_ready) hipStreamSynchronize(m->ctx->comm_stream);
   hipStreamSynchronize(m->ctx->stream);
+  for (auto it = m->ctx->models.begin(); it != m->ctx->models.end(); ++it)
+    if (*it == m) {
+      m->ctx->models.erase(it);
+      break;
+    }
 #ifndef OCN_HOST_EMU
   for (auto& e : m->graphs)
     if (e.exec) hipGraphExecDestroy((hipGraphExec_t)e.exec);
@@ -958,6 +1022,7 @@ int ocn_field_shape(const ocn_model* m, int field_id, int32_t total[3], int32_t 
 }
 
 void* ocn_field_device_ptr(ocn_model* m, int field_id) {
+  if (m) halo_settle(m);   // work the caller enqueues on ocn_stream() after this call sees complete halos
   Field* f = model_field(m, field_id);
   return f ? f->d : nullptr;
 }
@@ -1023,6 +1088,7 @@ static int parent_download(ocn_ctx* ctx, const Field* f, double* host) {
 }
 
 int ocn_field_upload(ocn_model* m, int field_id, const double* host) {
+  if (m && halo_settle(m)) return OCN_EHIP;
   if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF && materialize_gn(m)) return OCN_EHIP;
   Field* f = model_field(m, field_id);
   if (!f || !host) return OCN_EINVAL;
@@ -1030,6 +1096,7 @@ int ocn_field_upload(ocn_model* m, int field_id, const double* host) {
 }
 
 int ocn_field_download(const ocn_model* m, int field_id, double* host) {
+  if (m && halo_settle(const_cast<ocn_model*>(m))) return OCN_EHIP;
   Field* f = model_field(const_cast<ocn_model*>(m), field_id);
   if (!f || !host) return OCN_EINVAL;
   return parent_download(m->ctx, f, host);
@@ -1103,6 +1170,7 @@ int ocn_field_parent_download(const ocn_field* f, double* host) {
 }
 
 int ocn_field_set_interior(ocn_model* m, int field_id, const double* host) {
+  if (m && halo_settle(m)) return OCN_EHIP;
   if (m && field_id >= OCN_F_GN && field_id < OCN_F_GN + OCN_NF && materialize_gn(m)) return OCN_EHIP;
   Field* f = model_field(m, field_id);
   if (!f || !host) return OCN_EINVAL;
@@ -1118,6 +1186,7 @@ int ocn_field_set_interior(ocn_model* m, int field_id, const double* host) {
 }
 
 int ocn_field_get_interior(const ocn_model* m, int field_id, double* host) {
+  if (m && halo_settle(const_cast<ocn_model*>(m))) return OCN_EHIP;
   Field* f = model_field(const_cast<ocn_model*>(m), field_id);
   if (!f || !host) return OCN_EINVAL;
   int32_t it[3];
@@ -1150,6 +1219,7 @@ int ocn_update_state(ocn_model* m) { return m ? update_state(m) : OCN_EINVAL; }
 
 int ocn_compute_tendencies(ocn_model* m) {
   if (!m) return OCN_EINVAL;
+  if (halo_settle(m)) return OCN_EHIP;
   m->gn_alias_gm = false;
   launch_tendencies(m);
   return OCN_OK;
@@ -1157,6 +1227,7 @@ int ocn_compute_tendencies(ocn_model* m) {
 
 int ocn_ab2_step(ocn_model* m, double dt, double chi) {
   if (!m) return OCN_EINVAL;
+  if (halo_settle(m)) return OCN_EHIP;
   if (materialize_gn(m)) return OCN_EHIP;
   launch_step(m, dt, 1.5 + chi, -(0.5 + chi), 1);
   return OCN_OK;
@@ -1164,6 +1235,7 @@ int ocn_ab2_step(ocn_model* m, double dt, double chi) {
 
 int ocn_rk3_substep(ocn_model* m, double dt, double gamma, double zeta, int has_zeta) {
   if (!m) return OCN_EINVAL;
+  if (halo_settle(m)) return OCN_EHIP;
   if (materialize_gn(m)) return OCN_EHIP;
   launch_step(m, dt, gamma, zeta, has_zeta);
   return OCN_OK;
@@ -1171,6 +1243,7 @@ int ocn_rk3_substep(ocn_model* m, double dt, double gamma, double zeta, int has_
 
 int ocn_store_tendencies(ocn_model* m) {
   if (!m) return OCN_EINVAL;
+  if (halo_settle(m)) return OCN_EHIP;
   if (materialize_gn(m)) return OCN_EHIP;
   launch_store(m);
   return OCN_OK;
@@ -1180,12 +1253,14 @@ int ocn_pressure_correction(ocn_model* m, double dt) { return m ? pressure_corre
 
 int ocn_pressure_correct_velocities(ocn_model* m, double dt) {
   if (!m) return OCN_EINVAL;
+  if (halo_settle(m)) return OCN_EHIP;
   launch_pcorrect(m, dt);
   return OCN_OK;
 }
 
 int ocn_poisson_solve_host(ocn_model* m, const double* rhs, double* phi) {
   if (!m || !rhs || !phi) return OCN_EINVAL;
+  if (halo_settle(m)) return OCN_EHIP;
   size_t n = (size_t)m->g->N[0] * m->g->N[1] * m->g->N[2];
   double *a = nullptr, *b = nullptr;
   OCN_HIP_CHECK(m->ctx, hipMalloc((void**)&a, n * sizeof(double)));
@@ -1215,6 +1290,7 @@ int ocn_set_epilogue(ocn_model* m, int enforce_incompressibility) {
 int ocn_time_step(ocn_model* m, double dt, int force_euler) {
   if (!m) return OCN_EINVAL;
   ProfScope ps(m->ctx, "time_step");
+  if (!m->fast_path && halo_settle(m)) return OCN_EHIP;   // the all-in-one path overlaps its own exchanges (fused_substep)
 #ifndef OCN_HOST_EMU
   if (graph_eligible(m)) return step_graphed(m, dt, force_euler);
 #endif
@@ -1239,6 +1315,7 @@ int ocn_set_clock(ocn_model* m, double time, int64_t iteration, double previous_
 
 int ocn_max_abs_divergence(ocn_model* m, double* out) {
   if (!m || !out) return OCN_EINVAL;
+  if (halo_settle(m)) return OCN_EHIP;
   OCN_HIP_CHECK(m->ctx, hipMemsetAsync(m->d_red, 0, 8, m->ctx->stream));
   launch_maxdiv(m, m->d_red);
   OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));

@@ -296,8 +296,13 @@ int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* id128) {
 
 // Grouped point-to-point exchange: every op is (buffer, bytes, peer, tag).  All ranks call this collectively
 // with matching sends / receives (same tag on both sides).  Self-messages are plain device copies.
-int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs) {
-  hipStream_t st = c->stream;
+// The split of the tendency launch into interior and boundary levels (api.hip fused_substep) is used with every transport:
+// RCCL and the self-copies of a forced one-rank slab run are stream-ordered and really overlap; the host shared-memory
+// transport and the emulation's mailbox are blocking, so with them the same call sequence simply runs back to back.
+bool comm_can_overlap(const ocn_ctx* c) { (void)c; return true; }
+
+int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs, hipStream_t st_in) {
+  hipStream_t st = st_in ? st_in : c->stream;
 #ifndef OCN_HOST_EMU
   if (c->nranks == 1 && c->comm) {   // one-rank communicator (OCNHIP_RCCL_SELF): self messages through RCCL itself
     ncclComm_t comm1 = (ncclComm_t)c->comm;
@@ -370,7 +375,7 @@ int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vecto
 
 // z-halo exchange of whole parent planes (halo_communication.jl:68-183 semantics: send interior planes
 // [H, 2H) / [Nz, Nz+H) of the parent, receive into [0, H) / [Nz+H, Nz+2H)); periodic ring of slabs.
-int comm_halo_exchange_z(ocn_model* m, Field** fs, int n) {
+int comm_halo_exchange_z(ocn_model* m, Field** fs, int n, hipStream_t st) {
   ocn_ctx* c = m->ctx;
   ProfScope ps(c, "halo_exchange");
   const int R = c->nranks, r = c->rank;
@@ -389,7 +394,7 @@ int comm_halo_exchange_z(ocn_model* m, Field** fs, int n) {
     sends.push_back({base + plane * (size_t)H, blk, dn, 2 * i + 1});
     recvs.push_back({base + plane * (size_t)(Nz + H), blk, up, 2 * i + 1});
   }
-  return comm_exchange(c, sends, recvs);
+  return comm_exchange(c, sends, recvs, st);
 }
 
 // y-halo exchange for y-slabs (Bounded z): H rows of every (x, z) -- full parent extent in x and z, as the periodic
@@ -479,6 +484,15 @@ int comm_alltoall(ocn_ctx* c, const void* send, void* recv, size_t block_bytes) 
 }
 
 void comm_destroy(ocn_ctx* c) {
+  if (c->overlap_ready) {
+    c->overlap_ready = false;
+    hipStreamSynchronize(c->comm_stream);
+    hipStreamDestroy(c->comm_stream);
+    hipEventDestroy(c->ev_main);
+    hipEventDestroy(c->ev_halo);
+    hipEventDestroy(c->ev_halo2);
+    c->comm_stream = nullptr;
+  }
   shm_destroy(c);
 #ifndef OCN_HOST_EMU
   if (c->comm) ncclCommDestroy((ncclComm_t)c->comm);

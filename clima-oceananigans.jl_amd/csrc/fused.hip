@@ -41,6 +41,9 @@ struct FusedArgs {
   int ntx, BXo;                   // x-tiled variant: tiles along x, output columns per tile
   int prio;                       // wave-priority scheme of the tendency kernels (see PRIO_* below)
   double nu;                      // ScalarDiffusivity viscosity (0: none); see the viscous-flux note in k_tend_step3
+  int zlo, zhi;                   // levels [zlo, zhi) of this launch (the whole column, or the part of a slab whose z halos are
+  int zlo2, zhi2;                 // already / not yet there: api.hip fused_substep), optionally followed by a second run
+  int gran;                       // [zlo2, zhi2); segments start on multiples of `gran` levels of that concatenated space
 };
 
 // Wave priorities (s_setprio).  The VALU of a SIMD is handed out by priority, then by age, so the four waves a SIMD holds
@@ -131,13 +134,16 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
   // share an L2, so each XCD gets a contiguous band of segments.
   const int nseg = gridDim.x, per = nseg / 8;
   const long seg = (nseg % 8 == 0) ? (long)(blockIdx.x % 8) * per + blockIdx.x / 8 : (long)blockIdx.x;
-  const long total = (long)a.ntiles * g.Nz;
-  long lo = seg * total / nseg;
-  const long hi = (seg + 1) * total / nseg;
+  const int n1 = a.zhi - a.zlo, NzR = n1 + (a.zhi2 - a.zlo2);
+  const long total = (long)a.ntiles * NzR, units = total / a.gran;
+  long lo = (seg * units / nseg) * a.gran;
+  const long hi = ((seg + 1) * units / nseg) * a.gran;
   while (lo < hi) {
-  const int tile = (int)(lo / g.Nz);
-  const int k0 = (int)(lo - (long)tile * g.Nz);
-  const int k1 = (k0 + (hi - lo) < g.Nz) ? (int)(k0 + (hi - lo)) : g.Nz;
+  const int tile = (int)(lo / NzR);
+  const int vl = (int)(lo - (long)tile * NzR);                  // level index inside the (possibly two-piece) run of this tile
+  const int k0 = vl < n1 ? a.zlo + vl : a.zlo2 + (vl - n1);
+  const int kend = vl < n1 ? a.zhi : a.zhi2;
+  const int k1 = (k0 + (hi - lo) < kend) ? (int)(k0 + (hi - lo)) : kend;
   lo += k1 - k0;
   const int ytile = XT ? tile / a.ntx : tile, xt = XT ? tile - ytile * a.ntx : 0;
   const int i0 = XT ? xt * a.BXo : 0;
@@ -1020,6 +1026,8 @@ void fused_read_knobs(ocn_model* m) {
   m->knob_no_dma = env("OCNHIP_NO_LDS_DMA", 0);
   m->knob_no_tracer3 = env("OCNHIP_NO_TRACER3", 0);
   m->knob_xfft_team = env("OCNHIP_XFFT_TEAM", 0);
+  m->knob_overlap = env("OCNHIP_OVERLAP", -1);   // -1: on when there is more than one rank
+  m->knob_overlap_cus = env("OCNHIP_OVERLAP_CUS", 16);
   m->knob_graph = env("OCNHIP_NO_GRAPH", 0) ? 0 : 1;   // whole-step hipGraphs of the general path (api.hip step_graphed)
   // default 0x20FF: every row at priority 3 until the middle of its flux stage, then only the last output row keeps 2
   // (256^3: 0.575 ms against 0.590 with the hardware's age order; ten codes tried, all within 0.575 - 0.613)
@@ -1058,9 +1066,22 @@ static FusedShape fused_shape(const ocn_model* m, FusedArgs& a) {
     a.ntiles *= a.ntx;
   }
   int nseg = fused_cu_count(m);                   // one workgroup is resident per CU
-  const long total = (long)a.ntiles * gd.Nz;
-  if (nseg > total / 4) nseg = (int)(total / 4 > 8 ? total / 4 : 8);
-  nseg = ((nseg + 7) / 8) * 8;                    // XCD-aware remap inside the kernel wants a multiple of 8
+  const long total = (long)a.ntiles * ((a.zhi - a.zlo) + (a.zhi2 - a.zlo2));
+  a.gran = 1;
+  if (a.zhi2 > a.zlo2) {
+    // the boundary levels of a slab (their z halos arrived late), two short runs per tile: whole runs per workgroup -- a
+    // segment that ends inside a run pays the start-up of the march (register windows, first slab) a second time
+    a.gran = a.zhi - a.zlo;
+    const long runs = total / a.gran;
+    if (nseg > runs) nseg = (int)runs;
+  } else {
+    // the interior levels of a slab run while the halo planes travel: this kernel keeps one workgroup resident on every CU
+    // for its whole duration (LDS, 4 x 128 VGPRs per SIMD), so the communication kernels would find no CU to start on --
+    // or, once they hold a few, the workgroups that lost theirs would run as a second round.  Leave them some.
+    if (a.zhi - a.zlo < gd.Nz && nseg > 4 * m->knob_overlap_cus) nseg -= m->knob_overlap_cus;
+    if (nseg > total / 4) nseg = (int)(total / 4 > 8 ? total / 4 : 8);
+    nseg = ((nseg + 7) / 8) * 8;                  // XCD-aware remap inside the kernel wants a multiple of 8
+  }
 #ifdef OCN_HOST_EMU
   nseg = total >= 3 ? 3 : 1;                      // one OS thread per emulated GPU thread: few workgroups, still several segments
 #endif
@@ -1109,13 +1130,22 @@ static void fused_fill_args(ocn_model* m, FusedArgs& a, double dt, double cn, do
   a.dt = dt; a.cn = cn; a.cm = cm; a.use_m = use_m;
   a.prio = m->knob_prio;
   a.nu = 0.0;
+  a.zlo = 0;
+  a.zhi = m->gd.Nz;
+  a.zlo2 = a.zhi2 = 0;
+  a.gran = 1;
 }
 
 // all-in-one path: triply periodic, no closure or ScalarDiffusivity
-void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m) {
+void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m, int zlo, int zhi, int zlo2, int zhi2) {
   ProfScope ps(m->ctx, "fused_tendency_step");
   FusedArgs a;
   fused_fill_args(m, a, dt, cn, cm, use_m);
+  a.zlo = zlo;
+  a.zhi = zhi < 0 ? m->gd.Nz : zhi;
+  a.zlo2 = zlo2;
+  a.zhi2 = zhi2;
+  if (a.zhi <= a.zlo) return;
   a.nu = m->d.closure == OCN_CLOSURE_SCALAR ? m->d.nu : 0.0;
   const FusedShape f = fused_shape(m, a);
   hipStream_t s = m->ctx->stream;

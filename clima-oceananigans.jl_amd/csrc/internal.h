@@ -27,6 +27,12 @@ struct ocn_ctx {
   int rank = 0, nranks = 1;
   void* comm = nullptr;  // ncclComm_t
   void* shm = nullptr;   // ShmWorld: host shared-memory transport (tests / rehearsals on one GPU or none), comm.hip
+  // z-slab halo exchange overlapped with the interior levels of the next tendency kernel (api.hip fused_substep): the
+  // exchange runs on its own stream between two events
+  bool overlap_ready = false;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_main = nullptr, ev_halo = nullptr, ev_halo2 = nullptr;
+  std::vector<struct ocn_model*> models;   // live models (ocn_sync settles their exchanges)
 };
 
 void ocn_set_error(ocn_ctx* ctx, const char* fmt, ...);
@@ -119,6 +125,9 @@ struct ocn_model {
   // whole-step hipGraphs of the general path (api.hip step_graphed): one entry per distinct (dt, stepper state, buffer rotation)
   struct StepGraph { uint64_t key; int seen; void* exec; };
   std::vector<StepGraph> graphs;
+  int knob_overlap_cus = 16; // CUs the interior tendency launch leaves to the communication kernels (OCNHIP_OVERLAP_CUS)
+  int knob_overlap = -1;     // OCNHIP_OVERLAP=0|1: z-slab halo exchange overlapped with the next tendency launch (default: with > 1 rank)
+  bool halo_inflight = false, halo2_inflight = false;   // exchange of (u, v, w, tracers) / of pNHS started, not yet waited for
   int knob_xfft_team = 0;    // OCNHIP_XFFT_TEAM=1: the fused rhs + x transform loads in team order (the older variant; tests)
   int knob_graph = 1;        // OCNHIP_NO_GRAPH=1 clears it (model creation)
   bool graph_off = false;    // a capture failed: this model steps launch by launch from then on
@@ -162,7 +171,8 @@ bool launch_rest4(ocn_model* m);
 bool fused_tracer3_ok(const ocn_model* m);
 bool tracer_rest_shell(const ocn_model* m);
 void launch_tracer3(ocn_model* m, double dt, double cn, double cm, int use_m, bool rest);
-void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m);
+// levels [zlo, zhi) (-1: Nz), optionally followed by a second run [zlo2, zhi2) of the same length in the same launch
+void launch_fused_tend_step(ocn_model* m, double dt, double cn, double cm, int use_m, int zlo = 0, int zhi = -1, int zlo2 = 0, int zhi2 = 0);
 void launch_rhs_wrap(ocn_model* m, double dt, double* rhs);
 void launch_project(ocn_model* m, double dt, const double* phi);
 void launch_tracer_steps(ocn_model* m, double dt, double cn, double cm, int use_m);
@@ -193,8 +203,10 @@ void zslab_destroy(void* z);
 int zslab_run(ocn_ctx* ctx, void* z, void* spec, double dz2, double scale);
 
 // ---- comm.hip ---------------------------------------------------------------------------------------------
-int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs);
-int comm_halo_exchange_z(ocn_model* m, Field** fs, int n);
+int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs, hipStream_t st = nullptr);   // st: default the context's stream
+int comm_halo_exchange_z(ocn_model* m, Field** fs, int n, hipStream_t st = nullptr);
+bool comm_can_overlap(const ocn_ctx* c);   // the transport is stream-ordered on the device (RCCL, or self-copies of a forced one-rank slab run)
+int halo_settle(ocn_model* m);             // the model's stream waits for an exchange still in flight (api.hip)
 int comm_halo_exchange_y(ocn_model* m, Field** fs, int n);
 int comm_alltoall(ocn_ctx* c, const void* send, void* recv, size_t block_bytes);
 void comm_destroy(ocn_ctx* c);

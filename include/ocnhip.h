@@ -144,7 +144,10 @@ typedef struct ocn_model_desc {
 int ocn_abi_version(void);
 int ocn_init(int device_id, ocn_ctx** out);
 void ocn_destroy(ocn_ctx* ctx);
-int ocn_sync(ocn_ctx* ctx);                       /* wait(device(arch), event) everywhere in the reference */
+int ocn_sync(ocn_ctx* ctx);                       /* wait(device(arch), event) everywhere in the reference.  Slab runs: the
+                                                   * halo planes of the last step may still be travelling on the library's
+                                                   * communication stream when ocn_time_step returns; ocn_sync, every
+                                                   * field accessor and every phase-level call wait for them first */
 const char* ocn_last_error(ocn_ctx* ctx);         /* ctx may be NULL: last global error */
 void* ocn_stream(ocn_ctx* ctx);                   /* the hipStream_t, for callers that enqueue their own work */
 

@@ -155,11 +155,14 @@ def test_poisson_divergence_free_solution(ocn, topo, N):
     assert np.allclose(lap, R, rtol=1.5e-8, atol=1e-10)
 
 
-@pytest.mark.parametrize("kind", ["periodic", "bounded", "wide"])
-def test_bitwise_reproducible(ocn, kind):
+@pytest.mark.parametrize("kind", ["periodic", "bounded", "wide", "slab"])
+def test_bitwise_reproducible(ocn, kind, monkeypatch):
     """No atomics, no order-dependent reductions: two runs from the same state give bit-identical fields.  A race in the
     LDS-staged kernels (slab commit vs. flux stage, flux exchange vs. finalize) would show up here as run-to-run noise."""
-    N = {"periodic": (256, 64, 48), "bounded": (128, 96, 40), "wide": (400, 40, 24)}[kind]
+    if kind == "slab":   # z-slab code path with the halo planes travelling on the communication stream under the next interior launch:
+        monkeypatch.setenv("OCNHIP_FORCE_DIST", "1")   # a missing event wait between the two streams would show up as noise here
+        monkeypatch.setenv("OCNHIP_OVERLAP", "1")
+    N = {"periodic": (256, 64, 48), "bounded": (128, 96, 40), "wide": (400, 40, 24), "slab": (256, 64, 40)}[kind]
     topo = ("Periodic", "Periodic", "Bounded" if kind == "bounded" else "Periodic")
     rng = np.random.default_rng(21)
     init = {n: rng.random(N if not (n == "w" and kind == "bounded") else (N[0], N[1], N[2] + 1)) - 0.5 for n in "uvw"}
@@ -188,6 +191,7 @@ FORCED = ["ppp_weno_ab2", "ppp_weno_rk3_2tracers", "ppb_amd_config3", "ppb_weno_
 def test_forced_slab_case_matches_oracle(ocn, name, solver, monkeypatch):
     monkeypatch.setenv("OCNHIP_FORCE_DIST", "1")
     monkeypatch.setenv("OCNHIP_DIST_SOLVER", solver)
+    monkeypatch.setenv("OCNHIP_OVERLAP", "1")     # the multi-rank default: halo planes on the communication stream
     worst = run_case(ocn, name)
     bad = {k: v for k, v in worst.items() if v > CASES[name].get("tol", 2e-11)}
     assert not bad, bad
@@ -201,6 +205,7 @@ def test_config4_slab_shape_vs_oracle(ocn, forced, monkeypatch):
     import oracle as O
     if forced:
         monkeypatch.setenv("OCNHIP_FORCE_DIST", "1")
+        monkeypatch.setenv("OCNHIP_OVERLAP", "1")   # what each of the 8 ranks runs: interior levels under the travelling halo planes
     N = (512, 512, 32)
     rng = np.random.default_rng(4)
     init = {n: rng.random(N) - 0.5 for n in "uvw"}
@@ -276,7 +281,8 @@ def test_forced_slab_through_rccl_self(ocn, monkeypatch):
     from importlib import import_module
     monkeypatch.setenv("OCNHIP_FORCE_DIST", "1")
     monkeypatch.setenv("OCNHIP_RCCL_SELF", "1")
-    monkeypatch.delenv("OCNHIP_TRANSPORT", raising=False)
+    monkeypatch.setenv("OCNHIP_OVERLAP", "1")     # as with several ranks: the RCCL group of (u, v, w, tracers) and the one of pNHS run on
+    monkeypatch.delenv("OCNHIP_TRANSPORT", raising=False)   # the communication stream under the next step's interior tendency launch
     par = import_module("ocnhip.parallel")
     ctx = ocn.Context(0)
     par.init_comm_self(ctx)
@@ -289,7 +295,7 @@ def test_forced_slab_through_rccl_self(ocn, monkeypatch):
     om = O.NonhydrostaticModel(O.RectilinearGrid(**kw), advection=O.WENO5(), tracers=("c",))
     ocn.set_model(m, **init)
     O.set_model(om, **init)
-    for _ in range(2):
+    for _ in range(4):
         ocn.time_step(m, 2e-3)
         O.time_step(om, 2e-3)
     for a, b in ((m.u, om.u), (m.v, om.v), (m.w, om.w), (m.pNHS, om.pNHS), (m.tracers["c"], om.tracers["c"])):
