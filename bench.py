@@ -446,7 +446,8 @@ def main():
                        (f"{Nglobal[0]}x{Nglobal[1]}x{Nglobal[2]} (Periodic,Periodic,Bounded) stretched z, WENO5, RK3, T+S, "
                         "FPlane, linear EOS, AMD, flux/gradient BCs, Fourier-tridiagonal Poisson (BASELINE config 3)"),
                        "decomposition": f"{'y' if args.config == 3 else 'z'}-slabs x{world}", "dt": dt, "init": args.init,
-                       "local_size": list(n), "transport": transport},
+                       "local_size": list(n), "transport": transport,
+                       "kernel_path": None if args.rehearse_hostemu else model.kernel_path},
             "roofline": roofline,
             "step_roofline": {"alg_bytes_per_cell_update": b_alg, "frac_of_hbm_peak": step_frac,
                               "measured_copy_rate_GBps": copy_rate / 1e9 if copy_rate else None,

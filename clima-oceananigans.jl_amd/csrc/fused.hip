@@ -983,7 +983,12 @@ bool fused_available(const ocn_model* m) {
 bool rest4_ok(const ocn_model* m);
 void fused_describe(const ocn_model* m, char* buf, size_t n) {
   const char* why = tiled_blocker(m);
-  if (m->fast_path) snprintf(buf, n, "all-in-one periodic path: k_tend4 + fused Poisson passes + k_project");
+  if (m->fast_path) {
+    const bool ov = m->g->dist && (m->knob_overlap >= 0 ? m->knob_overlap != 0 : m->ctx->nranks > 1) && m->gd.Nz > 2 * m->gd.Hz + 2;
+    snprintf(buf, n, "all-in-one periodic path: k_tend4 + fused Poisson passes + k_project%s",
+             !m->g->dist ? "" : ov ? "; z-slabs, halo planes travel under the next interior tendency launch"
+                                   : "; z-slabs, halo exchange on the model's stream");
+  }
   else if (m->bz_fast) snprintf(buf, n, "tiled advection + update (k_tend4, REST) on top of the %s other terms",
                                 rest4_ok(m) ? "tiled kernel's (k_rest4)" : "general kernels'");
   else if (why) snprintf(buf, n, "general kernels: %s", why);
