@@ -566,7 +566,11 @@ static int fused_substep(ocn_model* m, double dt_full, double cn, double cm, int
   launch_project(m, dt_stage, poisson_rhs_buffer(m->solver));
   if (m->g->dist) {
     ocn_ctx* c = m->ctx;
-    const bool want = m->knob_overlap >= 0 ? m->knob_overlap != 0 : c->nranks > 1;   // a forced one-rank slab run copies on the device: nothing to hide
+    // Worth it when the transfer it hides is longer than what the split costs (0.05-0.07 ms): 19 MB per direction at config 4
+    // (512 x 512 planes), 5 MB on 256 x 256 planes -- about break-even on an xGMI link, left alone.  A forced one-rank slab run
+    // copies on the device: nothing to hide.
+    const size_t halo_bytes = (size_t)(3 + m->nt) * Hz * m->u.sz * sizeof(double);
+    const bool want = m->knob_overlap >= 0 ? m->knob_overlap != 0 : (c->nranks > 1 && halo_bytes >= ((size_t)8 << 20));
     if (want && comm_can_overlap(c) && Nz > 2 * Hz + 2 && overlap_streams(c) == OCN_OK) {
       // The halo planes travel on the communication stream while this stream goes on with the interior levels of the next
       // tendency kernel: what the next (sub)step needs first (u, v, w, tracers) in one group, pNHS (read by nobody until

@@ -984,7 +984,9 @@ bool rest4_ok(const ocn_model* m);
 void fused_describe(const ocn_model* m, char* buf, size_t n) {
   const char* why = tiled_blocker(m);
   if (m->fast_path) {
-    const bool ov = m->g->dist && (m->knob_overlap >= 0 ? m->knob_overlap != 0 : m->ctx->nranks > 1) && m->gd.Nz > 2 * m->gd.Hz + 2;
+    const size_t halo_bytes = (size_t)(3 + m->nt) * m->gd.Hz * m->u.sz * sizeof(double);
+    const bool ov = m->g->dist && m->gd.Nz > 2 * m->gd.Hz + 2 &&
+                    (m->knob_overlap >= 0 ? m->knob_overlap != 0 : (m->ctx->nranks > 1 && halo_bytes >= ((size_t)8 << 20)));
     snprintf(buf, n, "all-in-one periodic path: k_tend4 + fused Poisson passes + k_project%s",
              !m->g->dist ? "" : ov ? "; z-slabs, halo planes travel under the next interior tendency launch"
                                    : "; z-slabs, halo exchange on the model's stream");

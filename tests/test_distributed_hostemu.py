@@ -34,9 +34,11 @@ def run_ranks(ocn, R, fn):
 # levels (started while the previous step's halo planes are still travelling) and boundary levels (csrc/api.hip fused_substep).
 @pytest.mark.parametrize("R,stepper,adv,nzl", [(2, "AB2", "WENO5", 8), (2, "RK3", "WENO5", 8), (2, "AB2", "C2", 8), (4, "AB2", "WENO5", 8),
                                                (4, "AB2", "C2", 8), (2, "AB2", "WENO5", 10), (2, "RK3", "WENO5", 11), (3, "AB2", "WENO5", 9)])
-def test_slab_trajectory_matches_single_domain_oracle(ocn, backend, R, stepper, adv, nzl):
+def test_slab_trajectory_matches_single_domain_oracle(ocn, backend, R, stepper, adv, nzl, monkeypatch):
     if backend != "hostemu":
         pytest.skip("host-emulation run only")
+    if nzl != 8:
+        monkeypatch.setenv("OCNHIP_OVERLAP", "1")   # by default only with 8 MB or more of halo planes per direction
     N = (8, 8, nzl * R)
     rng = np.random.default_rng(5)
     init = {n: rng.random(N) - 0.5 for n in "uvw"}

@@ -108,7 +108,8 @@ def test_bench_falls_back_to_shm_when_rccl_cannot_start():
     assert "REHEARSAL" in rec["data"] and rec["max_abs_divergence"] < 1e-10
 
 
-GPU_CASES = [("zslab_ab2", {}), ("zslab_rk3_tracer", {"OCNHIP_DIST_SOLVER": "transpose"}), ("zslab_wide", {}),
+GPU_CASES = [("zslab_ab2", {"OCNHIP_OVERLAP": "1"}), ("zslab_rk3_tracer", {"OCNHIP_DIST_SOLVER": "transpose", "OCNHIP_OVERLAP": "1"}),
+             ("zslab_wide", {}),
              ("yslab_amd", {}), ("poisson", {})]
 
 
