@@ -640,8 +640,8 @@ __global__ void __launch_bounds__(BX* BY) k_rest4(GridDev g, RestArgs a) {
 // ---- Poisson right-hand side with wrap indexing (no halo fill of the predictor) ----------------------
 __global__ void k_rhs_wrap(GridDev g, const double* __restrict__ us, const double* __restrict__ vs,
                            const double* __restrict__ ws, double rdt, int zwrap, double* __restrict__ rhs) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int i, j;
+  ocn_cell_ij(i, j);
   const int k = blockIdx.z;
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long sy = g.sy, sz = g.sz;
@@ -685,8 +685,8 @@ OCN_DEVFN void store_images(const GridDev& g, double* f, int i, int j, int k, do
 }
 
 __global__ void k_project(GridDev g, ProjArgs a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int i, j;
+  ocn_cell_ij(i, j);
   const int k = blockIdx.z;
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long c = i + j * g.sy + k * g.sz;

@@ -53,8 +53,8 @@ template <int ADV, bool WALLS>
 __global__ void k_tend_uvw(GridDev g, Phys ph, const double* __restrict__ u, const double* __restrict__ v,
                            const double* __restrict__ w, double* __restrict__ Gu, double* __restrict__ Gv,
                            double* __restrict__ Gw) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int i, j;
+  ocn_cell_ij(i, j);
   const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long sy = g.sy, sz = g.sz;
@@ -155,8 +155,8 @@ template <int ADV, bool WALLS>
 __global__ void k_tend_c(GridDev g, const double* __restrict__ u, const double* __restrict__ v,
                          const double* __restrict__ w, const double* __restrict__ q, double kap,
                          const double* __restrict__ kap_e, int closure, double* __restrict__ Gc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int i, j;
+  ocn_cell_ij(i, j);
   const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long sy = g.sy, sz = g.sz;
@@ -308,8 +308,8 @@ struct StepPtrs {
 };
 
 __global__ void k_step(GridDev g, StepPtrs P, double dt, double cn, double cm, int use_m) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int i, j;
+  ocn_cell_ij(i, j);
   const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long c = i + j * g.sy + k * g.sz;
@@ -344,8 +344,8 @@ struct CopyPtrs {
   int n;
 };
 __global__ void k_copy_interior(GridDev g, CopyPtrs P) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int i, j;
+  ocn_cell_ij(i, j);
   const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long c = i + j * g.sy + k * g.sz;
@@ -553,8 +553,8 @@ void launch_fill_bounded(ocn_model* m, Field** fs, int n, int dim) {
 // ---- Poisson right-hand side (solve_for_pressure.jl:15-18,30-33) ------------------------------------------
 __global__ void k_rhs(GridDev g, const double* __restrict__ u, const double* __restrict__ v,
                       const double* __restrict__ w, double rdt, int mult_dz, double* __restrict__ rhs) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int i, j;
+  ocn_cell_ij(i, j);
   const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long c = i + j * g.sy + k * g.sz;
@@ -577,8 +577,8 @@ void launch_rhs(ocn_model* m, double dt, double* rhs, int mult_dz) {
 // us, vs, ws: the predictor (the same arrays as u, v, w, or the separate predictor buffers of the tiled Bounded-z path)
 __global__ void k_pcorrect(GridDev g, const double* __restrict__ p, double dt, const double* us, const double* vs,
                            const double* ws, double* u, double* v, double* w) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int i, j;
+  ocn_cell_ij(i, j);
   const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long c = i + j * g.sy + k * g.sz;
@@ -650,8 +650,8 @@ void launch_hydrostatic(ocn_model* m) {
 
 // ---- compact (Nx,Ny,Nz) array -> field interior (copy_real_component!, fft_based_poisson_solver.jl:122-125) --
 __global__ void k_copy_to_field(GridDev g, const double* __restrict__ src, double* __restrict__ dst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int i, j;
+  ocn_cell_ij(i, j);
   const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   dst[i + j * g.sy + k * g.sz] = src[i + (long)g.Nx * (j + (long)g.Ny * k)];
@@ -744,8 +744,8 @@ struct AmdTracers {
 template <int NT>   // NT >= 0: tracer count known at compile time (the loop unrolls, its loads can be issued early); -1: any
 __global__ void k_amd_all(AmdCtx a, double Cnu, double* __restrict__ nu, AmdTracers T) {
   const GridDev& g = a.g;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int i, j;
+  ocn_cell_ij(i, j);
   const int k = blockIdx.z;   // one level per workgroup: k is wave-uniform, so spacings are scalar loads and 1/dz is computed once per wave
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   const long sy = a.sy, sz = a.sz;

@@ -387,8 +387,8 @@ __global__ void k_pack_slab(int Nxh, int Ny, int Nzl, int Nyl, const double2_* _
 __global__ void k_scale_spectrum_slab(int Nxh, int Nyl, int Nzg, int ky0, const double* __restrict__ lx,
                                       const double* __restrict__ ly, const double* __restrict__ lz, double norm,
                                       double2_* __restrict__ a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int i, j;
+  ocn_cell_ij(i, j);
   const int k = blockIdx.z;
   if (i >= Nxh || j >= Nyl || k >= Nzg) return;
   const size_t c = i + (size_t)Nxh * (j + (size_t)Nyl * k);
@@ -409,8 +409,8 @@ __global__ void k_scale_spectrum_slab(int Nxh, int Nyl, int Nzg, int ky0, const 
 // phi^ = -b^ / (lx + ly + lz) * norm ; zero mode := 0   (fft_based_poisson_solver.jl:106-111)
 __global__ void k_scale_spectrum(int Nxh, int Ny, int Nz, const double* __restrict__ lx, const double* __restrict__ ly,
                                  const double* __restrict__ lz, double norm, double2_* __restrict__ a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int i, j;
+  ocn_cell_ij(i, j);
   const int k = blockIdx.z;
   if (i >= Nxh || j >= Ny || k >= Nz) return;
   const size_t c = i + (size_t)Nxh * (j + (size_t)Ny * k);
@@ -1163,8 +1163,8 @@ int poisson_solve(ocn_model* m, double dt) {
 }
 
 __global__ void k_mult_dz(GridDev g, double* __restrict__ r) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int i, j;
+  ocn_cell_ij(i, j);
   const int k = blockIdx.z;
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   r[i + (size_t)g.Nx * (j + (size_t)g.Ny * k)] *= g_dzc(g, k);

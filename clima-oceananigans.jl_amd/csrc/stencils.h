@@ -44,6 +44,19 @@ OCN_DEVFN double sym4_v(double m2, double m1, double c0, double c1) {
 }
 OCN_DEVFN double sym4(const double* p, long s) { return sym4_v(p[-s], p[0], p[s], p[2 * s]); }
 
+// ---- one-thread-per-cell kernels: (i, j) of this thread, the blocks of a level handed out XCD-major ---------------------------
+// Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2) in the order of their linear index, so blocks
+// that are neighbours in y -- they share the stencil rows between them -- sit on different L2s and every shared row is
+// fetched from HBM twice (k_amd_all: 1.38x its algorithmic reads; the y transform pass: 65 -> 48-57 us with this order).
+// Block b of a level takes the (bx, by) position (b % 8) * (n / 8) + b / 8: an XCD then owns a band of consecutive rows.
+OCN_DEVFN void ocn_cell_ij(int& i, int& j) {
+  const unsigned gx = gridDim.x, n = gx * gridDim.y;
+  unsigned bl = blockIdx.x + gx * blockIdx.y;
+  if (n % 8 == 0) bl = (bl % 8) * (n / 8) + bl / 8;
+  i = (int)((bl % gx) * blockDim.x + threadIdx.x);
+  j = (int)((bl / gx) * blockDim.y + threadIdx.y);
+}
+
 // ---- fast reciprocal for the WENO weights: one hardware rcp + 1 Newton step ------------------------
 // Measured on MI355X (tools/micro_checks.hip, 2^20 random arguments over 80 binades): v_rcp_f64 alone 4.6e-8 relative
 // error, one Newton step 2.2e-15, two steps 1.1e-16.  The reciprocal multiplies the weighted sum of candidate

@@ -329,7 +329,12 @@ __global__ void __launch_bounds__(256) k_yfft(cd* __restrict__ a, int Nxh, int N
   long base;
   bool ok = true;
   if ((long)blockIdx.x < nmain) {
-    const int tile = blockIdx.x % nfull, zz = blockIdx.x / nfull;
+    // A workgroup reads C consecutive kx (128 or 256 bytes) of every row, at 16-byte alignment: neighbouring kx tiles share
+    // cache lines.  Workgroups b and b + 8 land on the same XCD (its own L2) right after each other, so the tiles are
+    // handed out XCD-major: each L2 then fetches a shared line once instead of two XCDs fetching it each.
+    long b = blockIdx.x;
+    if (nmain % 8 == 0) b = (b % 8) * (nmain / 8) + b / 8;
+    const int tile = (int)(b % nfull), zz = (int)(b / nfull);
     base = C * tile + col + plane * zz;
   } else {
     const long cc = ((long)blockIdx.x - nmain) * C + col;      // flattened (kx_left, z)
