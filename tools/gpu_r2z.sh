@@ -15,14 +15,14 @@ d=json.load(open("$O/bench_$nm.json")); p=d["phases_ms_warmup"]; print("$nm ms/s
 PY
 }
 B="timeout -k 10 300 python bench.py --no-cpu-baseline --steps 200 --warmup 20"
-run slab512_ov OCNHIP_FORCE_DIST=1 $B --size 512 512 32 &&
-run slab512_noov OCNHIP_FORCE_DIST=1 OCNHIP_NO_OVERLAP=1 $B --size 512 512 32 &&
-run slab256_ov OCNHIP_FORCE_DIST=1 $B --size 256 256 128 &&
-run slab256_noov OCNHIP_FORCE_DIST=1 OCNHIP_NO_OVERLAP=1 $B --size 256 256 128 &&
-run slab256x64_ov OCNHIP_FORCE_DIST=1 $B --size 256 256 64 &&
-run slab256x64_noov OCNHIP_FORCE_DIST=1 OCNHIP_NO_OVERLAP=1 $B --size 256 256 64 &&
-run slab512_rk3_ov OCNHIP_FORCE_DIST=1 $B --size 512 512 32 --stepper RK3 --steps 60 &&
-run slab512_rk3_noov OCNHIP_FORCE_DIST=1 OCNHIP_NO_OVERLAP=1 $B --size 512 512 32 --stepper RK3 --steps 60
+run slab512_ov OCNHIP_FORCE_DIST=1 OCNHIP_OVERLAP=1 $B --size 512 512 32 &&
+run slab512_noov OCNHIP_FORCE_DIST=1 OCNHIP_OVERLAP=0 $B --size 512 512 32 &&
+run slab256_ov OCNHIP_FORCE_DIST=1 OCNHIP_OVERLAP=1 $B --size 256 256 128 &&
+run slab256_noov OCNHIP_FORCE_DIST=1 OCNHIP_OVERLAP=0 $B --size 256 256 128 &&
+run slab256x64_ov OCNHIP_FORCE_DIST=1 OCNHIP_OVERLAP=1 $B --size 256 256 64 &&
+run slab256x64_noov OCNHIP_FORCE_DIST=1 OCNHIP_OVERLAP=0 $B --size 256 256 64 &&
+run slab512_rk3_ov OCNHIP_FORCE_DIST=1 OCNHIP_OVERLAP=1 $B --size 512 512 32 --stepper RK3 --steps 60 &&
+run slab512_rk3_noov OCNHIP_FORCE_DIST=1 OCNHIP_OVERLAP=0 $B --size 512 512 32 --stepper RK3 --steps 60
 OCNHIP_TRANSPORT=shm OCNHIP_BENCH_NDEV=1 timeout -k 10 400 python bench.py --gpus 2 --steps 20 --warmup 3 > $O/bench_2ranks_1gpu_shm.json 2> $O/bench_2ranks_1gpu_shm.err; echo "2-rank rc=$?"
 python - <<PY
 import json
