@@ -1,0 +1,92 @@
+"""test/test_nonhydrostatic_models.jl of the reference on the oracle, the host emulation and the GPU:
+  * "Adjustment of halos in NonhydrostaticModel constructor" (:32-69): the model's grid has at least the halo its advection
+    scheme needs -- 1 (CenteredSecondOrder, the default), 2 (CenteredFourthOrder, UpwindBiasedThirdOrder), 3 (WENO5,
+    UpwindBiasedFifthOrder) -- on a (1, 1, 1)-cell grid with halo (1, 1, 1) and with the "funny" halo (1, 3, 4);
+  * "Setting model fields" (:84-161): arrays and functions land on the right nodes, update_state! leaves periodic and free-slip
+    halo values, and set!(u=0, v=0, w=1) comes back with |w| < 10 eps after the projection.
+ScalarBiharmonicDiffusivity and background fields (:63-69, :163-) are outside the path."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+EPS = np.finfo(float).eps
+
+
+def _lib(ocn, backend, gpu):
+    if gpu and backend != "gpu":
+        pytest.skip("HIP run only")
+    if not gpu and backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    return ocn
+
+
+def halo_adjustment(mod):
+    def halo_of(m):
+        return tuple(m.halo) if hasattr(m, "halo") else (m.grid.Hx, m.grid.Hy, m.grid.Hz)
+    for halo, need1, need2, need3 in [((1, 1, 1), (1, 1, 1), (2, 2, 2), (3, 3, 3)), ((1, 3, 4), (1, 3, 4), (2, 3, 4), (3, 3, 4))]:
+        def grid():
+            return mod.RectilinearGrid(size=(1, 1, 1), extent=(1, 2, 3), halo=halo)
+        assert halo_of(mod.NonhydrostaticModel(grid(), advection=mod.CenteredSecondOrder())) == need1
+        for scheme in (mod.CenteredFourthOrder(), mod.UpwindBiasedThirdOrder()):
+            assert halo_of(mod.NonhydrostaticModel(grid(), advection=scheme)) == need2
+        for scheme in (mod.WENO5(), mod.UpwindBiasedFifthOrder()):
+            assert halo_of(mod.NonhydrostaticModel(grid(), advection=scheme)) == need3
+
+
+def setting_model_fields(mod):
+    N, L = (4, 4, 4), (2 * np.pi, 3 * np.pi, 5 * np.pi)
+    g = mod.RectilinearGrid(size=N, extent=L, halo=(1, 1, 1))
+    m = mod.NonhydrostaticModel(g, advection=mod.CenteredSecondOrder(), buoyancy=mod.SeawaterBuoyancy(), tracers=("T", "S"))
+    rng = np.random.default_rng(8)
+    T0 = rng.random(N)
+    mod.set_model(m, enforce_incompressibility=False, T=T0)
+    assert np.allclose(m.tracers["T"].interior(), T0, rtol=1.5e-8, atol=0)
+    u0 = lambda x, y, z: 1 + x + y + z                    # noqa: E731
+    v0 = lambda x, y, z: 2 + np.sin(x * y * z)            # noqa: E731
+    w0 = lambda x, y, z: 3 + y * z + 0 * x                # noqa: E731
+    Tf = lambda x, y, z: 4 + np.tanh(x + y - z)           # noqa: E731
+    mod.set_model(m, enforce_incompressibility=False, u=u0, v=v0, w=w0, T=Tf, S=5.0)
+    dx, dy, dz = (L[d] / N[d] for d in range(3))
+    xC, yC = (np.arange(4) + 0.5) * dx, (np.arange(4) + 0.5) * dy
+    zC = -L[2] + (np.arange(4) + 0.5) * dz
+    xF, yF, zF = np.arange(4) * dx, np.arange(4) * dy, -L[2] + np.arange(5) * dz
+    g3 = lambda a, b, c: (a.reshape(-1, 1, 1), b.reshape(1, -1, 1), c.reshape(1, 1, -1))   # noqa: E731
+    ok = lambda a, b: np.allclose(a, b, rtol=1.5e-8, atol=0)                              # noqa: E731
+    assert ok(m.u.interior(), u0(*g3(xF, yC, zC)))
+    assert ok(m.v.interior(), v0(*g3(xC, yF, zC)))
+    assert ok(m.w.interior()[:, :, 1:4], w0(*g3(xC, yC, zF))[:, :, 1:4])
+    assert ok(m.tracers["T"].interior(), Tf(*g3(xC, yC, zC)))
+    assert ok(m.tracers["S"].interior(), 5.0)
+    # update_state! via the boundary conditions of u: parent index = reference index - 1 + H, H = 1
+    up = m.u.data if hasattr(m.u, "data") else m.u.parent()
+    assert up[1, 1, 1] == up[5, 1, 1] and up[1, 1, 1] == up[1, 5, 1]               # x / y periodicity
+    assert (up[1:5, 1:5, 1] == up[1:5, 1:5, 0]).all() and (up[1:5, 1:5, 4] == up[1:5, 1:5, 5]).all()   # free slip
+    mod.set_model(m, u=0.0, v=0.0, w=1.0, T=0.0, S=0.0)                               # enforce_incompressibility
+    assert (np.abs(m.w.interior()) < 10 * EPS).all()
+
+
+def test_halo_adjustment_oracle():
+    halo_adjustment(O)
+
+
+def test_halo_adjustment_library(ocn, backend):
+    halo_adjustment(_lib(ocn, backend, False))
+
+
+@pytest.mark.gpu
+def test_halo_adjustment_library_gpu(ocn, backend):
+    halo_adjustment(_lib(ocn, backend, True))
+
+
+def test_setting_model_fields_oracle():
+    setting_model_fields(O)
+
+
+def test_setting_model_fields_library(ocn, backend):
+    setting_model_fields(_lib(ocn, backend, False))
+
+
+@pytest.mark.gpu
+def test_setting_model_fields_library_gpu(ocn, backend):
+    setting_model_fields(_lib(ocn, backend, True))
