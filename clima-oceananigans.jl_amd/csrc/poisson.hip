@@ -448,10 +448,14 @@ __global__ void k_tridiag_setup(GridDev g, int Nxh, int Ny, int Nz, const double
     return -(up + lo) - g_dzc(g, k) * lam;
   };
   double beta = diag(0);
-  rb[col] = 1.0 / beta;
   t[col] = 0.0;
   int kbreak = Nz;
-  for (int k = 1; k < Nz; ++k) {
+  // A singular first pivot only happens for the horizontal-mean mode of a one-level column (lam = 0, Nz = 1: both faces are
+  // walls).  The FFT-based solver the reference uses on such a (regular) grid returns its gauge value 0 there
+  // (fft_based_poisson_solver.jl:113-114); so does this one: the level holds the stand-in 0 like every level past a break.
+  if (!(fabs(beta) > 10.0 * 2.220446049250313e-16)) kbreak = 0;
+  else rb[col] = 1.0 / beta;
+  for (int k = 1; k < Nz && kbreak > 0; ++k) {
     double off = g_rdzf(g, k);  // a^{k-1} = c^{k-1} = 1/dzf(k) (1-based face k+1 -> 0-based face k)
     double tk = off / beta;
     t[col + ncol * k] = tk;

@@ -90,3 +90,64 @@ def test_setting_model_fields_library(ocn, backend):
 @pytest.mark.gpu
 def test_setting_model_fields_library_gpu(ocn, backend):
     setting_model_fields(_lib(ocn, backend, True))
+
+
+# ---- test/test_time_stepping.jl:8-27, 262-303 ----------------------------------------------------------------------------
+FLAT_TOPOS = [("Flat", "Periodic", "Periodic"), ("Periodic", "Flat", "Periodic"), ("Periodic", "Periodic", "Flat"),
+              ("Flat", "Flat", "Bounded")]
+
+
+def flat_dimensions_step(mod, topo):
+    """time_stepping_works_with_flat_dimensions: one cell per non-Flat direction, one Euler step of dt = 1, no error, finite fields"""
+    n = sum(t != "Flat" for t in topo)
+    g = mod.RectilinearGrid(size=(1,) * n, extent=(1,) * n, topology=topo)
+    m = mod.NonhydrostaticModel(g, advection=mod.CenteredSecondOrder())
+    mod.time_step(m, 1.0, euler=True)
+    for f in (m.u, m.v, m.w):
+        assert np.isfinite(f.interior()).all()
+    assert m.iteration == 1 and m.time == 1.0
+
+
+def euler_step_ignores_nan_in_previous_tendency(mod):
+    """euler_time_stepping_doesnt_propagate_NaNs (the reference runs it on a HydrostaticFreeSurfaceModel; the AB2 rule it tests --
+    an Euler step zeroes G^- before using it, quasi_adams_bashforth_2.jl:74-84 -- is the same time stepper's)"""
+    g = mod.RectilinearGrid(size=(1, 1, 1), extent=(1, 2, 3))
+    m = mod.NonhydrostaticModel(g, advection=mod.CenteredSecondOrder(), buoyancy=mod.BuoyancyTracer(), tracers=("b",))
+    if mod is O:
+        m.Gm["u"].data[...] = np.nan
+    else:
+        gm = m.Gm["u"]                       # FieldView of G^-(u)
+        a = gm.parent()
+        a[...] = np.nan
+        gm.set_parent(a)
+    mod.time_step(m, 1.0, euler=True)
+    assert np.isfinite(m.u.interior()).all()
+
+
+@pytest.mark.parametrize("topo", FLAT_TOPOS, ids=["".join(t[0] for t in T) for T in FLAT_TOPOS])
+def test_flat_dimensions_oracle(topo):
+    flat_dimensions_step(O, topo)
+
+
+@pytest.mark.parametrize("topo", FLAT_TOPOS, ids=["".join(t[0] for t in T) for T in FLAT_TOPOS])
+def test_flat_dimensions_library(ocn, backend, topo):
+    flat_dimensions_step(_lib(ocn, backend, False), topo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("topo", FLAT_TOPOS, ids=["".join(t[0] for t in T) for T in FLAT_TOPOS])
+def test_flat_dimensions_library_gpu(ocn, backend, topo):
+    flat_dimensions_step(_lib(ocn, backend, True), topo)
+
+
+def test_euler_step_ignores_nan_oracle():
+    euler_step_ignores_nan_in_previous_tendency(O)
+
+
+def test_euler_step_ignores_nan_library(ocn, backend):
+    euler_step_ignores_nan_in_previous_tendency(_lib(ocn, backend, False))
+
+
+@pytest.mark.gpu
+def test_euler_step_ignores_nan_library_gpu(ocn, backend):
+    euler_step_ignores_nan_in_previous_tendency(_lib(ocn, backend, True))
