@@ -43,7 +43,7 @@ class ModelDesc(C.Structure):
                 ("coriolis_fplane", C.c_int32), ("f", C.c_double),
                 ("buoyancy", C.c_int32), ("b_index", C.c_int32), ("T_index", C.c_int32), ("S_index", C.c_int32),
                 ("g", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
-                ("bcs", (BC * 6) * (3 + MAX_TRACERS))]
+                ("bcs", (BC * 6) * (3 + MAX_TRACERS)), ("nu_bcs", BC * 6), ("kappa_bcs", (BC * 6) * MAX_TRACERS)]
 
 
 class OcnError(RuntimeError):
@@ -53,7 +53,7 @@ class OcnError(RuntimeError):
 _lib = None
 
 
-ABI_VERSION = 2   # OCN_ABI_VERSION of include/ocnhip.h
+ABI_VERSION = 3   # OCN_ABI_VERSION of include/ocnhip.h
 
 
 def lib_path():

@@ -356,23 +356,36 @@ class NonhydrostaticModel:
                 d.g, d.alpha, d.beta = buoyancy.g, buoyancy.alpha, buoyancy.beta
         self._keep = []
         names = ("u", "v", "w") + self.tracer_names
+        def fill(slot, side, bc):
+            b = slot[_SIDES[side]]
+            b.kind = bc.kind
+            if np.isscalar(bc.condition):
+                b.value = float(bc.condition)
+            else:
+                arr = np.asfortranarray(bc.condition, dtype=np.float64)
+                # arrays span the interior of the two directions tangential to the boundary
+                tang = tuple(n for a, n in enumerate(grid.N) if a != _SIDES[side] // 2)
+                if arr.shape != tang:
+                    raise ValueError(f"array boundary condition on side {side} must have shape {tang}")
+                self._keep.append(arr)
+                b.array = arr.ctypes.data_as(C.POINTER(C.c_double))
         for fname, sides in (boundary_conditions or {}).items():
+            if fname in ("nu_e", "kappa_e"):
+                # boundary_conditions = (; κₑ = (; b = FieldBoundaryConditions(...))) of the reference: the AMD diffusivity fields
+                if not isinstance(closure, AnisotropicMinimumDissipation):
+                    raise ValueError(f"boundary conditions for {fname} need a closure with diffusivity fields")
+                if fname == "nu_e":
+                    for side, bc in sides.items():
+                        fill(d.nu_bcs, side, bc)
+                else:
+                    for tname, tsides in sides.items():
+                        for side, bc in tsides.items():
+                            fill(d.kappa_bcs[self.tracer_names.index(tname)], side, bc)
+                continue
             if fname not in names:
                 raise ValueError(f"boundary conditions for unknown field {fname}")
-            fi = names.index(fname)
             for side, bc in sides.items():
-                b = d.bcs[fi][_SIDES[side]]
-                b.kind = bc.kind
-                if np.isscalar(bc.condition):
-                    b.value = float(bc.condition)
-                else:
-                    arr = np.asfortranarray(bc.condition, dtype=np.float64)
-                    # arrays span the interior of the two directions tangential to the boundary
-                    tang = tuple(n for a, n in enumerate(grid.N) if a != _SIDES[side] // 2)
-                    if arr.shape != tang:
-                        raise ValueError(f"array boundary condition on side {side} must have shape {tang}")
-                    self._keep.append(arr)
-                    b.array = arr.ctypes.data_as(C.POINTER(C.c_double))
+                fill(d.bcs[names.index(fname)], side, bc)
         self.desc = d
         self.h = C.c_void_p()
         check(self.lib.ocn_model_create(grid.h, C.byref(d), C.byref(self.h)), self.ctx.h)

@@ -886,10 +886,14 @@ int ocn_model_create(ocn_grid* g, const ocn_model_desc* desc, ocn_model** out) {
     for (int t = 0; t < m->nt; ++t) default_bcs(m, m->kappa_e[t], true);
   }
   // user boundary conditions
-  for (int f = 0; f < 3 + m->nt; ++f) {
-    Field* fld = f == 0 ? &m->u : f == 1 ? &m->v : f == 2 ? &m->w : &m->tr[f - 3];
+  // u, v, w, tracers, then -- AnisotropicMinimumDissipation only -- the diffusivity fields nu_e and kappa_e of every tracer
+  // (boundary_conditions = (; kappa_e = (; b = ...)) of the reference: nonhydrostatic_model.jl:150-160, test_boundary_conditions_integration.jl:52-66)
+  const int nbc = 3 + m->nt + (desc->closure == OCN_CLOSURE_AMD ? 1 + m->nt : 0);
+  for (int f = 0; f < nbc; ++f) {
+    const int fd = f - (3 + m->nt);   // index among the diffusivity fields
+    Field* fld = f == 0 ? &m->u : f == 1 ? &m->v : f == 2 ? &m->w : f < 3 + m->nt ? &m->tr[f - 3] : fd == 0 ? &m->nu_e : &m->kappa_e[fd - 1];
     for (int s = 0; s < 6; ++s) {
-      const ocn_bc& b = desc->bcs[f][s];
+      const ocn_bc& b = f < 3 + m->nt ? desc->bcs[f][s] : fd == 0 ? desc->nu_bcs[s] : desc->kappa_bcs[fd - 1][s];
       if (b.kind == OCN_BC_DEFAULT) continue;
       int dim = s / 2;
       if (g->topo[dim] != OCN_BOUNDED) {

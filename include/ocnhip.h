@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OCN_ABI_VERSION 2
+#define OCN_ABI_VERSION 3
 
 /* error codes */
 enum {
@@ -138,6 +138,10 @@ typedef struct ocn_model_desc {
   int32_t b_index, T_index, S_index; /* tracer indices used by the buoyancy model (-1: absent) */
   double g, alpha, beta; /* SeawaterBuoyancy(LinearEquationOfState)   */
   ocn_bc bcs[3 + OCN_MAX_TRACERS][6]; /* [field: u,v,w,tracers...][side] */
+  /* boundary conditions of the AMD diffusivity fields (boundary_conditions = (; nu_e = ..., kappa_e = (; T = ...)) in the
+   * reference: nonhydrostatic_model.jl:150-160); OCN_BC_DEFAULT (0) everywhere = the auxiliary-field defaults */
+  ocn_bc nu_bcs[6];
+  ocn_bc kappa_bcs[OCN_MAX_TRACERS][6];
 } ocn_model_desc;
 
 /* ---- context (Architectures.jl:53-142: device, array_type, arch_array, device_event) ---------- */

@@ -63,7 +63,7 @@ function ocn_grid(arch::ROCmGPU, grid::RectilinearGrid)
     return h[]
 end
 
-# `ocn_model_desc` (include/ocnhip.h; OCN_ABI_VERSION 2), field by field.  isbits, so it crosses ccall by reference.
+# `ocn_model_desc` (include/ocnhip.h; OCN_ABI_VERSION 3), field by field.  isbits, so it crosses ccall by reference.
 const MAXTR = 8
 struct BC; kind::Int32; value::Float64; array::Ptr{Float64}; end                       # ocn_bc
 struct ModelDesc
@@ -73,6 +73,7 @@ struct ModelDesc
     coriolis_fplane::Int32; f::Float64
     buoyancy::Int32; b_index::Int32; T_index::Int32; S_index::Int32; g::Float64; alpha::Float64; beta::Float64
     bcs::NTuple{3 + MAXTR, NTuple{6, BC}}                                               # [u, v, w, tracers...][west .. top]
+    nu_bcs::NTuple{6, BC}; kappa_bcs::NTuple{MAXTR, NTuple{6, BC}}                      # AMD diffusivity fields (model.diffusivity_fields)
 end
 
 adv_code(::Nothing) = Int32(0); adv_code(::CenteredSecondOrder) = Int32(1); adv_code(::CenteredFourthOrder) = Int32(2)
@@ -117,7 +118,9 @@ function ocn_model(arch::ROCmGPU, gridh, m)                                     
                      m.timestepper isa QuasiAdamsBashforth2TimeStepper ? m.timestepper.χ : 0.1, nt, closure, nu, kap, Cnu, Ck, Cb, hasCb,
                      m.coriolis === nothing ? 0 : 1, m.coriolis === nothing ? 0.0 : m.coriolis.f,
                      buoy, idx(:b), idx(:T), idx(:S), g, α, β,
-                     ntuple(i -> i <= length(fields) ? sides(fields[i]) : none, 3 + MAXTR))
+                     ntuple(i -> i <= length(fields) ? sides(fields[i]) : none, 3 + MAXTR),
+                     closure == 2 ? sides(m.diffusivity_fields.νₑ) : none,
+                     ntuple(i -> (closure == 2 && i <= nt) ? sides(m.diffusivity_fields.κₑ[i]) : none, MAXTR))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve keep check(ccall((:ocn_model_create, libocnhip), Cint, (Ptr{Cvoid}, Ref{ModelDesc}, Ref{Ptr{Cvoid}}), gridh, desc, h), arch.ctx)
     return h[]
@@ -205,10 +208,10 @@ kernel_path(model::RM) = (buf = Vector{UInt8}(undef, 256);
 # Distributed: MultiArch(ROCmGPU(); ranks=(1, 1, R)) -> ocn_comm_init(ctx, rank, R, id) with the 128-byte id of
 # ocn_comm_unique_id broadcast over MPI (Distributed/multi_architectures.jl:20-47); everything else is unchanged.
 # Launch-bound models (config 1) are replayed from hipGraphs inside ocn_time_step; ocn_model_graph_replays(handle, n, active)
-# reports it.  The library reports OCN_ABI_VERSION through ocn_abi_version(): __init__ compares it with 2.
+# reports it.  The library reports OCN_ABI_VERSION through ocn_abi_version(): __init__ compares it with 3.
 function __init__()
     v = ccall((:ocn_abi_version, libocnhip), Cint, ())
-    v == 2 || error("libocnhip reports ABI version $v; this shim is written for 2")
+    v == 3 || error("libocnhip reports ABI version $v; this shim is written for 3")
 end
 
 end # module

@@ -35,13 +35,17 @@ class AnisotropicMinimumDissipation:
 
 
 class Closure:
-    def __init__(self, model, closure):
+    def __init__(self, model, closure, boundary_conditions=None):
         self.m, self.c = model, closure
         self.nu_e, self.kappa_e = None, {}
         if isinstance(closure, AnisotropicMinimumDissipation):
+            # DiffusivityFields(grid, tracer_names, bcs, closure) (anisotropic_minimum_dissipation.jl:346-370): user boundary
+            # conditions for nu_e / kappa_e arrive as boundary_conditions = (; nu_e = ..., kappa_e = (; T = ...))
             g = model.grid
-            self.nu_e = Field(g, (Center,) * 3)
-            self.kappa_e = {n: Field(g, (Center,) * 3) for n in model.tracer_names}
+            bcs = boundary_conditions or {}
+            kb = bcs.get("kappa_e") or {}
+            self.nu_e = Field(g, (Center,) * 3, bcs.get("nu_e"))
+            self.kappa_e = {n: Field(g, (Center,) * 3, kb.get(n)) for n in model.tracer_names}
 
     def diffusivity_fields(self):
         if self.nu_e is None:

@@ -81,7 +81,7 @@ class NonhydrostaticModel:
         locs = {"u": self.u.loc, "v": self.v.loc, "w": self.w.loc}
         self.Gn = {n: Field(grid, locs.get(n, (Center,) * 3)) for n in names}
         self.Gm = {n: Field(grid, locs.get(n, (Center,) * 3)) for n in names}
-        self.closure_impl = Closure(self, closure)
+        self.closure_impl = Closure(self, closure, bcs)
         # PressureSolver (NonhydrostaticModels.jl:18-27)
         if grid.z_regular or grid.topo[2] == Flat:
             self.solver = FFTBasedPoissonSolver(grid)

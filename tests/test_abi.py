@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
     missing = [s for s in declared_symbols() if not hasattr(L, s)]
     assert not missing, missing
     L.ocn_abi_version.restype = ctypes.c_int
-    assert L.ocn_abi_version() == 2
+    assert L.ocn_abi_version() == 3
 
 
 def test_product_fails_loudly_without_library(monkeypatch, tmp_path):

@@ -151,3 +151,75 @@ def test_euler_step_ignores_nan_library(ocn, backend):
 @pytest.mark.gpu
 def test_euler_step_ignores_nan_library_gpu(ocn, backend):
     euler_step_ignores_nan_in_previous_tendency(_lib(ocn, backend, True))
+
+
+# ---- test/test_boundary_conditions_integration.jl:6-24, 194-205: time stepping with every kind of boundary condition -----------
+BC_CASES = [(kind, val, side) for kind in ("gradient", "flux", "value") for val in (1, float(np.pi), "array")
+            for side in ("east", "south", "top")]
+
+
+def boundary_condition_step(mod, kind, val, side):
+    """one cell, (Bounded, Bounded, Bounded), extent (1, pi, 42), T with one Gradient / Flux / Value condition given as an integer,
+    a float or a 1 x 1 array on the east, south or top side: an Euler step of 1e-16 runs and leaves finite fields (function
+    conditions are Julia closures: outside the C ABI)"""
+    ctor = {"flux": mod.FluxBC, "value": mod.ValueBC, "gradient": mod.GradientBC}[kind]
+    v = np.random.default_rng(2).random((1, 1)) if val == "array" else val
+    g = mod.RectilinearGrid(size=(1, 1, 1), extent=(1, np.pi, 42), topology=("Bounded",) * 3)
+    m = mod.NonhydrostaticModel(g, advection=mod.CenteredSecondOrder(), buoyancy=mod.SeawaterBuoyancy(), tracers=("T", "S"),
+                                boundary_conditions={"T": {side: ctor(v)}})
+    mod.time_step(m, 1e-16, euler=True)
+    for f in (m.u, m.v, m.w, m.tracers["T"], m.tracers["S"], m.pNHS):
+        assert np.isfinite(f.interior()).all()
+
+
+@pytest.mark.parametrize("kind,val,side", BC_CASES, ids=[f"{k}-{'arr' if v == 'array' else ('int' if v == 1 else 'pi')}-{s}" for k, v, s in BC_CASES])
+def test_boundary_condition_step_oracle(kind, val, side):
+    boundary_condition_step(O, kind, val, side)
+
+
+@pytest.mark.parametrize("kind,val,side", BC_CASES, ids=[f"{k}-{'arr' if v == 'array' else ('int' if v == 1 else 'pi')}-{s}" for k, v, s in BC_CASES])
+def test_boundary_condition_step_library(ocn, backend, kind, val, side):
+    boundary_condition_step(_lib(ocn, backend, False), kind, val, side)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,val,side", BC_CASES, ids=[f"{k}-{'arr' if v == 'array' else ('int' if v == 1 else 'pi')}-{s}" for k, v, s in BC_CASES])
+def test_boundary_condition_step_library_gpu(ocn, backend, kind, val, side):
+    boundary_condition_step(_lib(ocn, backend, True), kind, val, side)
+
+
+# ---- test/test_boundary_conditions_integration.jl:52-113, 266-274: custom diffusivity boundary conditions -----------------------
+def diffusivity_boundary_conditions(mod):
+    """AMD on a resting stratified fluid: kappa_e is zero in the interior, its bottom Value condition kappa0 makes the
+    diffusivity at the bottom face kappa0, and with the bottom Gradient condition bz on b the only flux into the domain is
+    -kappa0 bz: <b> changes by flux * t / Lz (atol 1e-6 in the reference; Float64 values quoted there: -3.141592656e-5 against
+    -3.141592654e-5)."""
+    Lz, kappa0, bz = 1.0, float(np.exp(-3)), float(np.pi)
+    flux = -kappa0 * bz
+    g = mod.RectilinearGrid(size=(16, 16, 16), extent=(1, 1, Lz), halo=(1, 1, 1))
+    m = mod.NonhydrostaticModel(g, advection=mod.CenteredSecondOrder(), tracers=("b",), buoyancy=mod.BuoyancyTracer(),
+                                closure=mod.AnisotropicMinimumDissipation(),
+                                boundary_conditions={"b": {"bottom": mod.GradientBC(bz)},
+                                                     "kappa_e": {"b": {"bottom": mod.ValueBC(kappa0)}}})
+    mod.set_model(m, b=lambda x, y, z: z * bz + 0 * (x + y))
+    mean0 = m.tracers["b"].interior().mean()
+    dt = 1e-6 * Lz ** 2 / kappa0
+    for n in range(10):
+        mod.time_step(m, dt, euler=(n == 0))
+    change = m.tracers["b"].interior().mean() - mean0
+    assert abs(change - flux * m.time / Lz) < 1e-6
+    assert abs(change - flux * m.time / Lz) < 1e-12          # what Float64 actually gives (the reference quotes 2.5e-15)
+    assert abs(mean0 - (-1.5707963267949192)) < 1e-13         # the mean the reference quotes for Float64 (summation order differs)
+
+
+def test_diffusivity_boundary_conditions_oracle():
+    diffusivity_boundary_conditions(O)
+
+
+def test_diffusivity_boundary_conditions_library(ocn, backend):
+    diffusivity_boundary_conditions(_lib(ocn, backend, False))
+
+
+@pytest.mark.gpu
+def test_diffusivity_boundary_conditions_library_gpu(ocn, backend):
+    diffusivity_boundary_conditions(_lib(ocn, backend, True))
