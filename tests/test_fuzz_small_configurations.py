@@ -86,3 +86,54 @@ def test_random_small_configuration(ocn, backend, seed):
 @pytest.mark.parametrize("seed", range(80))
 def test_random_small_configuration_gpu(ocn, seed):
     _run(ocn, seed)
+
+
+# ---- medium shapes: the tiled kernels' variants (row widths around the workgroup sizes, odd extents, x-tiles, walls, slabs) -----
+def random_medium_case(rng):
+    zt = str(rng.choice([P, B], p=[0.5, 0.5]))
+    xt, yt = (str(rng.choice([P, B], p=[0.8, 0.2])) for _ in range(2)) if zt == B else (P, P)
+    nx = int(rng.choice([16, 31, 32, 57, 64, 65, 100, 127, 128, 129, 192, 255, 256, 257, 300, 384]))
+    size = (nx, int(rng.integers(6, 28)), int(rng.integers(6, 26)))
+    cfg = dict(size=size, topo=(xt, yt, zt), extent=(1.0, 0.8, 0.6), adv=str(rng.choice(["WENO5", "WENO5JS", "U5"])),
+               stepper=str(rng.choice(["AB2", "RK3"])), steps=2, dt=2e-3 / nx * 16)
+    ntr = int(rng.integers(0, 3))
+    closure = str(rng.choice(["none", "scalar", "amd"], p=[0.4, 0.35, 0.25]))
+    if ntr == 2 and zt == B and rng.random() < 0.6:
+        cfg["tracers"], cfg["buoyancy"] = ("T", "S"), "TS"
+    elif ntr:
+        cfg["tracers"] = tuple("ab"[:ntr])
+    if closure == "scalar":
+        cfg["closure"] = (1e-3, 2e-3)
+    elif closure == "amd":
+        cfg["closure"] = "amd"
+    if rng.random() < 0.4:
+        cfg["coriolis"] = 0.1
+    if zt == B and rng.random() < 0.5:      # stretched z
+        f = np.sort(rng.random(size[2] - 1)) * 0.6 - 0.6
+        cfg["zfaces"] = [-0.6] + [float(v) for v in f] + [0.0]
+        cfg["xy"] = ((0, 1.0), (0, 0.8))
+        del cfg["extent"]
+        if min(np.diff(cfg["zfaces"])) < 1e-3:
+            cfg["zfaces"] = list(np.linspace(-0.6, 0, size[2] + 1))
+    if zt == B and rng.random() < 0.5:
+        cfg["bcs"] = {"u": {"top": ("flux", -1e-3)}}
+        if "tracers" in cfg:
+            cfg["bcs"][cfg["tracers"][0]] = {"top": ("flux", 2e-3), "bottom": ("gradient", 0.01)}
+    return cfg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(40))
+def test_random_medium_configuration_gpu(ocn, seed, monkeypatch):
+    rng = np.random.default_rng(5000 + seed)
+    cfg = random_medium_case(rng)
+    if cfg["topo"] == (P, P, P) and rng.random() < 0.4 and cfg["size"][2] >= 8:
+        monkeypatch.setenv("OCNHIP_FORCE_DIST", "1")      # the slab code path, with the halo planes on the communication stream
+        monkeypatch.setenv("OCNHIP_OVERLAP", "1")
+    pc.CASES["_fuzz"] = cfg
+    try:
+        worst = pc.run_case(ocn, "_fuzz")
+        bad = {k: v for k, v in worst.items() if not v <= 5e-10}
+        assert not bad, (cfg, bad)
+    finally:
+        pc.CASES.pop("_fuzz", None)
