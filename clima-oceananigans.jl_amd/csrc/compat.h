@@ -39,6 +39,9 @@ static inline void ocn_launch_sync(K kern, dim3 grid, dim3 block, hipStream_t s,
 }
 #define OCN_SHARED __shared__
 #define OCN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// an opaque use of three loaded values: the compiler must have them in registers at this point of every path (it places
+// the s_waitcnt of their loads here instead of wherever their registers are next written)
+#define OCN_TOUCH3(a, b, c) asm volatile("" ::"v"(a), "v"(b), "v"(c))
 
 // ---- wave-level primitives of the tiled kernels ----------------------------------------------------------------------
 // 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4: no VGPR round trip): lane l of the
@@ -95,6 +98,7 @@ extern std::recursive_mutex g_emu_launch_mutex;   // one emulated kernel at a ti
 #define OCN_DEVFN inline
 #define OCN_SHARED static
 #define OCN_SCHED_FENCE() ((void)0)
+#define OCN_TOUCH3(a, b, c) ((void)0)
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };

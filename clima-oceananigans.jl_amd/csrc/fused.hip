@@ -263,50 +263,35 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
     commit(0);
     prefetch(k0 + 1);                       // k1 > k0, and level k1 is staged too: its w feeds the last bottom fluxes
   }
+  // Order of a level (round 3).  vmcnt counts loads and stores together and, once both kinds are outstanding, can only be
+  // waited to zero; the level of round 2 ended with the z-window loads of the next level and the six stores of the update,
+  // so every wave sat out a full memory round trip in front of the barrier -- all of them at the same time (rocprofv3:
+  // VALU busy 79 %).  Now: every load a level needs (G^-, rest terms, the NEXT level's window entries) is issued right after
+  // the barrier; the z reconstructions come first and the update of level k-1 -- the only consumer of those loads -- follows,
+  // with its stores issued BEFORE the slab DMA of level k+1 and the long x / y flux stage, under which both complete; the
+  // window shift at the end is register moves only.
   for (int k = k0; k <= k1; ++k) {
     const int kb = (k - k0) & 1;
     const unsigned c = cxy + (unsigned)k * szb;
     const bool last = (k == k1);
     __syncthreads();                        // the one barrier of the level (with DMA in flight it also waits for vmcnt(0))
-    if (!last) {                            // stage level k+1 (up to k1) into the buffer level k-1 was read from
-      if (DMA) dma(k + 1, kb ^ 1);
-      else {
-        commit(kb ^ 1);
-        if (k + 2 <= k1) prefetch(k + 2);
-      }
+    if (!last && !DMA) {                    // register staging: level k+1 into the buffer level k-1 was read from
+      commit(kb ^ 1);
+      if (k + 2 <= k1) prefetch(k + 2);
     }
-    prio_start(a.prio, sty, BY);
-    const double* S = lds + kb * SLAB + ty * SX + tx;     // lowest corner of this thread's stencil footprint; own cell at (3, 3)
-    double gm0 = 0, gm1 = 0, gm2 = 0, rs0 = 0, rs1 = 0, rs2 = 0;
-    if (REST && full && k > k0) {
-      rs0 = ldo(a.gnu, c - szb);
-      rs1 = ldo(a.gnv, c - szb);
-      rs2 = ldo(a.gnw, c - szb);
-    }
-    if (a.use_m && full && k > k0) {
-      gm0 = ldo(a.gmu, c - szb);
-      gm1 = ldo(a.gmv, c - szb);
-      gm2 = ldo(a.gmw, c - szb);
-    }
-    // complete the horizontal divergence of level k-1 with the neighbours' fluxes (complete since the barrier)
-    if (full && k > k0) {
-      const double* fyp = fyb + (kb ^ 1) * 3 * T;
-      hu = fma(fyp[0 * T + nid_n], rdy, hu);
-      hv = fma(fyp[1 * T + nid_n], rdy, hv);
-      hw = fma(fyp[2 * T + nid_n], rdy, hw);
-      if (xedge) {
-        const double* fxp = fxe + (kb ^ 1) * 3 * BY * NW;
-        hu = fma(fxp[0 * BY * NW + eidx], rdx, hu);
-        hv = fma(fxp[1 * BY * NW + eidx], rdx, hv);
-        hw = fma(fxp[2 * BY * NW + eidx], rdx, hw);
-      }
-    }
+    // Loads are unconditional inside their region and every loaded value is used on every path (clamped addresses where
+    // the value is not needed: first level of a march, steps without G^-, last level): a register that may still have a
+    // load in flight when it is next written makes the compiler drain vmcnt to zero in the middle of the level.
+    const unsigned cnx = last ? c : c + 3 * szb;       // the window entries level k+1 will need on top
+    double znu, znv, znw;
     constexpr bool visc = VISC;   // compile-time: the inviscid kernel must not pay registers for these terms
     double wxm = 0, wym = 0;
     if (visc && !last) {
       wxm = ldo(a.w, c + szb - sxb);
       wym = ldo(a.w, c + szb - syb);
     }
+    prio_start(a.prio, sty, BY);
+    const double* S = lds + kb * SLAB + ty * SX + tx;     // lowest corner of this thread's stencil footprint; own cell at (3, 3)
     // idx: the reference's 1-based index of the evaluation point along z (face k+1 for the bottom face of level k,
     // centre k for the w flux below face k); all conditions are uniform over the workgroup
     auto symz_at = [&](const double* z, int idx) {
@@ -345,6 +330,79 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
                               : rec_v(SLB(f, 3, 0), SLB(f, 3, 1), SLB(f, 3, 2), SLB(f, 3, 3), SLB(f, 3, 4), SLB(f, 3, 5), ut))
 #define YREC(f, ut, idx) ((wy && !in_rec((ut) > 0.0, idx, g.Ny)) ? 0.5 * (SLB(f, 2, 3) + SLB(f, 3, 3)) \
                               : rec_v(SLB(f, 0, 3), SLB(f, 1, 3), SLB(f, 2, 3), SLB(f, 3, 3), SLB(f, 4, 3), SLB(f, 5, 3), ut))
+    // ---- bottom-face fluxes of level k (= top-face fluxes of level k-1), then the update of level k-1 --------------------
+    if (full) {
+      const bool upd = k > k0;
+      const unsigned cm1 = upd ? c - szb : c;         // level k-1 (first level of a march: nothing to update, loads unused)
+      double rs0 = 0, rs1 = 0, rs2 = 0;
+      if (REST) {
+        rs0 = ldo(a.gnu, cm1);
+        rs1 = ldo(a.gnv, cm1);
+        rs2 = ldo(a.gnw, cm1);
+      }
+      const unsigned cgm = a.use_m ? cm1 : a.org;     // without G^- (Euler start, first RK3 stage): one cached element
+      double gm0 = ldo(a.gmu, cgm), gm1 = ldo(a.gmv, cgm), gm2 = ldo(a.gmw, cgm);
+      znu = ldo(a.u, cnx);
+      znv = ldo(a.v, cnx);
+      znw = ldo(a.w, cnx);
+      double wtu = XSYM(2, ix);
+      double Fwu = wtu * reconz(zu, wtu);
+      double wtv = YSYM(2, jy);
+      double Fwv = wtv * reconz(zv, wtv);
+      double wtw = symz_at(zw, k);                    // centre below face k
+      double Fww = wtw * reconz_at(zw, wtw, k);
+      if (visc) {
+        Fwu -= a.nu * (zu[3] - zu[2]) * rdz;
+        Fwv -= a.nu * (zv[3] - zv[2]) * rdz;
+        const double dwz = (zw[3] - zw[2]) * rdz;
+        Fww -= a.nu * (dwz + dprev);                    // dprev = div U at (i, j, k-1)
+        if (!last) dprev = (SLB(0, 3, 4) - SLB(0, 3, 3)) * rdx + (SLB(1, 4, 3) - SLB(1, 3, 3)) * rdy + (zw[4] - zw[3]) * rdz;
+      }
+      // complete the horizontal divergence of level k-1 with the neighbours' fluxes (complete since the barrier)
+      const double* fyp = fyb + (kb ^ 1) * 3 * T;
+      hu = fma(fyp[0 * T + nid_n], rdy, hu);
+      hv = fma(fyp[1 * T + nid_n], rdy, hv);
+      hw = fma(fyp[2 * T + nid_n], rdy, hw);
+      if (xedge) {
+        const double* fxp = fxe + (kb ^ 1) * 3 * BY * NW;
+        hu = fma(fxp[0 * BY * NW + eidx], rdx, hu);
+        hv = fma(fxp[1 * BY * NW + eidx], rdx, hv);
+        hw = fma(fxp[2 * BY * NW + eidx], rdx, hw);
+      }
+      const int km = upd ? k - 1 : k;
+      const double rzc = ZB ? g_rdzc(g, km) : rdz, rzf = ZB ? g_rdzf(g, km) : rdz;
+      const double Gu = rs0 - (hu + (Fwu - bu) * rzc);
+      const double Gv = rs1 - (hv + (Fwv - bv) * rzc);
+      const double Gw = rs2 - (hw + (Fww - bw) * rzf);
+      OCN_TOUCH3(gm0, gm1, gm2);                      // the loads land HERE on every path (see above), G^- used or not
+      double iu, iv, iw;
+      if (a.use_m) {
+        iu = a.dt * (a.cn * Gu + a.cm * gm0);
+        iv = a.dt * (a.cn * Gv + a.cm * gm1);
+        iw = a.dt * (a.cn * Gw + a.cm * gm2);
+      } else {
+        iu = a.dt * a.cn * Gu;
+        iv = a.dt * a.cn * Gv;
+        iw = a.dt * a.cn * Gw;
+      }
+      if (upd) {                                      // all six stores together, after the last use of a loaded value
+        sto(a.gnu, cm1, Gu);
+        sto(a.gnv, cm1, Gv);
+        sto(a.gnw, cm1, Gw);
+        sto(a.us, cm1, zu[2] + iu);
+        sto(a.vs, cm1, zv[2] + iv);
+        sto(a.ws, cm1, zw[2] + iw);
+      }
+      bu = Fwu;
+      bv = Fwv;
+      bw = Fww;
+    } else {
+      znu = ldo(a.u, cnx);
+      znv = ldo(a.v, cnx);
+      znw = ldo(a.w, cnx);
+    }
+    if (DMA && !last) dma(k + 1, kb ^ 1);    // level k+1 (up to k1) into the buffer level k-1 was read from; lands under the flux stage
+    // ---- west- and south-face fluxes of level k --------------------------------------------------------------------------
     double f0 = 0, f1 = 0, f2 = 0;            // fluxes through the west faces of this thread's u, v, w cells (level k)
     double s0 = 0, s1 = 0, s2 = 0;            // ... through the south faces
     if (!last) {
@@ -380,83 +438,34 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
         fyn[2 * T + tid] = s2;
       }
     }
-    double Fwu = 0, Fwv = 0, Fww = 0;
-    if (full) {
-      double wtu = XSYM(2, ix);
-      Fwu = wtu * reconz(zu, wtu);
-      double wtv = YSYM(2, jy);
-      Fwv = wtv * reconz(zv, wtv);
-      double wtw = symz_at(zw, k);                    // centre below face k
-      Fww = wtw * reconz_at(zw, wtw, k);
-      if (visc) {
-        Fwu -= a.nu * (zu[3] - zu[2]) * rdz;
-        Fwv -= a.nu * (zv[3] - zv[2]) * rdz;
-        const double dwz = (zw[3] - zw[2]) * rdz;
-        Fww -= a.nu * (dwz + dprev);                    // dprev = div U at (i, j, k-1)
-        if (!last) dprev = (SLB(0, 3, 4) - SLB(0, 3, 3)) * rdx + (SLB(1, 4, 3) - SLB(1, 3, 3)) * rdy + (zw[4] - zw[3]) * rdz;
-      }
-    }
 #undef XSYM
 #undef YSYM
 #undef XREC
 #undef YREC
-    // east fluxes: the next lane's west fluxes (uniform control flow: every lane of every wave takes part)
-    double e0 = 0, e1 = 0, e2 = 0;
     if (!last) {
-      e0 = ocn_shfl_next(f0);
-      e1 = ocn_shfl_next(f1);
-      e2 = ocn_shfl_next(f2);
+      // east fluxes: the next lane's west fluxes (uniform control flow: every lane of every wave takes part)
+      const double e0 = ocn_shfl_next(f0), e1 = ocn_shfl_next(f1), e2 = ocn_shfl_next(f2);
       if (tx % WV == 0 && do_x) {
         double* fxn = fxe + kb * 3 * BY * NW + ty * NW + tx / WV;
         fxn[0 * BY * NW] = f0;
         fxn[1 * BY * NW] = f1;
         fxn[2 * BY * NW] = f2;
       }
-    }
-    if (full) {
-      if (k > k0) {
-        const unsigned cm1 = c - szb;
-        const double rzc = ZB ? g_rdzc(g, k - 1) : rdz, rzf = ZB ? g_rdzf(g, k - 1) : rdz;
-        double Gu = rs0 - (hu + (Fwu - bu) * rzc);
-        double Gv = rs1 - (hv + (Fwv - bv) * rzc);
-        double Gw = rs2 - (hw + (Fww - bw) * rzf);
-        sto(a.gnu, cm1, Gu);
-        sto(a.gnv, cm1, Gv);
-        sto(a.gnw, cm1, Gw);
-        double iu, iv, iw;
-        if (a.use_m) {
-          iu = a.dt * (a.cn * Gu + a.cm * gm0);
-          iv = a.dt * (a.cn * Gv + a.cm * gm1);
-          iw = a.dt * (a.cn * Gw + a.cm * gm2);
-        } else {
-          iu = a.dt * a.cn * Gu;
-          iv = a.dt * a.cn * Gv;
-          iw = a.dt * a.cn * Gw;
-        }
-        sto(a.us, cm1, zu[2] + iu);
-        sto(a.vs, cm1, zv[2] + iv);
-        sto(a.ws, cm1, zw[2] + iw);
-      }
-      if (!last) {
+      if (full) {
         // (east - west) / dx - south / dy now; north / dy (and east / dx on x-edge lanes) after the next barrier
         hu = fma(xedge ? -f0 : e0 - f0, rdx, -s0 * rdy);
         hv = fma(xedge ? -f1 : e1 - f1, rdx, -s1 * rdy);
         hw = fma(xedge ? -f2 : e2 - f2, rdx, -s2 * rdy);
-        bu = Fwu;
-        bv = Fwv;
-        bw = Fww;
       }
-    }
-    if (!last) {
 #pragma unroll
       for (int q = 0; q < 5; ++q) {
         zu[q] = zu[q + 1];
         zv[q] = zv[q + 1];
         zw[q] = zw[q + 1];
       }
-      zu[5] = ldo(a.u, c + 3 * szb);
-      zv[5] = ldo(a.v, c + 3 * szb);
-      zw[5] = ldo(a.w, c + 3 * szb);
+      zu[5] = znu;
+      zv[5] = znv;
+      zw[5] = znw;
     }
   }
   }  // segments

@@ -24,6 +24,16 @@ def pytest_configure(config):
             os.environ["OCNHIP_LIB"] = os.path.abspath(alt)
     else:
         os.environ["OCNHIP_LIB"] = HOSTEMU
+        # The CPU suite is ~540 small, independent runs (oracle, host emulation, 2-3 process gloo / shm jobs with their own free
+        # ports and pid-named mailboxes): spread them over four pytest-xdist workers unless the caller chose -n / -p no:xdist.
+        # `-m gpu` runs stay in ONE process (one context on the card, and the driver records which .so that process loaded).
+        opt = config.option
+        if (config.pluginmanager.hasplugin("xdist") and getattr(opt, "numprocesses", None) is None
+                and not hasattr(config, "workerinput") and not getattr(opt, "collectonly", False)
+                and not getattr(opt, "usepdb", False) and os.environ.get("OCNHIP_TEST_SERIAL") != "1"):
+            opt.numprocesses = min(4, os.cpu_count() or 1)
+            opt.dist = "load"
+            opt.tx = ["popen"] * opt.numprocesses
 
 
 @pytest.fixture(scope="session")

@@ -201,50 +201,8 @@ def test_passive_tracer_advection(stepper):
     assert rel < 1e-4
 
 
-# ---- WENO5 fifth-order convergence, 1-D (one_dimensional_advection_schemes.jl) -----------------
-def _gauss(x, t, U, kap, t0):
-    return 1 / np.sqrt(4 * np.pi * kap * (t + t0)) * np.exp(-(x - U * t) ** 2 / (4 * kap * (t + t0)))
-
-
-def _advect_1d(Nx, dt, scheme, axis, U=1.0, kap=1e-8, width=0.05):
-    t0 = width ** 2 / (4 * kap)
-    size, dom = [1, 1, 1], [(0, 1), (0, 1), (0, 1)]
-    size[axis], dom[axis] = Nx, (-1, 1.5)
-    g = O.RectilinearGrid(size=size, x=dom[0], y=dom[1], z=dom[2], halo=(3, 3, 3), topology=(P, P, P))
-    m = O.NonhydrostaticModel(g, advection=scheme, timestepper="RungeKutta3", tracers=("c",),
-                              closure=O.ScalarDiffusivity(nu=kap, kappa=kap))
-    prof = lambda x, y, z: _gauss((x, y, z)[axis], 0, U, kap, t0) + 0 * (x + y + z)   # noqa: E731
-    names = ["u", "v", "w"]
-    init = {n: prof for n in names}
-    init[names[axis]] = U
-    O.set_model(m, c=prof, **init)
-    O.time_step(m, dt)
-    xs = (g.xnodes, g.ynodes, g.znodes)[axis](O.Center)
-    ca = _gauss(xs, m.time, U, kap, t0)
-    out = {}
-    for n, f in (("c", m.tracers["c"]), ("u", m.u), ("v", m.v), ("w", m.w)):
-        if n == names[axis]:
-            continue
-        out[n] = np.mean(np.abs(f.interior().ravel() - ca))
-    return out
-
-
-@pytest.mark.parametrize("scheme,order,tol", [(O.WENO5(), 5, 0.4), (O.UpwindBiasedFifthOrder(), 5, 0.2),
-                                              (O.CenteredFourthOrder(), 4, 0.06), (O.CenteredSecondOrder(), 2, 0.02),
-                                              (O.UpwindBiasedThirdOrder(), 3, 0.1), (O.UpwindBiasedFirstOrder(), 1, 0.2)])
-def test_advection_scheme_convergence(scheme, order, tol):
-    U, kap = 1.0, 1e-8
-    h = 2.5 / 512
-    dt = min(0.01 * h / U, 0.1 * h ** 2 / kap)
-    errs = {N: [_advect_1d(N, dt, scheme, ax) for ax in range(3)] for N in (384, 512)}
-    for ax in range(3):
-        for name in errs[512][ax]:
-            rate = np.log(errs[512][ax][name] / errs[384][ax][name]) / np.log(512 / 384)
-            assert abs(rate + order) < tol, (ax, name, rate)
-    # directional symmetry: cx ~ cy ~ cz, uy ~ uz, vx ~ vz, wx ~ wy
-    e = errs[512]
-    assert np.isclose(e[0]["c"], e[1]["c"]) and np.isclose(e[0]["c"], e[2]["c"])
-    assert np.isclose(e[1]["u"], e[2]["u"]) and np.isclose(e[0]["v"], e[2]["v"]) and np.isclose(e[0]["w"], e[1]["w"])
+# WENO5 / U5 / C4 / C2 / U3 convergence orders (one_dimensional_advection_schemes.jl): tests/test_reference_convergence.py,
+# on the oracle AND through the library.
 
 
 # ---- AMD closure: vanishes for laminar flows (pure strain, uniform shear), positive for a turbulent-like field --

@@ -1,53 +1,54 @@
-"""Summarises gpurun_out/prof_final/ (tools/collect_profiles.sh) into profiles/:
-   <tag>_kernel_stats.csv (copied), <tag>_pmc_traffic_raw.json (per-kernel FETCH_SIZE / WRITE_SIZE, KB per launch),
-   r01_traffic.json (what bench.py reads for roofline.traffic).
+"""Summarises the separate `rocprofv3 --pmc` passes of tools/gpu_run.sh (`pmc:<name>`) per kernel:
 
-FETCH_SIZE under-reports on gfx950 by a factor that depends on the bytes per lane of the loads; it is calibrated on
-kernels whose read volume is known exactly (k_zsolve256 / k_project: 16 B per lane -> x1.99; 8 B per lane -> x1.54),
-as measured in round 1 (profiles/r01_pmc_notes.md).  WRITE_SIZE needs no correction.
+    python tools/summarize_pmc.py gpurun_out/<tag> <name> [cells_per_launch]  > profiles/rNN_<name>_pmc.json
+
+For every kernel: launches seen, the average per launch of each counter, and for kernels with both traffic counters the
+HBM-side bytes per launch as MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE come in KB from
+separate passes; on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane streaming reads, so the read side is doubled
+(an upper bound for the 8-B-per-lane loads mixed in: round 1 calibrated x1.54 for those, `traffic_bytes_8B_calibration`);
+WRITE_SIZE is exact.  SQ counters count quad-cycles; only their ratios are used.
 """
 import csv
 import glob
 import json
 import os
-import shutil
 import sys
 from collections import defaultdict
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "prof_final")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+CAL8 = 1.5403810697802829      # 8 B per lane loads (profiles/r01_pmc_notes.md)
 
 
-def per_kernel(counter):
-    f = glob.glob(os.path.join(src, f"pmc_{counter}_counter_collection.csv"))
-    tot, cnt = defaultdict(float), defaultdict(int)
-    seen = set()
-    for row in csv.DictReader(open(f[0])):
-        if row["Counter_Name"] != counter:
-            continue
-        name = row["Kernel_Name"].split("(")[0]
-        tot[name] += float(row["Counter_Value"])
-        key = (name, row.get("Dispatch_Id"))
-        if key not in seen:
-            seen.add(key)
-            cnt[name] += 1
-    return {k: tot[k] / max(cnt[k], 1) for k in tot}
+def main():
+    out_dir, name = sys.argv[1], sys.argv[2]
+    cells = float(sys.argv[3]) if len(sys.argv) > 3 else 256.0 ** 3
+    tot = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(set))
+    for f in glob.glob(os.path.join(out_dir, f"{name}_*", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"].split("(")[0]
+            c = row["Counter_Name"]
+            tot[k][c] += float(row["Counter_Value"])
+            cnt[k][c].add(row.get("Dispatch_Id"))
+    res = {}
+    for k in sorted(tot):
+        e = {"launches": max(len(s) for s in cnt[k].values())}
+        for c in sorted(tot[k]):
+            e[c] = tot[k][c] / max(len(cnt[k][c]), 1)
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            e["traffic_bytes_per_launch"] = 2.0 * e["FETCH_SIZE"] * 1024 + e["WRITE_SIZE"] * 1024
+            e["traffic_bytes_8B_calibration"] = CAL8 * e["FETCH_SIZE"] * 1024 + e["WRITE_SIZE"] * 1024
+        if "SQ_INSTS_VALU" in e:
+            e["SQ_INSTS_VALU_per_64_cells"] = e["SQ_INSTS_VALU"] / (cells / 64.0)
+        if "SQ_ACTIVE_INST_VALU" in e and e.get("SQ_WAVE_CYCLES"):
+            # a SIMD issues one VALU instruction at a time: with 4 resident waves per SIMD (k_tend4: 16 waves per CU) its VALU
+            # is busy 4 x (VALU-active wave cycles / wave cycles) of the time -- the figure round 2 reported as "VALU busy"
+            e["valu_busy_frac_at_4_waves_per_simd"] = 4.0 * e["SQ_ACTIVE_INST_VALU"] / e["SQ_WAVE_CYCLES"]
+        if "SQ_WAIT_ANY" in e and e.get("SQ_WAVE_CYCLES"):
+            e["wait_any_frac_of_wave_cycles"] = e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]
+        res[k] = e
+    json.dump({"source": f"rocprofv3 --pmc (separate passes) of bench.py --steps 3 --warmup 1, {out_dir} {name}",
+               "kernels": res}, sys.stdout, indent=1)
 
 
-fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
-raw = {k: {"FETCH_SIZE_KB": fetch.get(k, 0.0), "WRITE_SIZE_KB": write.get(k, 0.0)} for k in sorted(set(fetch) | set(write))}
-json.dump(raw, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_raw.json"), "w"), indent=1)
-shutil.copy(os.path.join(src, "trace_kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
-
-CAL8 = 1.5403810697802829      # 8 B per lane loads (round-1 calibration)
-tend = [k for k in raw if "k_tend_step3" in k][0]
-traffic = raw[tend]["FETCH_SIZE_KB"] * 1024 * CAL8 + raw[tend]["WRITE_SIZE_KB"] * 1024
-out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 3, build {tag}",
-       "read_calibration": {"8B_per_lane": CAL8, "note": "see profiles/r01_pmc_notes.md"},
-       "kernels": {"fused_tendency_step": {"kernel": tend, "FETCH_SIZE_KB": raw[tend]["FETCH_SIZE_KB"],
-                                           "WRITE_SIZE_KB": raw[tend]["WRITE_SIZE_KB"],
-                                           "traffic_bytes_per_launch": traffic,
-                                           "algorithmic_bytes_per_launch": 96 * 256 ** 3}}}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r01_traffic.json"), "w"), indent=1)
-print(json.dumps(out["kernels"], indent=1))
+if __name__ == "__main__":
+    main()
