@@ -274,3 +274,30 @@ def run_case(ocn, name, check_each_step=True):
             compare(f"step{s}")
     assert abs(om.time - dm.time) < 1e-14 and om.iteration == dm.iteration
     return worst
+
+
+def run_config1(ocn, dt, steps, N=(128, 128)):
+    """BASELINE config 1 at its own size: examples/two_dimensional_turbulence.jl:26-31,42-50 -- 128 x 128 (Periodic, Periodic,
+    Flat), 2 pi box, RungeKutta3, ScalarDiffusivity(nu = 1e-5), WENO5 in place of the script's UpwindBiasedFifthOrder, u, v ~
+    U[0, 1) minus their means (PCG64(20240601)), then set!'s projection -- through the library and through the oracle,
+    every parent array compared after every step.  Returns the library's model."""
+    rng = np.random.Generator(np.random.PCG64(20240601))
+    u0, v0 = rng.random(N + (1,)), rng.random(N + (1,))
+    u0 -= u0.mean()
+    v0 -= v0.mean()
+    kw = dict(size=N, extent=(2 * np.pi, 2 * np.pi), topology=(P, P, F))
+    mk = lambda mod: mod.NonhydrostaticModel(mod.RectilinearGrid(**kw), advection=mod.WENO5(), timestepper="RungeKutta3",   # noqa: E731
+                                             closure=mod.ScalarDiffusivity(nu=1e-5))
+    m, om = mk(ocn), mk(O)
+    ocn.set_model(m, u=u0, v=v0)
+    O.set_model(om, u=u0, v=v0)
+    for step in range(steps):
+        ocn.time_step(m, dt)
+        O.time_step(om, dt)
+        a, b = fields_of(om, True), fields_of(m, False)
+        for k in a:
+            assert a[k].shape == b[k].shape
+            assert np.abs(a[k] - b[k]).max() <= 2e-11 * max(np.abs(a[k]).max(), 1e-300), (step, k)
+    assert abs(om.time - m.time) < 1e-14 and om.iteration == m.iteration == steps
+    assert m.max_abs_divergence() <= 1e-12 * np.abs(u0).max() / (2 * np.pi / N[0]) * 50
+    return m

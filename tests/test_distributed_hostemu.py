@@ -35,9 +35,23 @@ def run_ranks(ocn, R, fn):
 @pytest.mark.parametrize("R,stepper,adv,nzl", [(2, "AB2", "WENO5", 8), (2, "RK3", "WENO5", 8), (2, "AB2", "C2", 8), (4, "AB2", "WENO5", 8),
                                                (4, "AB2", "C2", 8), (2, "AB2", "WENO5", 10), (2, "RK3", "WENO5", 11), (3, "AB2", "WENO5", 9)])
 def test_slab_trajectory_matches_single_domain_oracle(ocn, backend, R, stepper, adv, nzl, monkeypatch):
+    _slab_trajectory(ocn, backend, R, stepper, adv, nzl, monkeypatch)
+
+
+# The target machine: R = 8 (BASELINE config 4 is 512 x 512 x 256 in eight z-slabs).  Slabs of exactly 9 and of 8 levels sit on
+# either side of the overlap split's limit (more than 2 H + 2 = 8 levels: interior levels start while the halo planes travel),
+# AB2 and RK3 + tracer, with the Green's-function z stage and with the all-to-all transposed one.
+@pytest.mark.parametrize("solver", ["green", "transpose"])
+@pytest.mark.parametrize("stepper,nzl", [("AB2", 9), ("RK3", 9), ("AB2", 8), ("RK3", 8)])
+def test_eight_rank_slabs_match_single_domain_oracle(ocn, backend, stepper, nzl, solver, monkeypatch):
+    monkeypatch.setenv("OCNHIP_DIST_SOLVER", solver)
+    _slab_trajectory(ocn, backend, 8, stepper, "WENO5", nzl, monkeypatch, overlap=True)
+
+
+def _slab_trajectory(ocn, backend, R, stepper, adv, nzl, monkeypatch, overlap=None):
     if backend != "hostemu":
         pytest.skip("host-emulation run only")
-    if nzl != 8:
+    if nzl != 8 or overlap:
         monkeypatch.setenv("OCNHIP_OVERLAP", "1")   # by default only with 8 MB or more of halo planes per direction
     N = (8, 8, nzl * R)
     rng = np.random.default_rng(5)
@@ -111,7 +125,7 @@ def _yslab_case(kind):
     return cfg
 
 
-@pytest.mark.parametrize("R,kind", [(2, "amd"), (2, "scalar"), (3, "scalar")])
+@pytest.mark.parametrize("R,kind", [(2, "amd"), (2, "scalar"), (3, "scalar"), (8, "amd")])
 def test_yslab_trajectory_matches_single_domain_oracle(ocn, backend, R, kind):
     """(Periodic, Periodic, Bounded) with T/S, buoyancy, Coriolis, closure (AMD or scalar), flux / gradient boundary
     conditions, WENO5, RK3 on R y-slabs against the single-domain oracle: every field, parent arrays with halos."""

@@ -335,3 +335,18 @@ def test_step_graph_replay_is_bitwise_the_launch_train(ocn, name, monkeypatch):
     assert ta == tb and ia == ib
     for k in fa:
         assert np.isfinite(fa[k]).all() and np.array_equal(fa[k], fb[k]), k
+
+
+# ---- BASELINE config 1 at its own size ----------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("graphs", [True, False], ids=["step_graphs", "launch_by_launch"])
+@pytest.mark.parametrize("dt_kind", ["example", "bench"])
+def test_config1_128x128_matches_oracle(ocn, graphs, dt_kind, monkeypatch):
+    """parity_cases.run_config1 (examples/two_dimensional_turbulence.jl at its own 128 x 128) with the script's dt = 0.2 and with
+    bench.py's 0.2 dx / 4, replayed from whole-step hipGraphs and launch by launch."""
+    from parity_cases import run_config1
+    if not graphs:
+        monkeypatch.setenv("OCNHIP_NO_GRAPH", "1")
+    m = run_config1(ocn, 0.2 if dt_kind == "example" else 0.2 * (2 * np.pi / 128) / 4.0, steps=4)
+    replays, active = m.graph_replays
+    assert (replays >= 1 and active) if graphs else (replays == 0 and not active)

@@ -24,3 +24,12 @@ def test_x_tiled_tendency_kernel(ocn, backend, name, monkeypatch):
     worst = run_case(ocn, name)
     bad = {k: v for k, v in worst.items() if v > 2e-11}
     assert not bad, bad
+
+
+def test_config1_128x128_matches_oracle_hostemu(ocn, backend):
+    """BASELINE config 1 at its own 128 x 128 through the host emulation of the general kernels (two steps of the example's
+    dt = 0.2); the `-m gpu` twin runs four steps with and without whole-step hipGraphs."""
+    if backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    from parity_cases import run_config1
+    run_config1(ocn, 0.2, steps=2)
