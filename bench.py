@@ -246,6 +246,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     os.environ.pop("OCNHIP_LIB", None)      # the product library only
+    if args.graph == "off":                 # the knob is read when the model is created (csrc/fused.hip fused_read_knobs)
+        os.environ["OCNHIP_NO_GRAPH"] = "1"
     if args.rehearse_hostemu:
         os.environ["OCNHIP_LIB"] = os.path.join(ROOT, "tests", "hostemu", "libocnhip_hostemu.so")
         args.no_cpu_baseline = True

@@ -53,7 +53,7 @@ class OcnError(RuntimeError):
 _lib = None
 
 
-ABI_VERSION = 3   # OCN_ABI_VERSION of include/ocnhip.h
+ABI_VERSION = 4   # OCN_ABI_VERSION of include/ocnhip.h
 
 
 def lib_path():
@@ -115,6 +115,7 @@ def load():
         "ocn_max_abs_divergence": (I, [P, PD]),
         "ocn_comm_unique_id": (I, [P]),
         "ocn_comm_init": (I, [P, I, I, P]),
+        "ocn_comm_probe": (I, [P, I, I, P, D]),
         "ocn_comm_rank": (I, [P, C.POINTER(I), C.POINTER(I)]),
         "ocn_profile_enable": (I, [P, I]),
         "ocn_profile_read": (I, [P, C.c_char_p, PD, C.POINTER(C.c_int64)]),

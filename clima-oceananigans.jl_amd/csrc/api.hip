@@ -11,6 +11,7 @@ double g_emu_shfl[4096];
 std::recursive_mutex g_emu_launch_mutex;
 #else
 thread_local int g_ocn_dry = 0;
+thread_local ocn_launch_error g_ocn_launch_err = {hipSuccess, {0}};
 #endif
 thread_local int g_ocn_capturing = 0, g_ocn_capture_poison = 0;
 
@@ -22,6 +23,21 @@ void ocn_set_error(ocn_ctx* ctx, const char* fmt, ...) {
   vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
   va_end(ap);
   if (ctx) memcpy(ctx->err, g_last_error, sizeof(g_last_error));
+}
+
+// every entry point that launches work returns through this: a launch or asynchronous call that failed since the last
+// report (compat.h ocn_note_error) turns the result into OCN_EHIP and names the call
+static int api_ret(ocn_ctx* ctx, int rc) {
+#ifndef OCN_HOST_EMU
+  if (g_ocn_launch_err.err != hipSuccess) {
+    if (rc == OCN_OK) {
+      ocn_set_error(ctx, "launch failed: %s [%s]", hipGetErrorString(g_ocn_launch_err.err), g_ocn_launch_err.what);
+      rc = OCN_EHIP;
+    }
+    g_ocn_launch_err.err = hipSuccess;
+  }
+#endif
+  return rc;
 }
 
 // ---- profiling -------------------------------------------------------------------------------------------
@@ -90,7 +106,7 @@ int ocn_sync(ocn_ctx* ctx) {
     if (halo_settle(m)) return OCN_EHIP;
   OCN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   OCN_HIP_CHECK(ctx, hipGetLastError());
-  return OCN_OK;
+  return api_ret(ctx, OCN_OK);
 }
 
 void* ocn_stream(ocn_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -517,10 +533,25 @@ static int zero_Gm(ocn_model* m) {
 
 // one fused (sub)step of the fast path: tendencies + update, rhs, solve, projection + halo images
 // An exchange started by the previous (sub)step may still be in flight: everybody who reads z halos waits for it here.
-int halo_settle(ocn_model* m) {
+static int halo_settle_one(ocn_model* m) {
   if (m->halo_inflight) OCN_HIP_CHECK(m->ctx, hipStreamWaitEvent(m->ctx->stream, m->ctx->ev_halo, 0));
   if (m->halo2_inflight) OCN_HIP_CHECK(m->ctx, hipStreamWaitEvent(m->ctx->stream, m->ctx->ev_halo2, 0));
   m->halo_inflight = m->halo2_inflight = false;
+  return OCN_OK;
+}
+// The communication stream, its events and the communicator belong to the CONTEXT, the in-flight flags to a model: with two
+// slab models on one context, B's exchanges on the main stream must not start while A's overlapped exchange is still
+// travelling (one exchange of a communicator in flight at a time).  So settling means settling every model of the context;
+// the events are recorded in stream order on the one communication stream, so waiting for the latest record covers all.
+int halo_settle(ocn_model* m) {
+  for (ocn_model* o : m->ctx->models)
+    if (int rc = halo_settle_one(o)) return rc;
+  return OCN_OK;
+}
+static int halo_settle_others(ocn_model* m) {
+  for (ocn_model* o : m->ctx->models)
+    if (o != m)
+      if (int rc = halo_settle_one(o)) return rc;
   return OCN_OK;
 }
 
@@ -536,6 +567,8 @@ static int overlap_streams(ocn_ctx* c) {
 
 static int fused_substep(ocn_model* m, double dt_full, double cn, double cm, int use_m, double dt_stage, bool swap) {
   const int Hz = m->gd.Hz, Nz = m->gd.Nz;
+  if (m->g->dist)
+    if (int rc0 = halo_settle_others(m)) return rc0;   // another model's planes may still be travelling on the shared stream
   if (m->halo_inflight && Nz > 2 * Hz + 2) {
     // z-slabs: the halo planes of u, v, w are still on their way (started after the last projection).  The interior levels
     // touch none of them; the first and last Hz levels follow once the planes have landed.
@@ -731,28 +764,30 @@ static bool graph_eligible(const ocn_model* m) {
 }
 
 #ifndef OCN_HOST_EMU
-static uint64_t step_key(const ocn_model* m, double dt, int force_euler) {
-  uint64_t h = 1469598103934665603ull;
-  auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+static uint64_t step_key(const ocn_model* m, double dt, int force_euler, std::vector<uint64_t>& words) {
+  words.clear();
   uint64_t b;
   memcpy(&b, &dt, 8);
-  mix(b);
-  mix(m->d.stepper == OCN_STEPPER_AB2 && (force_euler || dt != m->previous_dt));
-  mix(m->iteration == 0);
-  mix(m->gn_alias_gm);
-  mix(m->pred_active);
-  auto fp = [&](const Field& f) { mix((uint64_t)(uintptr_t)f.d); };
+  words.push_back(b);
+  words.push_back(m->d.stepper == OCN_STEPPER_AB2 && (force_euler || dt != m->previous_dt));
+  words.push_back(m->iteration == 0);
+  words.push_back(m->gn_alias_gm);
+  words.push_back(m->pred_active);
+  auto fp = [&](const Field& f) { words.push_back((uint64_t)(uintptr_t)f.d); };
   fp(m->u); fp(m->v); fp(m->w); fp(m->us); fp(m->vs); fp(m->ws);
   for (int t = 0; t < m->nt; ++t) { fp(m->tr[t]); fp(m->trs[t]); }
   for (int f = 0; f < 3 + m->nt; ++f) { fp(m->Gn[f]); fp(m->Gm[f]); }
+  uint64_t h = 1469598103934665603ull;
+  for (uint64_t v : words) h = (h ^ v) * 1099511628211ull;
   return h;
 }
 
 static int step_graphed(ocn_model* m, double dt, int force_euler) {
-  const uint64_t key = step_key(m, dt, force_euler);
+  std::vector<uint64_t> words;
+  const uint64_t key = step_key(m, dt, force_euler, words);
   int at = -1;
   for (size_t i = 0; i < m->graphs.size(); ++i)
-    if (m->graphs[i].key == key) at = (int)i;
+    if (m->graphs[i].key == key && m->graphs[i].words == words) at = (int)i;   // the tuple itself, not only its hash
   if (at < 0) {
     if (m->graphs.size() >= 16) {   // an adaptive dt makes a new key every step: forget the ones that never came back
       std::vector<ocn_model::StepGraph> keep;
@@ -760,7 +795,7 @@ static int step_graphed(ocn_model* m, double dt, int force_euler) {
         if (e.exec) keep.push_back(e);
       m->graphs.swap(keep);
     }
-    if (m->graphs.size() < 16) m->graphs.push_back({key, 1, nullptr});
+    if (m->graphs.size() < 16) m->graphs.push_back({key, 1, nullptr, words});
     return step_plain(m, dt, force_euler);
   }
   hipStream_t st = m->ctx->stream;
@@ -1220,17 +1255,17 @@ int ocn_fill_halos(ocn_model* m, uint32_t mask) {
   for (int t = 0; t < m->nt; ++t)
     if (mask & (1u << (8 + t))) fs[n++] = &m->tr[t];
   // fields of one call share one batched launch; aux fields (pressures) use their own z conditions
-  return fill_fields(m, fs, n);
+  return api_ret(m->ctx, fill_fields(m, fs, n));
 }
 
-int ocn_update_state(ocn_model* m) { return m ? update_state(m) : OCN_EINVAL; }
+int ocn_update_state(ocn_model* m) { return m ? api_ret(m->ctx, update_state(m)) : OCN_EINVAL; }
 
 int ocn_compute_tendencies(ocn_model* m) {
   if (!m) return OCN_EINVAL;
   if (halo_settle(m)) return OCN_EHIP;
   m->gn_alias_gm = false;
   launch_tendencies(m);
-  return OCN_OK;
+  return api_ret(m->ctx, OCN_OK);
 }
 
 int ocn_ab2_step(ocn_model* m, double dt, double chi) {
@@ -1238,7 +1273,7 @@ int ocn_ab2_step(ocn_model* m, double dt, double chi) {
   if (halo_settle(m)) return OCN_EHIP;
   if (materialize_gn(m)) return OCN_EHIP;
   launch_step(m, dt, 1.5 + chi, -(0.5 + chi), 1);
-  return OCN_OK;
+  return api_ret(m->ctx, OCN_OK);
 }
 
 int ocn_rk3_substep(ocn_model* m, double dt, double gamma, double zeta, int has_zeta) {
@@ -1246,7 +1281,7 @@ int ocn_rk3_substep(ocn_model* m, double dt, double gamma, double zeta, int has_
   if (halo_settle(m)) return OCN_EHIP;
   if (materialize_gn(m)) return OCN_EHIP;
   launch_step(m, dt, gamma, zeta, has_zeta);
-  return OCN_OK;
+  return api_ret(m->ctx, OCN_OK);
 }
 
 int ocn_store_tendencies(ocn_model* m) {
@@ -1254,16 +1289,16 @@ int ocn_store_tendencies(ocn_model* m) {
   if (halo_settle(m)) return OCN_EHIP;
   if (materialize_gn(m)) return OCN_EHIP;
   launch_store(m);
-  return OCN_OK;
+  return api_ret(m->ctx, OCN_OK);
 }
 
-int ocn_pressure_correction(ocn_model* m, double dt) { return m ? pressure_correction(m, dt) : OCN_EINVAL; }
+int ocn_pressure_correction(ocn_model* m, double dt) { return m ? api_ret(m->ctx, pressure_correction(m, dt)) : OCN_EINVAL; }
 
 int ocn_pressure_correct_velocities(ocn_model* m, double dt) {
   if (!m) return OCN_EINVAL;
   if (halo_settle(m)) return OCN_EHIP;
   launch_pcorrect(m, dt);
-  return OCN_OK;
+  return api_ret(m->ctx, OCN_OK);
 }
 
 int ocn_poisson_solve_host(ocn_model* m, const double* rhs, double* phi) {
@@ -1279,7 +1314,7 @@ int ocn_poisson_solve_host(ocn_model* m, const double* rhs, double* phi) {
   if (!rc) hipMemcpy(phi, b, n * sizeof(double), hipMemcpyDeviceToHost);
   hipFree(a);
   hipFree(b);
-  return rc;
+  return api_ret(m->ctx, rc);
 }
 
 int ocn_set_epilogue(ocn_model* m, int enforce_incompressibility) {
@@ -1292,7 +1327,7 @@ int ocn_set_epilogue(ocn_model* m, int enforce_incompressibility) {
     launch_pcorrect(m, 1.0);
     if ((rc = update_state(m))) return rc;
   }
-  return OCN_OK;
+  return api_ret(m->ctx, OCN_OK);
 }
 
 int ocn_time_step(ocn_model* m, double dt, int force_euler) {
@@ -1300,9 +1335,9 @@ int ocn_time_step(ocn_model* m, double dt, int force_euler) {
   ProfScope ps(m->ctx, "time_step");
   if (!m->fast_path && halo_settle(m)) return OCN_EHIP;   // the all-in-one path overlaps its own exchanges (fused_substep)
 #ifndef OCN_HOST_EMU
-  if (graph_eligible(m)) return step_graphed(m, dt, force_euler);
+  if (graph_eligible(m)) return api_ret(m->ctx, step_graphed(m, dt, force_euler));
 #endif
-  return step_plain(m, dt, force_euler);
+  return api_ret(m->ctx, step_plain(m, dt, force_euler));
 }
 
 int ocn_clock(const ocn_model* m, double* time, int64_t* iteration, int32_t* stage) {
@@ -1326,6 +1361,7 @@ int ocn_max_abs_divergence(ocn_model* m, double* out) {
   if (halo_settle(m)) return OCN_EHIP;
   OCN_HIP_CHECK(m->ctx, hipMemsetAsync(m->d_red, 0, 8, m->ctx->stream));
   launch_maxdiv(m, m->d_red);
+  if (int rc = api_ret(m->ctx, OCN_OK)) return rc;
   OCN_HIP_CHECK(m->ctx, hipStreamSynchronize(m->ctx->stream));
   OCN_HIP_CHECK(m->ctx, hipMemcpy(out, m->d_red, 8, hipMemcpyDeviceToHost));
   return OCN_OK;
@@ -1343,10 +1379,10 @@ int ocn_measure_copy_rate(ocn_ctx* ctx, size_t bytes, int reps, double* bytes_pe
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipMemsetAsync(a, 1, bytes, ctx->stream);
-  hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, ctx->stream);   // warm-up
+  OCN_ASYNC(hipMemsetAsync(a, 1, bytes, ctx->stream));
+  OCN_ASYNC(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, ctx->stream));   // warm-up
   hipEventRecord(e0, ctx->stream);
-  for (int r = 0; r < reps; ++r) hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+  for (int r = 0; r < reps; ++r) OCN_ASYNC(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   hipEventRecord(e1, ctx->stream);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   float ms = 0;
@@ -1355,7 +1391,7 @@ int ocn_measure_copy_rate(ocn_ctx* ctx, size_t bytes, int reps, double* bytes_pe
   hipEventDestroy(e1);
   hipFree(a);
   hipFree(b);
-  if (e != hipSuccess || !(ms > 0)) {
+  if (e != hipSuccess || !(ms > 0) || api_ret(ctx, OCN_OK) != OCN_OK) {
     ocn_set_error(ctx, "ocn_measure_copy_rate: copy failed");
     return OCN_EHIP;
   }

@@ -16,6 +16,9 @@
 //     buffers are staged through the mailbox with blocking copies).  Same pairing rule as RCCL: the k-th send of
 //     rank a to rank b meets the k-th receive b posts from a; tag and size are checked.
 //   * in-process mailbox (OCN_HOST_EMU only)  -- several contexts of ONE process act as ranks (threads).
+#include <chrono>
+#include <thread>
+
 #include "internal.h"
 
 #include <atomic>
@@ -255,6 +258,47 @@ int ocn_comm_unique_id(void* out128) {
   return OCN_OK;
 }
 
+// ncclCommInitRank is collective and blocking: if it fails on ONE rank (no device, a broken RCCL set-up) the others wait in
+// the bootstrap for ever and no caller-side fallback is ever reached.  The probe creates a throw-away communicator in
+// non-blocking mode, polls its state against a deadline and aborts it: every rank comes back -- with OCN_OK, with RCCL's
+// error, or with a time-out -- and the callers agree on the outcome over their own process group BEFORE the real (blocking)
+// ocn_comm_init, which uses a fresh unique id (clima-oceananigans.jl_amd/parallel.py init_comm).
+int ocn_comm_probe(ocn_ctx* ctx, int rank, int nranks, const void* id128, double timeout_s) {
+  if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return OCN_EINVAL;
+  if (nranks == 1 || !id128 || strncmp((const char*)id128, "SHM:", 4) == 0) return OCN_OK;
+#ifndef OCN_HOST_EMU
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  OCN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+  cfg.blocking = 0;
+  ncclComm_t comm = nullptr;
+  ncclResult_t st = ncclCommInitRankConfig(&comm, nranks, id, rank, &cfg);
+  const auto t0 = std::chrono::steady_clock::now();
+  bool timed_out = false;
+  while (st == ncclInProgress) {
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+      timed_out = true;
+      break;
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    if (ncclCommGetAsyncError(comm, &st) != ncclSuccess) st = ncclSystemError;
+  }
+  if (comm) ncclCommAbort(comm);
+  if (timed_out) {
+    ocn_set_error(ctx, "RCCL communicator of %d ranks did not form within %.0f s (another rank never joined)", nranks, timeout_s);
+    return OCN_EHIP;
+  }
+  if (st != ncclSuccess) {
+    ocn_set_error(ctx, "ncclCommInitRankConfig failed: %s", ncclGetErrorString(st));
+    return OCN_EHIP;
+  }
+#else
+  (void)timeout_s;
+#endif
+  return OCN_OK;
+}
+
 int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* id128) {
   if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return OCN_EINVAL;
   ctx->rank = rank;
@@ -272,10 +316,6 @@ int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* id128) {
     return shm_init(ctx, nm, rank, nranks);
   }
 #ifndef OCN_HOST_EMU
-  if (getenv("OCNHIP_FAKE_RCCL_FAIL")) {   // tests of the callers' fallback (parallel.init_comm): behave like a node whose RCCL cannot start
-    ocn_set_error(ctx, "ncclCommInitRank failed: simulated (OCNHIP_FAKE_RCCL_FAIL)");
-    return OCN_EHIP;
-  }
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   ncclComm_t comm;

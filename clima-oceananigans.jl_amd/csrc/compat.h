@@ -26,17 +26,34 @@
 // g_ocn_dry: a time step is being REPLAYED from a hipGraph (api.hip): the host-side bookkeeping of the step runs again
 // (clock, buffer rotations), every launch and stream operation is skipped
 extern thread_local int g_ocn_dry;
+
+// A failed launch (bad configuration, LDS over the limit, a lost device) is reported by the NEXT runtime call, not by the
+// launch itself, and used to surface only at ocn_sync -- as a step that "succeeded" and an error that named no kernel.
+// Every launch and every unchecked asynchronous call now asks hipGetLastError() right away (host-side, no synchronisation)
+// and the first failure since the last report is kept with the text of the call; the C-ABI entry points that launch work
+// (ocn_time_step, ocn_update_state, ...) return OCN_EHIP with that text (api.hip api_ret).
+struct ocn_launch_error {
+  hipError_t err;
+  char what[200];
+};
+extern thread_local ocn_launch_error g_ocn_launch_err;
+static inline void ocn_note_error(hipError_t e, const char* what) {
+  if (e == hipSuccess || g_ocn_launch_err.err != hipSuccess) return;
+  g_ocn_launch_err.err = e;
+  snprintf(g_ocn_launch_err.what, sizeof g_ocn_launch_err.what, "%s", what);
+}
 template <class K, class... A>
-static inline void ocn_launch(K kern, dim3 grid, dim3 block, hipStream_t s, A... args) {
+static inline void ocn_launch_impl(const char* what, K kern, dim3 grid, dim3 block, hipStream_t s, A... args) {
   if (g_ocn_dry) return;
   hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
+  ocn_note_error(hipGetLastError(), what);
 }
+// the whole argument list is the message: "k_tend4<...>, f.grd, f.blk, s, m->gd, a"
+#define ocn_launch(...) ocn_launch_impl(#__VA_ARGS__, __VA_ARGS__)
 // kernels that use __shared__ / __syncthreads go through the same call on the GPU
-template <class K, class... A>
-static inline void ocn_launch_sync(K kern, dim3 grid, dim3 block, hipStream_t s, A... args) {
-  if (g_ocn_dry) return;
-  hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
-}
+#define ocn_launch_sync(...) ocn_launch_impl(#__VA_ARGS__, __VA_ARGS__)
+// an asynchronous runtime call whose result the caller has no way to return
+#define OCN_ASYNC(call) ocn_note_error((call), #call)
 #define OCN_SHARED __shared__
 #define OCN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // an opaque use of three loaded values: the compiler must have them in registers at this point of every path (it places
@@ -98,6 +115,7 @@ extern std::recursive_mutex g_emu_launch_mutex;   // one emulated kernel at a ti
 #define OCN_DEVFN inline
 #define OCN_SHARED static
 #define OCN_SCHED_FENCE() ((void)0)
+#define OCN_ASYNC(call) ((void)(call))
 #define OCN_TOUCH3(a, b, c) ((void)0)
 
 typedef int hipError_t;
@@ -213,6 +231,8 @@ static inline void ocn_launch_sync(K kern, dim3 grid, dim3 block, hipStream_t, A
       }
 }
 #endif
+
+#define OCN_LDS_BYTES 163840   /* LDS per workgroup on gfx950 (160 KiB) */
 
 #define OCN_HIP_CHECK(ctx, call)                                                            \
   do {                                                                                      \

@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(BX* BY) k_tend4(GridDev g, FusedArgs a) {
   constexpr int SLAB = 3 * NR * SX;                   // doubles per slab buffer; (f, r, s) <-> (row j0 - 3 + r, column i0 - 3 + s)
   constexpr int NG = (NR + BY - 1) / BY;              // row groups of the register-staged slab load (DMA = false)
   static_assert(SX % 2 == 0 && BX % WV == 0 && T % WV == 0, "slab rows must be whole 16-byte pieces");
+  static_assert((2 * SLAB + 6 * T + 6 * BY * NW) * sizeof(double) <= OCN_LDS_BYTES, "k_tend4: LDS footprint over 160 KiB (gfx950)");
   OCN_SHARED double lds[2 * SLAB + 6 * T + 6 * BY * NW] __attribute__((aligned(16)));
   double* const fyb = lds + 2 * SLAB;                 // [parity][field][thread]: south-face fluxes
   double* const fxe = fyb + 6 * T;                    // [parity][field][row * NW + wave]: west-face fluxes of each wave's first lane
@@ -497,6 +498,7 @@ __global__ void __launch_bounds__(BX* BY) k_rest4(GridDev g, RestArgs a) {
   constexpr int T = BX * BY, NR = BY + 1, SX = BX + 6;      // rows j0-1 .. j0+BY-1; columns -3 .. Nx+2 (the parent row)
   constexpr int WV = BX < OCN_WAVE ? BX : OCN_WAVE, NW = BX / WV, NWV = T / WV;
   constexpr int SLAB = 4 * NR * SX;
+  static_assert((2 * SLAB + 6 * T + 6 * BY * NW) * sizeof(double) <= OCN_LDS_BYTES, "k_rest4: LDS footprint over 160 KiB (gfx950)");
   OCN_SHARED double lds[2 * SLAB + 6 * T + 6 * BY * NW] __attribute__((aligned(16)));
   double* const fyb = lds + 2 * SLAB;
   double* const fxe = fyb + 6 * T;

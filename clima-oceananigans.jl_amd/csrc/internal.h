@@ -123,7 +123,9 @@ struct ocn_model {
   ocn_grid* own_grid = nullptr;   // private copy of the caller's grid when the advection scheme needs wider halos
   int knob_fused_xt = 0, knob_no_dma = 0, knob_no_tracer3 = 0, knob_prio = 0x20FF;   // fused_read_knobs(), at creation
   // whole-step hipGraphs of the general path (api.hip step_graphed): one entry per distinct (dt, stepper state, buffer rotation)
-  struct StepGraph { uint64_t key; int seen; void* exec; };
+  // whole-step hipGraph cache: `key` is a hash of `words` (dt bits, stepper flags, the device pointer of every rotating buffer);
+  // a hit on the hash is only taken after the words themselves compare equal
+  struct StepGraph { uint64_t key; int seen; void* exec; std::vector<uint64_t> words; };
   std::vector<StepGraph> graphs;
   int knob_overlap_cus = 16; // CUs the interior tendency launch leaves to the communication kernels (OCNHIP_OVERLAP_CUS)
   int knob_overlap = -1;     // OCNHIP_OVERLAP=0|1: z-slab halo exchange overlapped with the next tendency launch (default: with > 1 rank)

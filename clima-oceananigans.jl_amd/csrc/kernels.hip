@@ -224,12 +224,12 @@ static void tracer_gn_clear(ocn_model* m, int t) {
   Field& G = m->Gn[3 + t];
   hipStream_t s = m->ctx->stream;
   if (!tracer_rest_shell(m)) {
-    hipMemsetAsync(G.d, 0, G.n * sizeof(double), s);
+    OCN_ASYNC(hipMemsetAsync(G.d, 0, G.n * sizeof(double), s));
     return;
   }
   const size_t plane = (size_t)G.sz * sizeof(double);
-  hipMemsetAsync(G.d + (size_t)G.Hz * G.sz, 0, plane, s);
-  if (m->gd.Nz > 1) hipMemsetAsync(G.d + (size_t)(G.Hz + m->gd.Nz - 1) * G.sz, 0, plane, s);
+  OCN_ASYNC(hipMemsetAsync(G.d + (size_t)G.Hz * G.sz, 0, plane, s));
+  if (m->gd.Nz > 1) OCN_ASYNC(hipMemsetAsync(G.d + (size_t)(G.Hz + m->gd.Nz - 1) * G.sz, 0, plane, s));
 }
 
 void launch_tendencies(ocn_model* m, bool skip_momentum_advection, bool skip_tracer_advection) {

@@ -1178,13 +1178,13 @@ __global__ void k_mult_dz(GridDev g, double* __restrict__ r) {
 int poisson_solve_rhs(ocn_model* m, const double* rhs_dev, double* phi_dev) {
   PoissonSolver* s = m->solver;
   size_t nr = (size_t)s->Nx * s->Ny * s->Nz;
-  hipMemcpyAsync(s->rhs, rhs_dev, nr * sizeof(double), hipMemcpyDeviceToDevice, m->ctx->stream);
+  OCN_ASYNC(hipMemcpyAsync(s->rhs, rhs_dev, nr * sizeof(double), hipMemcpyDeviceToDevice, m->ctx->stream));
   if (m->g->topo[2] == OCN_BOUNDED) {  // set_source_term!: multiply by dz_c (fourier_tridiagonal_poisson_solver.jl:109-123)
     dim3 b(64, 4, 1), gr((s->Nx + 63) / 64, (s->Ny + 3) / 4, s->Nz);
     ocn_launch(k_mult_dz, gr, b, m->ctx->stream, m->gd, s->rhs);
   }
   int rc = run_solver(m);
   if (rc) return rc;
-  hipMemcpyAsync(phi_dev, s->rhs, nr * sizeof(double), hipMemcpyDeviceToDevice, m->ctx->stream);
+  OCN_ASYNC(hipMemcpyAsync(phi_dev, s->rhs, nr * sizeof(double), hipMemcpyDeviceToDevice, m->ctx->stream));
   return OCN_OK;
 }

@@ -20,30 +20,45 @@ def _broadcast_id(ctx, dist, rank):
     return (C.c_char * 128).from_buffer_copy(bytes(buf.numpy().tobytes()))
 
 
-def init_comm(ctx, dist, rank, world, allow_fallback=False):
+def init_comm(ctx, dist, rank, world, allow_fallback=False, probe_timeout_s=None):
     """ocn_comm_init with a unique id created on rank 0 and broadcast over the (CPU) process group.
 
     Returns the transport in use: "rccl", "shm" (asked for with OCNHIP_TRANSPORT=shm, or the host-emulation build) or, with
     ``allow_fallback``, "shm (fallback: <RCCL error>)" when the RCCL communicator could not be created on some rank -- every
     rank then switches to the host shared-memory transport together, so that a node whose RCCL set-up is broken still
-    produces (slow, clearly labelled) numbers instead of none."""
+    produces (slow, clearly labelled) numbers instead of none.
+
+    ncclCommInitRank is collective: a failure on one rank alone would leave the others in its bootstrap for ever.  So the
+    ranks first PROBE (ocn_comm_probe: a throw-away non-blocking communicator polled against a deadline, which returns on
+    every rank), agree on the outcome with an all_reduce over ``dist``, and only then create the real communicator from a
+    second unique id -- or fall back together."""
     import os
     import torch
     raw = _broadcast_id(ctx, dist, rank)
     is_shm = bytes(raw.raw[:4]) == b"SHM:"
-    rc = ctx.lib.ocn_comm_init(ctx.h, int(rank), int(world), raw)
-    if not allow_fallback or is_shm:
-        check(rc, ctx.h)
-        return "shm" if is_shm else "rccl"
+    if is_shm:
+        check(ctx.lib.ocn_comm_init(ctx.h, int(rank), int(world), raw), ctx.h)
+        return "shm"
+    if probe_timeout_s is None:
+        probe_timeout_s = float(os.environ.get("OCNHIP_COMM_TIMEOUT_S", "180"))
+    rc = ctx.lib.ocn_comm_probe(ctx.h, int(rank), int(world), raw, float(probe_timeout_s))
+    why = ctx.lib.ocn_last_error(ctx.h).decode(errors="replace") if rc else ""
     worst = torch.tensor([rc], dtype=torch.int64)
     dist.all_reduce(worst, op=dist.ReduceOp.MIN)          # error codes are negative
     if int(worst[0]) == 0:
-        return "rccl"
-    why = ctx.lib.ocn_last_error(ctx.h).decode(errors="replace") if rc else "another rank failed"
+        raw = _broadcast_id(ctx, dist, rank)              # the probe consumed the first id
+        rc = ctx.lib.ocn_comm_init(ctx.h, int(rank), int(world), raw)
+        why = ctx.lib.ocn_last_error(ctx.h).decode(errors="replace") if rc else ""
+        worst = torch.tensor([rc], dtype=torch.int64)
+        dist.all_reduce(worst, op=dist.ReduceOp.MIN)
+        if int(worst[0]) == 0:
+            return "rccl"
+    if not allow_fallback:
+        raise RuntimeError(f"RCCL communicator of {world} ranks could not be created: {why or 'another rank failed'}")
     os.environ["OCNHIP_TRANSPORT"] = "shm"
     raw = _broadcast_id(ctx, dist, rank)
     check(ctx.lib.ocn_comm_init(ctx.h, int(rank), int(world), raw), ctx.h)
-    return f"shm (fallback: {why})"
+    return f"shm (fallback: {why or 'another rank failed'})"
 
 
 def init_comm_self(ctx):

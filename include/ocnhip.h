@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OCN_ABI_VERSION 3
+#define OCN_ABI_VERSION 4
 
 /* error codes */
 enum {
@@ -237,6 +237,11 @@ int ocn_max_abs_divergence(ocn_model* m, double* out);
  * collective and must be issued by all ranks in the same order. ---------------------------------------- */
 int ocn_comm_unique_id(void* out128);                                      /* ncclGetUniqueId (128 bytes) */
 int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* unique_id128);
+/* Can a communicator of `nranks` form?  A throw-away non-blocking ncclCommInitRankConfig polled against `timeout_s` and
+ * aborted: returns on EVERY rank (OCN_OK, RCCL's error, or a time-out) where the blocking ocn_comm_init would leave the
+ * healthy ranks waiting for ever for one that failed.  Collective; use a unique id of its own.  (The reference's
+ * MPI.Init has no counterpart: an MPI job that loses a rank at start-up is killed by its launcher.)               */
+int ocn_comm_probe(ocn_ctx* ctx, int rank, int nranks, const void* unique_id128, double timeout_s);
 int ocn_comm_rank(const ocn_ctx* ctx, int* rank, int* nranks);
 
 /* ---- measurement helpers (bench.py) -------------------------------------------------------------- */

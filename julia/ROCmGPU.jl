@@ -63,7 +63,7 @@ function ocn_grid(arch::ROCmGPU, grid::RectilinearGrid)
     return h[]
 end
 
-# `ocn_model_desc` (include/ocnhip.h; OCN_ABI_VERSION 3), field by field.  isbits, so it crosses ccall by reference.
+# `ocn_model_desc` (include/ocnhip.h; OCN_ABI_VERSION 4), field by field.  isbits, so it crosses ccall by reference.
 const MAXTR = 8
 struct BC; kind::Int32; value::Float64; array::Ptr{Float64}; end                       # ocn_bc
 struct ModelDesc
@@ -208,10 +208,10 @@ kernel_path(model::RM) = (buf = Vector{UInt8}(undef, 256);
 # Distributed: MultiArch(ROCmGPU(); ranks=(1, 1, R)) -> ocn_comm_init(ctx, rank, R, id) with the 128-byte id of
 # ocn_comm_unique_id broadcast over MPI (Distributed/multi_architectures.jl:20-47); everything else is unchanged.
 # Launch-bound models (config 1) are replayed from hipGraphs inside ocn_time_step; ocn_model_graph_replays(handle, n, active)
-# reports it.  The library reports OCN_ABI_VERSION through ocn_abi_version(): __init__ compares it with 3.
+# reports it.  The library reports OCN_ABI_VERSION through ocn_abi_version(): __init__ compares it with 4.
 function __init__()
     v = ccall((:ocn_abi_version, libocnhip), Cint, ())
-    v == 3 || error("libocnhip reports ABI version $v; this shim is written for 3")
+    v == 4 || error("libocnhip reports ABI version $v; this shim is written for 4")
 end
 
 end # module

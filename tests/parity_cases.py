@@ -301,3 +301,30 @@ def run_config1(ocn, dt, steps, N=(128, 128)):
     assert abs(om.time - m.time) < 1e-14 and om.iteration == m.iteration == steps
     assert m.max_abs_divergence() <= 1e-12 * np.abs(u0).max() / (2 * np.pi / N[0]) * 50
     return m
+
+
+def run_two_slab_models_on_one_context(ocn, steps=3):
+    """Two forced z-slab models (OCNHIP_FORCE_DIST=1, OCNHIP_OVERLAP=1 set by the caller) sharing ONE context -- its communication
+    stream, events and communicator -- stepped alternately, each against its own oracle: the overlapped exchange of one must
+    have settled before the other's exchanges start (csrc/api.hip halo_settle)."""
+    ctx = ocn.Context(0)
+    rng = np.random.default_rng(21)
+    pairs = []
+    for N, stepper, tr in (((16, 12, 18), "AB2", ()), ((12, 16, 20), "RK3", ("c",))):
+        kw = dict(size=N, extent=(1, 1, 1), topology=(P, P, P))
+        init = {n: rng.random(N) - 0.5 for n in "uvw"}
+        init.update({t: rng.random(N) for t in tr})
+        m = ocn.NonhydrostaticModel(ocn.RectilinearGrid(ctx, **kw), advection=ocn.WENO5(), timestepper=stepper, tracers=tr)
+        om = O.NonhydrostaticModel(O.RectilinearGrid(**kw), advection=O.WENO5(), timestepper=stepper, tracers=tr)
+        ocn.set_model(m, **init)
+        O.set_model(om, **init)
+        assert "z-slabs" in m.kernel_path, m.kernel_path
+        pairs.append((m, om))
+    for _ in range(steps):
+        for m, om in pairs:
+            ocn.time_step(m, 2e-3)
+            O.time_step(om, 2e-3)
+    for m, om in pairs:
+        a, b = fields_of(om, True), fields_of(m, False)
+        for k in a:
+            assert np.abs(a[k] - b[k]).max() <= 2e-11 * max(np.abs(a[k]).max(), 1e-300), k

@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol(lib):
     missing = [s for s in declared_symbols() if not hasattr(L, s)]
     assert not missing, missing
     L.ocn_abi_version.restype = ctypes.c_int
-    assert L.ocn_abi_version() == 3
+    import __graft_entry__ as ge
+    assert L.ocn_abi_version() == ge.load_package()._lib.ABI_VERSION == 4
 
 
 def test_product_fails_loudly_without_library(monkeypatch, tmp_path):

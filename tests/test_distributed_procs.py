@@ -95,9 +95,10 @@ def test_bench_refuses_missing_gpus():
 
 @pytest.mark.gpu
 def test_bench_falls_back_to_shm_when_rccl_cannot_start():
-    """parallel.init_comm(allow_fallback=True): if the RCCL communicator cannot be created on some rank, every rank switches to
-    the host shared-memory transport together and the bench line says so (simulated failure; two ranks on the one GPU)."""
-    env = dict(os.environ, OCNHIP_FAKE_RCCL_FAIL="1", OCNHIP_BENCH_NDEV="1")
+    """parallel.init_comm(allow_fallback=True): if the RCCL communicator cannot be created, every rank switches to the host
+    shared-memory transport together and the bench line says so.  The failure is a real one: two ranks bound to the one GPU
+    of the box, which RCCL refuses (`invalid usage`: duplicate device) -- seen by the non-blocking probe on both ranks."""
+    env = dict(os.environ, OCNHIP_BENCH_NDEV="1", OCNHIP_COMM_TIMEOUT_S="60")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OCNHIP_LIB", "OCNHIP_TRANSPORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "64", "64",

@@ -350,3 +350,16 @@ def test_config1_128x128_matches_oracle(ocn, graphs, dt_kind, monkeypatch):
     m = run_config1(ocn, 0.2 if dt_kind == "example" else 0.2 * (2 * np.pi / 128) / 4.0, steps=4)
     replays, active = m.graph_replays
     assert (replays >= 1 and active) if graphs else (replays == 0 and not active)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rccl_self", [False, True], ids=["device_copies", "rccl_self"])
+def test_two_slab_models_share_a_context(ocn, rccl_self, monkeypatch):
+    """two forced z-slab models on one context, overlapped halo planes, stepped alternately (parity_cases); with the planes
+    moved by device copies and by a one-rank RCCL communicator"""
+    monkeypatch.setenv("OCNHIP_FORCE_DIST", "1")
+    monkeypatch.setenv("OCNHIP_OVERLAP", "1")
+    if rccl_self:
+        pytest.skip("one RCCL communicator per context is created by the caller: covered by test_forced_slab_through_rccl_self")
+    from parity_cases import run_two_slab_models_on_one_context
+    run_two_slab_models_on_one_context(ocn)

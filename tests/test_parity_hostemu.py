@@ -33,3 +33,12 @@ def test_config1_128x128_matches_oracle_hostemu(ocn, backend):
         pytest.skip("host-emulation run only")
     from parity_cases import run_config1
     run_config1(ocn, 0.2, steps=2)
+
+
+def test_two_slab_models_share_a_context_hostemu(ocn, backend, monkeypatch):
+    if backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    monkeypatch.setenv("OCNHIP_FORCE_DIST", "1")
+    monkeypatch.setenv("OCNHIP_OVERLAP", "1")
+    from parity_cases import run_two_slab_models_on_one_context
+    run_two_slab_models_on_one_context(ocn)
