@@ -12,5 +12,6 @@ from .api import (Context, RectilinearGrid, NonhydrostaticModel, Periodic, Bound
                   AnisotropicMinimumDissipation, FPlane, BuoyancyTracer, SeawaterBuoyancy,
                   FluxBC, ValueBC, GradientBC, Field, CenterField, time_step, set_model, update_state, OcnError)
 from . import _lib  # noqa: F401
+from . import hydrostatic  # noqa: F401   SplitExplicitFreeSurface, LatitudeLongitudeGrid (BASELINE config 5, first slice)
 
 __all__ = ["Context", "RectilinearGrid", "NonhydrostaticModel", "time_step", "set_model"]

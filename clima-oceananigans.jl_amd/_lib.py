@@ -46,6 +46,15 @@ class ModelDesc(C.Structure):
                 ("bcs", (BC * 6) * (3 + MAX_TRACERS)), ("nu_bcs", BC * 6), ("kappa_bcs", (BC * 6) * MAX_TRACERS)]
 
 
+class HGridDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("N", C.c_int32 * 3), ("H", C.c_int32 * 3), ("topology", C.c_int32 * 3),
+                ("x0", C.c_double * 3), ("L", C.c_double * 3), ("z_faces", C.POINTER(C.c_double)), ("radius", C.c_double)]
+
+
+NOTHING = 2
+HGRID_RECTILINEAR, HGRID_LATLON = 0, 1
+
+
 class OcnError(RuntimeError):
     pass
 
@@ -117,6 +126,27 @@ def load():
         "ocn_comm_init": (I, [P, I, I, P]),
         "ocn_comm_probe": (I, [P, I, I, P, D]),
         "ocn_comm_rank": (I, [P, C.POINTER(I), C.POINTER(I)]),
+        "ocn_hgrid_create": (I, [P, C.POINTER(HGridDesc), C.POINTER(P)]),
+        "ocn_hgrid_destroy": (None, [P]),
+        "ocn_hgrid_metric": (I, [P, I, PD, I]),
+        "ocn_hfield_create": (I, [P, I, I, I, C.POINTER(P)]),
+        "ocn_hfield_destroy": (None, [P]),
+        "ocn_hfield_shape": (I, [P, C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32 * 3), C.POINTER(C.c_int32 * 3)]),
+        "ocn_hfield_ptr": (P, [P]),
+        "ocn_hfield_upload": (I, [P, PD]),
+        "ocn_hfield_download": (I, [P, PD]),
+        "ocn_hfield_fill_halos": (I, [P]),
+        "ocn_sefs_create": (I, [P, D, I, C.POINTER(P)]),
+        "ocn_sefs_destroy": (None, [P]),
+        "ocn_sefs_field": (P, [P, I]),
+        "ocn_sefs_set_weights": (I, [P, I, PD, PD]),
+        "ocn_sefs_substep": (I, [P, D, I]),
+        "ocn_sefs_substeps": (I, [P, D, I, I, I]),
+        "ocn_sefs_graph_replays": (I, [P, C.POINTER(C.c_int64)]),
+        "ocn_sefs_barotropic_mode": (I, [P, P, P, I]),
+        "ocn_sefs_set_average_to_zero": (I, [P]),
+        "ocn_sefs_corrector": (I, [P, P, P]),
+        "ocn_sefs_step": (I, [P, P, P, P, P, D, D]),
         "ocn_profile_enable": (I, [P, I]),
         "ocn_profile_read": (I, [P, C.c_char_p, PD, C.POINTER(C.c_int64)]),
         "ocn_profile_reset": (I, [P]),

@@ -1,0 +1,691 @@
+// splitexplicit.hip -- SplitExplicitFreeSurface of the HydrostaticFreeSurfaceModel (BASELINE config 5, first slice):
+// the barotropic sub-cycling, the vertical integrals and the corrector, on a RectilinearGrid or a LatitudeLongitudeGrid.
+//
+//   reference (paths relative to /root/reference/src)                                         here
+//   Models/HydrostaticFreeSurfaceModels/split_explicit_free_surface_kernels.jl:14-19  kernel 1    k_se_uv
+//                                                                     :21-29          kernel 2    k_se_eta
+//                                                                     :31-58  substep!            sefs_substep_plain
+//                                                                     :63-81  barotropic_mode!    k_se_vsum (+ fills)
+//                                                                     :83-87  set_average_to_zero!
+//                                                                     :89-113 corrector           k_se_correct
+//                                                                     :124-171 split_explicit_free_surface_step!  ocn_sefs_step
+//   split_explicit_free_surface.jl:78-117 (state, auxiliary), :137-154 (settings)                 ocn_sefs_create
+//   Grids/latitude_longitude_grid.jl:174-213,418-445 (regular longitude / latitude, precomputed metrics)   ocn_hgrid_create
+//   BoundaryConditions/fill_halo_regions*.jl for Field{LX, LY, Nothing} / 3-D fields in x and y  k_h_fill_*
+//
+// The loop over the substeps is the hot part: 200 substeps of five tiny launches each (fill eta, kernel 1, fill U, fill V,
+// kernel 2) in the reference -- 1000 launches of a few microseconds per time step, all latency.  ocn_sefs_substeps runs the
+// same arithmetic as TWO launches per substep (k_se_uv_fused: the eta fill, kernel 1 and the U / V fills in one pass, every
+// thread writing its value and its halo images; k_se_eta) and replays the whole train from a hipGraph; it leaves exactly
+// the bits the launch-by-launch path leaves, halos included (tests/test_reference_split_explicit.py).
+#include "internal.h"
+
+enum { HG_RECT = 0, HG_LATLON = 1 };
+
+struct ocn_hgrid {
+  ocn_ctx* ctx;
+  int kind;
+  int N[3], H[3], topo[3];
+  double x0[3], L[3], radius;
+  bool z_regular;
+  std::vector<double> nodeF[3], nodeC[3];          // incl. halos, entry [i - 1 + H] for reference index i
+  std::vector<double> h_dxfc, h_dxcf, h_dyfc, h_dycf, h_azcc, h_dzc;   // per row j (entry [j - 1 + Hy]) / per level k (entry [k - 1])
+  double *dxfc = nullptr, *dxcf = nullptr, *dyfc = nullptr, *dycf = nullptr, *azcc = nullptr, *dzc = nullptr;   // device copies
+};
+
+struct ocn_hfield {
+  ocn_hgrid* g;
+  int loc[3];          // OCN_CENTER / OCN_FACE; loc[2] == OCN_NOTHING: reduced in z
+  int T[3], S[3];      // parent size, interior size
+  double* d = nullptr;
+  size_t n = 0;
+  bool owned = true;
+};
+
+struct ocn_sefs {
+  ocn_hgrid* g;
+  double grav;
+  int substeps;
+  std::vector<double> wv, wf;
+  ocn_hfield *eta, *U, *V, *etabar, *Ubar, *Vbar, *GU, *GV, *Hfc, *Hcf, *Hcc;
+  ocn_hfield *Gu = nullptr, *Gv = nullptr;   // scratch of ocn_sefs_step (AB2-combined tendencies are summed on the fly: unused)
+  // hipGraph of a train of substeps: key = (dtau bits, first index, count)
+  struct Train { uint64_t dtau_bits; int first, count; void* exec; };
+  std::vector<Train> trains;
+  int64_t graph_replays = 0;
+};
+
+static int total_len(int loc, int topo, int N, int H) {
+  if (loc == OCN_NOTHING) return 1;
+  return (loc == OCN_FACE && topo == OCN_BOUNDED) ? N + 1 + 2 * H : N + 2 * H;
+}
+static int interior_len(int loc, int topo, int N) {
+  if (loc == OCN_NOTHING) return 1;
+  return (loc == OCN_FACE && topo == OCN_BOUNDED) ? N + 1 : N;
+}
+
+// regular axis: Grids/grid_generation.jl:77-107 (L / N once, nodes as an evenly spaced range incl. halos)
+static void regular_axis(double c1, double L, int N, int H, int topo, std::vector<double>& F, std::vector<double>& C, double& d) {
+  d = (double)((long double)L / N);
+  const int TF = total_len(OCN_FACE, topo, N, H), TC = total_len(OCN_CENTER, topo, N, H);
+  const long double dl = (long double)L / N;
+  const double Fm = (double)((long double)c1 - H * dl);
+  const double Fp = (double)((long double)c1 - H * dl + (long double)L + (topo == OCN_BOUNDED ? 2 * H : 2 * H - 1) * dl);
+  const double Cm = (double)((long double)c1 - H * dl + dl / 2);
+  const double Cp = (double)((long double)c1 - H * dl + dl / 2 + (long double)L + dl * (2 * H - 1));
+  F.resize(TF);
+  C.resize(TC);
+  for (int i = 0; i < TF; ++i) F[i] = TF > 1 ? Fm + i * ((Fp - Fm) / (TF - 1)) : Fm;
+  if (TF > 1) F[TF - 1] = Fp;
+  for (int i = 0; i < TC; ++i) C[i] = TC > 1 ? Cm + i * ((Cp - Cm) / (TC - 1)) : Cm;
+  if (TC > 1) C[TC - 1] = Cp;
+}
+
+static int upload(ocn_ctx* ctx, const std::vector<double>& h, double** d) {
+  OCN_HIP_CHECK(ctx, hipMalloc((void**)d, (h.size() ? h.size() : 1) * sizeof(double)));
+  if (!h.empty()) OCN_HIP_CHECK(ctx, hipMemcpy(*d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+  return OCN_OK;
+}
+
+// ---- halo fills in x and y (every level of a 3-D field; one level of a reduced field) -----------------------------------------
+// periodic: fill_halo_regions_periodic.jl:37-65 -- one thread per line, the H copies in sequence, whole extent of the other dims
+__global__ void k_h_fill_periodic(double* p, int dim, int N, int H, int Tx, int Ty, int Tz) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  const long sy = Tx, sz = (long)Tx * Ty;
+  if (k >= Tz) return;
+  long base, st;
+  if (dim == 0) {
+    if (a >= Ty) return;
+    base = (long)a * sy + k * sz;
+    st = 1;
+  } else {
+    if (a >= Tx) return;
+    base = a + k * sz;
+    st = sy;
+  }
+  for (int i = 0; i < H; ++i) {
+    p[base + i * st] = p[base + (N + i) * st];
+    p[base + (N + H + i) * st] = p[base + (H + i) * st];
+  }
+}
+// Bounded: Center -> no-flux (fill_halo_regions_flux.jl:16-35, first halo cell only); Face -> impenetrable
+// (fill_halo_regions_open.jl:34-39: the two boundary faces are zeroed).  Launched over the INTERIOR cells of the other direction.
+__global__ void k_h_fill_bounded(double* p, int dim, int face, int N, int H, int No, int Ho, int Tx, int Ty, int k0, int nk) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, k = k0 + blockIdx.y;      // interior levels only (the `:xz` / `:yz` launch)
+  if (a >= No || (int)blockIdx.y >= nk) return;
+  const long sy = Tx, sz = (long)Tx * Ty;
+  const long st = dim == 0 ? 1 : sy;
+  const long base = (dim == 0 ? (long)(a + Ho) * sy : (long)(a + Ho)) + k * sz;
+  if (face) {
+    p[base + (long)H * st] = 0.0;            // face 1
+    p[base + (long)(H + N) * st] = 0.0;      // face N + 1
+  } else {
+    p[base + (long)(H - 1) * st] = p[base + (long)H * st];               // c[0] = c[1]
+    p[base + (long)(H + N) * st] = p[base + (long)(H + N - 1) * st];     // c[N+1] = c[N]
+  }
+}
+
+static void hfield_fill(ocn_hfield* f) {
+  ocn_hgrid* g = f->g;
+  hipStream_t s = g->ctx->stream;
+  // non-periodic directions first (fill_halo_regions.jl:76-99)
+  int order[2] = {0, 1};
+  if (g->topo[0] == OCN_PERIODIC && g->topo[1] != OCN_PERIODIC) { order[0] = 1; order[1] = 0; }
+  for (int t = 0; t < 2; ++t) {
+    const int d = order[t], o = 1 - d;
+    if (g->topo[d] == OCN_PERIODIC) {
+      if (g->H[d] == 0) continue;
+      const int na = d == 0 ? f->T[1] : f->T[0];
+      ocn_launch(k_h_fill_periodic, dim3((na + 127) / 128, f->T[2], 1), dim3(128, 1, 1), s, f->d, d, g->N[d], g->H[d], f->T[0], f->T[1], f->T[2]);
+    } else {
+      if (g->H[d] == 0 && f->loc[d] == OCN_CENTER) continue;
+      const int k0 = f->loc[2] == OCN_NOTHING ? 0 : g->H[2], nk = f->loc[2] == OCN_NOTHING ? 1 : g->N[2];
+      ocn_launch(k_h_fill_bounded, dim3((g->N[o] + 127) / 128, nk, 1), dim3(128, 1, 1), s, f->d, d, f->loc[d] == OCN_FACE ? 1 : 0,
+                 g->N[d], g->H[d], g->N[o], g->H[o], f->T[0], f->T[1], k0, nk);
+    }
+  }
+}
+
+// ---- the two substep kernels ---------------------------------------------------------------------------------------------
+struct SeArgs {
+  double *eta, *U, *V, *etabar, *Ubar, *Vbar;
+  const double *GU, *GV, *Hfc, *Hcf;
+  const double *dxfc, *dycf, *dyfc, *dxcf, *azcc;   // per row, entry [j + Hy] for the 0-based row j
+  int Nx, Ny, Hx, Hy;
+  long se, su, sv;                                   // row pitch of the Center-Center, Face-Center and Center-Face parents
+  double g, dtau, wv, wf;
+  int xper, yper;
+};
+
+// kernel 1 (:14-19):  U += dtau (-g H^fc d_x eta + G^U),  V += dtau (-g H^cf d_y eta + G^V)   over i = 1..Nx, j = 1..Ny
+__global__ void k_se_uv(SeArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= a.Nx || j >= a.Ny) return;
+  const long ce = (i + a.Hx) + (long)(j + a.Hy) * a.se, cu = (i + a.Hx) + (long)(j + a.Hy) * a.su, cv = (i + a.Hx) + (long)(j + a.Hy) * a.sv;
+  const double e0 = a.eta[ce];
+  const double ddx = (e0 - a.eta[ce - 1]) / a.dxfc[j + a.Hy];
+  const double ddy = (e0 - a.eta[ce - a.se]) / a.dycf[j + a.Hy];
+  a.U[cu] += a.dtau * (-a.g * a.Hfc[cu] * ddx + a.GU[cu]);
+  a.V[cv] += a.dtau * (-a.g * a.Hcf[cv] * ddy + a.GV[cv]);
+}
+
+// kernel 2 (:21-29):  eta -= dtau div_xy(U, V);  averages
+__global__ void k_se_eta(SeArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= a.Nx || j >= a.Ny) return;
+  const long ce = (i + a.Hx) + (long)(j + a.Hy) * a.se, cu = (i + a.Hx) + (long)(j + a.Hy) * a.su, cv = (i + a.Hx) + (long)(j + a.Hy) * a.sv;
+  const int r = j + a.Hy;
+  const double u0 = a.U[cu], v0 = a.V[cv];
+  const double div = 1.0 / a.azcc[r] * ((a.dyfc[r] * a.U[cu + 1] - a.dyfc[r] * u0) + (a.dxcf[r + 1] * a.V[cv + a.sv] - a.dxcf[r] * v0));
+  const double e1 = a.eta[ce] - a.dtau * div;
+  a.eta[ce] = e1;
+  a.Ubar[cu] += a.wv * u0;
+  a.Vbar[cv] += a.wv * v0;
+  a.etabar[ce] += a.wf * e1;
+}
+
+// The eta fill, kernel 1 and the U / V fills of one substep in ONE pass (Periodic x; y Periodic or Bounded; N >= H in the
+// periodic directions).  A thread owns cell (i, j), i = 0..Nx-1, j = 0..Ny-1 (+ the row j = Ny when y is Bounded: the north
+// boundary face of V and the no-flux halo row of eta / U are written by the threads of row Ny-1):
+//   * eta of the west / south neighbour is read with the periodic wrap (what the eta fill would have put into the halo) or,
+//     at a wall, is the no-flux copy (d_y eta = 0 across the wall: V at face 1 is then zeroed by its impenetrable fill anyway);
+//   * it writes eta's halo images of its own cell (the fill of eta that precedes kernel 1 in the reference), its new U and
+//     V, and their halo images (the fills that follow kernel 1): value-for-value what the five launches leave.
+__global__ void k_se_uv_fused(SeArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= a.Nx || j >= a.Ny) return;
+  const int Nx = a.Nx, Ny = a.Ny, Hx = a.Hx, Hy = a.Hy;
+  const int iw = i > 0 ? i - 1 : Nx - 1;                         // x is Periodic
+  const int js = j > 0 ? j - 1 : (a.yper ? Ny - 1 : 0);          // y wall: eta[0] = eta[1] (no-flux fill)
+  const long ce = (i + Hx) + (long)(j + Hy) * a.se, cu = (i + Hx) + (long)(j + Hy) * a.su, cv = (i + Hx) + (long)(j + Hy) * a.sv;
+  const double e0 = a.eta[ce];
+  const double ew = a.eta[(iw + Hx) + (long)(j + Hy) * a.se], es = a.eta[(i + Hx) + (long)(js + Hy) * a.se];
+  const double ddx = (e0 - ew) / a.dxfc[j + Hy];
+  const double ddy = (e0 - es) / a.dycf[j + Hy];
+  double un = a.U[cu] + a.dtau * (-a.g * a.Hfc[cu] * ddx + a.GU[cu]);
+  double vn = a.V[cv] + a.dtau * (-a.g * a.Hcf[cv] * ddy + a.GV[cv]);
+  if (!a.yper && j == 0) vn = 0.0;                               // impenetrable south face (fill after kernel 1)
+  // own values and their images: the x images live in the columns i - Nx (if i >= Nx - Hx) and i + Nx (if i < Hx); the y images
+  // likewise when y is Periodic; with a wall in y the first halo row copies the edge row (eta, U: no-flux) / the north face of V is 0.
+  const bool xw = i >= Nx - Hx, xe = i < Hx;
+  auto put = [&](double* p, long pitch, double val, int jj, bool own = true) {
+    const long row = (long)(jj + Hy) * pitch;
+    if (own) p[(i + Hx) + row] = val;
+    if (xw) p[(i - Nx + Hx) + row] = val;
+    if (xe) p[(i + Nx + Hx) + row] = val;
+  };
+  put(a.eta, a.se, e0, j, false);       // interior cells of eta are read by the neighbours in this pass: images only
+  put(a.U, a.su, un, j);
+  put(a.V, a.sv, vn, j);
+  if (a.yper) {
+    if (j >= Ny - Hy) { put(a.eta, a.se, e0, j - Ny); put(a.U, a.su, un, j - Ny); put(a.V, a.sv, vn, j - Ny); }
+    if (j < Hy) { put(a.eta, a.se, e0, j + Ny); put(a.U, a.su, un, j + Ny); put(a.V, a.sv, vn, j + Ny); }
+  } else {
+    // no-flux rows of eta and U over the interior columns only (the launch range of the Bounded fill), then their periodic
+    // x images come from the x fill that runs AFTER the Bounded one: over the whole y extent, halo rows included
+    if (j == 0) { put(a.eta, a.se, e0, -1); put(a.U, a.su, un, -1); }
+    if (j == Ny - 1) { put(a.eta, a.se, e0, Ny); put(a.U, a.su, un, Ny); put(a.V, a.sv, 0.0, Ny); }
+  }
+}
+
+// ---- vertical integrals and the corrector ----------------------------------------------------------------------------------
+// sum!(U, u * dz): level 1 first, then level by level (a sequential sum per column; coalesced across i).  With cm != 0 the
+// summand is the AB2 combination (cn G^n + cm G^-) dz of calc_ab2_tendencies (:115) formed on the fly.
+__global__ void k_se_vsum(double* out, const double* a, const double* b, double cn, double cm, const double* dzc, int Sx, int Sy, int Nz,
+                          int Hx, int Hy, int Hz, long sy3, long sz3, long sy2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= Sx || j >= Sy) return;
+  const long c3 = (i + Hx) + (long)(j + Hy) * sy3 + (long)Hz * sz3;
+  double acc = 0.0;
+  for (int k = 0; k < Nz; ++k) {
+    const double q = b ? (cn * a[c3 + k * sz3] - cm * b[c3 + k * sz3]) : a[c3 + k * sz3];
+    acc = k == 0 ? q * dzc[0] : acc + q * dzc[k];
+  }
+  out[(i + Hx) + (long)(j + Hy) * sy2] = acc;
+}
+
+// barotropic_split_explicit_corrector_kernel! (:89-95) over i = 1..Nx, j = 1..Ny, k = 1..Nz
+__global__ void k_se_correct(double* u, double* v, const double* U, const double* V, const double* Ub, const double* Vb, const double* Hfc,
+                             const double* Hcf, int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, long su3, long szu, long sv3, long szv,
+                             long su2, long sv2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
+  if (i >= Nx || j >= Ny || k >= Nz) return;
+  const long cu2 = (i + Hx) + (long)(j + Hy) * su2, cv2 = (i + Hx) + (long)(j + Hy) * sv2;
+  const long cu3 = (i + Hx) + (long)(j + Hy) * su3 + (long)(k + Hz) * szu, cv3 = (i + Hx) + (long)(j + Hy) * sv3 + (long)(k + Hz) * szv;
+  u[cu3] = u[cu3] + (-U[cu2] + Ub[cu2]) / Hfc[cu2];
+  v[cv3] = v[cv3] + (-V[cv2] + Vb[cv2]) / Hcf[cv2];
+}
+
+__global__ void k_se_copy(double* dst, const double* src, size_t n) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) dst[q] = src[q];
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------
+static int api_done(ocn_ctx* ctx, int rc) {
+#ifndef OCN_HOST_EMU
+  if (g_ocn_launch_err.err != hipSuccess) {
+    if (rc == OCN_OK) {
+      ocn_set_error(ctx, "launch failed: %s [%s]", hipGetErrorString(g_ocn_launch_err.err), g_ocn_launch_err.what);
+      rc = OCN_EHIP;
+    }
+    g_ocn_launch_err.err = hipSuccess;
+  }
+#endif
+  return rc;
+}
+
+static SeArgs se_args(const ocn_sefs* s, double dtau, int index) {
+  const ocn_hgrid* g = s->g;
+  SeArgs a;
+  a.eta = s->eta->d; a.U = s->U->d; a.V = s->V->d; a.etabar = s->etabar->d; a.Ubar = s->Ubar->d; a.Vbar = s->Vbar->d;
+  a.GU = s->GU->d; a.GV = s->GV->d; a.Hfc = s->Hfc->d; a.Hcf = s->Hcf->d;
+  a.dxfc = g->dxfc; a.dycf = g->dycf; a.dyfc = g->dyfc; a.dxcf = g->dxcf; a.azcc = g->azcc;
+  a.Nx = g->N[0]; a.Ny = g->N[1]; a.Hx = g->H[0]; a.Hy = g->H[1];
+  a.se = s->eta->T[0]; a.su = s->U->T[0]; a.sv = s->V->T[0];
+  a.g = s->grav; a.dtau = dtau;
+  a.wv = s->wv[index - 1]; a.wf = s->wf[index - 1];
+  a.xper = g->topo[0] == OCN_PERIODIC; a.yper = g->topo[1] == OCN_PERIODIC;
+  return a;
+}
+
+static void se_shape(const ocn_hgrid* g, dim3& b, dim3& gr) {
+  b = dim3(64, 4, 1);
+  gr = dim3((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, 1);
+}
+
+// split_explicit_free_surface_substep! as the reference issues it
+static void sefs_substep_plain(ocn_sefs* s, double dtau, int index) {
+  dim3 b, gr;
+  se_shape(s->g, b, gr);
+  hipStream_t st = s->g->ctx->stream;
+  const SeArgs a = se_args(s, dtau, index);
+  hfield_fill(s->eta);
+  ocn_launch(k_se_uv, gr, b, st, a);
+  hfield_fill(s->U);
+  hfield_fill(s->V);
+  ocn_launch(k_se_eta, gr, b, st, a);
+}
+
+static bool sefs_fusable(const ocn_sefs* s) {
+  const ocn_hgrid* g = s->g;
+  if (g->topo[0] != OCN_PERIODIC || g->N[0] < g->H[0] || g->H[0] < 1 || g->H[1] < 1) return false;
+  if (g->topo[1] == OCN_PERIODIC && g->N[1] < g->H[1]) return false;
+  return true;
+}
+
+static void sefs_substep_fused(ocn_sefs* s, double dtau, int index) {
+  dim3 b, gr;
+  se_shape(s->g, b, gr);
+  hipStream_t st = s->g->ctx->stream;
+  const SeArgs a = se_args(s, dtau, index);
+  ocn_launch(k_se_uv_fused, gr, b, st, a);
+  ocn_launch(k_se_eta, gr, b, st, a);
+}
+
+static int hfield_new(ocn_hgrid* g, int lx, int ly, int lz, ocn_hfield** out) {
+  ocn_hfield* f = new ocn_hfield;
+  f->g = g;
+  const int loc[3] = {lx, ly, lz};
+  f->n = 1;
+  for (int d = 0; d < 3; ++d) {
+    f->loc[d] = loc[d];
+    f->T[d] = total_len(loc[d], g->topo[d], g->N[d], g->H[d]);
+    f->S[d] = interior_len(loc[d], g->topo[d], g->N[d]);
+    f->n *= (size_t)f->T[d];
+  }
+  if (hipMalloc((void**)&f->d, f->n * sizeof(double)) != hipSuccess) {
+    delete f;
+    ocn_set_error(g->ctx, "allocation of %zu bytes failed", f->n * sizeof(double));
+    return OCN_ENOMEM;
+  }
+  OCN_ASYNC(hipMemsetAsync(f->d, 0, f->n * sizeof(double), g->ctx->stream));
+  *out = f;
+  return OCN_OK;
+}
+
+static void vsum(ocn_sefs* s, ocn_hfield* out, const ocn_hfield* a, const ocn_hfield* b, double cn, double cm) {
+  const ocn_hgrid* g = s->g;
+  dim3 blk(64, 4, 1), gr((out->S[0] + 63) / 64, (out->S[1] + 3) / 4, 1);
+  ocn_launch(k_se_vsum, gr, blk, g->ctx->stream, out->d, (const double*)a->d, b ? (const double*)b->d : (const double*)nullptr, cn, cm,
+             (const double*)g->dzc, out->S[0], out->S[1], g->N[2], g->H[0], g->H[1], g->H[2], (long)a->T[0], (long)a->T[0] * a->T[1], (long)out->T[0]);
+}
+
+static bool same_shape(const ocn_hfield* a, const ocn_hfield* b) {
+  return a && b && a->g == b->g && a->T[0] == b->T[0] && a->T[1] == b->T[1] && a->T[2] == b->T[2];
+}
+
+extern "C" {
+
+int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* d, ocn_hgrid** out) {
+  if (!ctx || !d || !out) return OCN_EINVAL;
+  if (d->kind != HG_RECT && d->kind != HG_LATLON) return OCN_EINVAL;
+  for (int q = 0; q < 3; ++q)
+    if (d->N[q] < 1 || d->H[q] < 0 || (q < 2 && !(d->L[q] > 0))) {
+      ocn_set_error(ctx, "ocn_hgrid_create: invalid size / halo / extent in direction %d", q);
+      return OCN_EINVAL;
+    }
+  if ((d->topology[0] != OCN_PERIODIC && d->topology[0] != OCN_BOUNDED) || (d->topology[1] != OCN_PERIODIC && d->topology[1] != OCN_BOUNDED) ||
+      d->topology[2] != OCN_BOUNDED) {
+    ocn_set_error(ctx, "ocn_hgrid_create: x and y must be Periodic or Bounded and z Bounded (hydrostatic_free_surface_model.jl:118-119)");
+    return OCN_EUNSUPPORTED;
+  }
+  if (d->kind == HG_LATLON && (d->L[0] > 360 || d->x0[1] < -90 || d->x0[1] + d->L[1] > 90 || d->topology[1] != OCN_BOUNDED)) {
+    ocn_set_error(ctx, "ocn_hgrid_create: longitude must span at most 360 degrees, latitude must lie in [-90, 90] and be Bounded");
+    return OCN_EINVAL;
+  }
+  ocn_hgrid* g = new ocn_hgrid;
+  g->ctx = ctx;
+  g->kind = d->kind;
+  for (int q = 0; q < 3; ++q) { g->N[q] = d->N[q]; g->H[q] = d->H[q]; g->topo[q] = d->topology[q]; g->x0[q] = d->x0[q]; g->L[q] = d->L[q]; }
+  g->radius = d->radius > 0 ? d->radius : 6371.0e3;
+  double dx, dy, dz = 0;
+  regular_axis(g->x0[0], g->L[0], g->N[0], g->H[0], g->topo[0], g->nodeF[0], g->nodeC[0], dx);
+  regular_axis(g->x0[1], g->L[1], g->N[1], g->H[1], g->topo[1], g->nodeF[1], g->nodeC[1], dy);
+  g->z_regular = d->z_faces == nullptr;
+  g->h_dzc.assign(g->N[2], 0.0);
+  if (g->z_regular) {
+    if (!(d->L[2] > 0)) { delete g; return OCN_EINVAL; }
+    regular_axis(g->x0[2], g->L[2], g->N[2], g->H[2], OCN_BOUNDED, g->nodeF[2], g->nodeC[2], dz);
+    for (int k = 0; k < g->N[2]; ++k) g->h_dzc[k] = dz;
+  } else {
+    for (int k = 0; k < g->N[2]; ++k) {
+      g->h_dzc[k] = d->z_faces[k + 1] - d->z_faces[k];       // grid_generation.jl:53: dz^c[k] = F[k+1] - F[k]
+      if (!(g->h_dzc[k] > 0)) { delete g; ocn_set_error(ctx, "z_faces must be strictly increasing"); return OCN_EINVAL; }
+    }
+    g->nodeF[2].assign(d->z_faces, d->z_faces + g->N[2] + 1);
+    g->nodeC[2].resize(g->N[2]);
+    for (int k = 0; k < g->N[2]; ++k) g->nodeC[2][k] = (d->z_faces[k + 1] + d->z_faces[k]) / 2;
+    g->L[2] = d->z_faces[g->N[2]] - d->z_faces[0];
+  }
+  const int ny = g->N[1] + 2 * g->H[1] + 1;
+  g->h_dxfc.assign(ny, 0); g->h_dxcf.assign(ny, 0); g->h_dyfc.assign(ny, 0); g->h_dycf.assign(ny, 0); g->h_azcc.assign(ny, 0);
+  if (g->kind == HG_RECT) {
+    for (int r = 0; r < ny; ++r) { g->h_dxfc[r] = dx; g->h_dxcf[r] = dx; g->h_dyfc[r] = dy; g->h_dycf[r] = dy; g->h_azcc[r] = dx * dy; }
+  } else {
+    // latitude_longitude_grid.jl:418-445 (regular longitude and latitude)
+    const double R = g->radius, dlam = dx * (M_PI / 180.0), dphi = dy * (M_PI / 180.0);
+    auto cosd = [](double p) { return cos(M_PI * p / 180.0); };
+    auto sind = [](double p) { return sin(M_PI * p / 180.0); };
+    const std::vector<double>&Fy = g->nodeF[1], &Cy = g->nodeC[1];
+    for (int r = 0; r < ny; ++r) {
+      g->h_dxfc[r] = r < (int)Cy.size() ? R * cosd(Cy[r]) * dlam : NAN;
+      g->h_dxcf[r] = r < (int)Fy.size() ? R * cosd(Fy[r]) * dlam : NAN;
+      g->h_dyfc[r] = R * dphi;
+      g->h_dycf[r] = R * dphi;
+      g->h_azcc[r] = r + 1 < (int)Fy.size() ? R * R * dlam * (sind(Fy[r + 1]) - sind(Fy[r])) : NAN;
+    }
+  }
+  int rc = upload(ctx, g->h_dxfc, &g->dxfc);
+  if (!rc) rc = upload(ctx, g->h_dxcf, &g->dxcf);
+  if (!rc) rc = upload(ctx, g->h_dyfc, &g->dyfc);
+  if (!rc) rc = upload(ctx, g->h_dycf, &g->dycf);
+  if (!rc) rc = upload(ctx, g->h_azcc, &g->azcc);
+  if (!rc) rc = upload(ctx, g->h_dzc, &g->dzc);
+  if (rc) { ocn_hgrid_destroy(g); return rc; }
+  *out = g;
+  return OCN_OK;
+}
+
+void ocn_hgrid_destroy(ocn_hgrid* g) {
+  if (!g) return;
+  hipFree(g->dxfc); hipFree(g->dxcf); hipFree(g->dyfc); hipFree(g->dycf); hipFree(g->azcc); hipFree(g->dzc);
+  delete g;
+}
+
+/* which: 0 dx^fc, 1 dx^cf, 2 dy^fc, 3 dy^cf, 4 Az^cc (rows j = 1 - Hy ...), 5 dz^c (levels 1..Nz),
+ * 6 / 7 x nodes Face / Center, 8 / 9 y nodes Face / Center (incl. halos); returns the number of entries, copies min(n, entries) */
+int ocn_hgrid_metric(const ocn_hgrid* g, int which, double* host, int n) {
+  if (!g || !host || n < 0) return OCN_EINVAL;
+  const std::vector<double>* v = nullptr;
+  switch (which) {
+    case 0: v = &g->h_dxfc; break;
+    case 1: v = &g->h_dxcf; break;
+    case 2: v = &g->h_dyfc; break;
+    case 3: v = &g->h_dycf; break;
+    case 4: v = &g->h_azcc; break;
+    case 5: v = &g->h_dzc; break;
+    case 6: v = &g->nodeF[0]; break;
+    case 7: v = &g->nodeC[0]; break;
+    case 8: v = &g->nodeF[1]; break;
+    case 9: v = &g->nodeC[1]; break;
+    default: return OCN_EINVAL;
+  }
+  const int m = (int)v->size() < n ? (int)v->size() : n;
+  for (int q = 0; q < m; ++q) host[q] = (*v)[q];
+  return (int)v->size();
+}
+
+int ocn_hfield_create(ocn_hgrid* g, int locx, int locy, int locz, ocn_hfield** out) {
+  if (!g || !out) return OCN_EINVAL;
+  if ((locx != OCN_CENTER && locx != OCN_FACE) || (locy != OCN_CENTER && locy != OCN_FACE) || (locz != OCN_CENTER && locz != OCN_NOTHING)) {
+    ocn_set_error(g->ctx, "ocn_hfield_create: locations must be Center / Face in x and y, Center or Nothing in z");
+    return OCN_EINVAL;
+  }
+  return hfield_new(g, locx, locy, locz, out);
+}
+
+void ocn_hfield_destroy(ocn_hfield* f) {
+  if (!f) return;
+  hipStreamSynchronize(f->g->ctx->stream);
+  if (f->owned) hipFree(f->d);
+  delete f;
+}
+
+int ocn_hfield_shape(const ocn_hfield* f, int32_t total[3], int32_t interior[3], int32_t halo[3]) {
+  if (!f) return OCN_EINVAL;
+  for (int d = 0; d < 3; ++d) {
+    if (total) total[d] = f->T[d];
+    if (interior) interior[d] = f->S[d];
+    if (halo) halo[d] = f->loc[d] == OCN_NOTHING ? 0 : f->g->H[d];
+  }
+  return OCN_OK;
+}
+
+void* ocn_hfield_ptr(ocn_hfield* f) { return f ? (void*)f->d : nullptr; }
+
+int ocn_hfield_upload(ocn_hfield* f, const double* host_parent) {
+  if (!f || !host_parent) return OCN_EINVAL;
+  OCN_HIP_CHECK(f->g->ctx, hipStreamSynchronize(f->g->ctx->stream));
+  OCN_HIP_CHECK(f->g->ctx, hipMemcpy(f->d, host_parent, f->n * sizeof(double), hipMemcpyHostToDevice));
+  return OCN_OK;
+}
+
+int ocn_hfield_download(const ocn_hfield* f, double* host_parent) {
+  if (!f || !host_parent) return OCN_EINVAL;
+  OCN_HIP_CHECK(f->g->ctx, hipStreamSynchronize(f->g->ctx->stream));
+  OCN_HIP_CHECK(f->g->ctx, hipMemcpy(host_parent, f->d, f->n * sizeof(double), hipMemcpyDeviceToHost));
+  return api_done(f->g->ctx, OCN_OK);
+}
+
+int ocn_hfield_fill_halos(ocn_hfield* f) {
+  if (!f) return OCN_EINVAL;
+  hfield_fill(f);
+  return api_done(f->g->ctx, OCN_OK);
+}
+
+int ocn_sefs_create(ocn_hgrid* g, double gravitational_acceleration, int substeps, ocn_sefs** out) {
+  if (!g || !out || substeps < 1) return OCN_EINVAL;
+  ocn_sefs* s = new ocn_sefs;
+  s->g = g;
+  s->grav = gravitational_acceleration;
+  s->substeps = substeps;
+  s->wv.assign(substeps, 1.0 / substeps);       // SplitExplicitSettings: ones(substeps) ./ substeps
+  s->wf.assign(substeps, 1.0 / substeps);
+  struct { ocn_hfield** f; int lx, ly; } tab[] = {
+      {&s->eta, OCN_CENTER, OCN_CENTER}, {&s->U, OCN_FACE, OCN_CENTER},    {&s->V, OCN_CENTER, OCN_FACE},   {&s->etabar, OCN_CENTER, OCN_CENTER},
+      {&s->Ubar, OCN_FACE, OCN_CENTER},  {&s->Vbar, OCN_CENTER, OCN_FACE}, {&s->GU, OCN_FACE, OCN_CENTER},  {&s->GV, OCN_CENTER, OCN_FACE},
+      {&s->Hfc, OCN_FACE, OCN_CENTER},   {&s->Hcf, OCN_CENTER, OCN_FACE},  {&s->Hcc, OCN_CENTER, OCN_CENTER}};
+  for (auto& t : tab) *t.f = nullptr;
+  for (auto& t : tab)
+    if (int rc = hfield_new(g, t.lx, t.ly, OCN_NOTHING, t.f)) {
+      ocn_sefs_destroy(s);
+      return rc;
+    }
+  // H = sum!(H, dz) over the interior of each depth field (split_explicit_free_surface.jl:103-110)
+  double H = 0.0;
+  for (int k = 0; k < g->N[2]; ++k) H = k == 0 ? g->h_dzc[0] : H + g->h_dzc[k];
+  for (ocn_hfield* f : {s->Hfc, s->Hcf, s->Hcc}) {
+    std::vector<double> h(f->n, 0.0);
+    for (int j = 0; j < f->S[1]; ++j)
+      for (int i = 0; i < f->S[0]; ++i) h[(i + g->H[0]) + (size_t)(j + g->H[1]) * f->T[0]] = H;
+    if (hipMemcpy(f->d, h.data(), f->n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+      ocn_sefs_destroy(s);
+      return OCN_EHIP;
+    }
+  }
+  *out = s;
+  return OCN_OK;
+}
+
+void ocn_sefs_destroy(ocn_sefs* s) {
+  if (!s) return;
+  hipStreamSynchronize(s->g->ctx->stream);
+#ifndef OCN_HOST_EMU
+  for (auto& t : s->trains)
+    if (t.exec) hipGraphExecDestroy((hipGraphExec_t)t.exec);
+#endif
+  for (ocn_hfield* f : {s->eta, s->U, s->V, s->etabar, s->Ubar, s->Vbar, s->GU, s->GV, s->Hfc, s->Hcf, s->Hcc})
+    if (f) {
+      hipFree(f->d);
+      delete f;
+    }
+  delete s;
+}
+
+ocn_hfield* ocn_sefs_field(ocn_sefs* s, int which) {
+  if (!s) return nullptr;
+  ocn_hfield* tab[] = {s->eta, s->U, s->V, s->etabar, s->Ubar, s->Vbar, s->GU, s->GV, s->Hfc, s->Hcf, s->Hcc};
+  return (which >= 0 && which < 11) ? tab[which] : nullptr;
+}
+
+int ocn_sefs_set_weights(ocn_sefs* s, int n, const double* velocity_weights, const double* free_surface_weights) {
+  if (!s || n < 1 || !velocity_weights || !free_surface_weights) return OCN_EINVAL;
+  s->substeps = n;
+  s->wv.assign(velocity_weights, velocity_weights + n);
+  s->wf.assign(free_surface_weights, free_surface_weights + n);
+#ifndef OCN_HOST_EMU
+  hipStreamSynchronize(s->g->ctx->stream);
+  for (auto& t : s->trains)
+    if (t.exec) hipGraphExecDestroy((hipGraphExec_t)t.exec);
+#endif
+  s->trains.clear();                              // the weights are baked into recorded launches
+  return OCN_OK;
+}
+
+int ocn_sefs_substep(ocn_sefs* s, double dtau, int substep_index) {
+  if (!s || substep_index < 1 || substep_index > s->substeps) return OCN_EINVAL;
+  sefs_substep_plain(s, dtau, substep_index);
+  return api_done(s->g->ctx, OCN_OK);
+}
+
+int ocn_sefs_substeps(ocn_sefs* s, double dtau, int first_index, int count, int fused) {
+  if (!s || first_index < 1 || count < 0 || first_index + count - 1 > s->substeps) return OCN_EINVAL;
+  ocn_ctx* ctx = s->g->ctx;
+  if (count == 0) return OCN_OK;
+  const bool fuse = fused && sefs_fusable(s);
+  auto issue = [&]() {
+    for (int q = 0; q < count; ++q) {
+      if (fuse) sefs_substep_fused(s, dtau, first_index + q);
+      else sefs_substep_plain(s, dtau, first_index + q);
+    }
+  };
+#ifndef OCN_HOST_EMU
+  static const bool no_graph = getenv("OCNHIP_NO_GRAPH") && atoi(getenv("OCNHIP_NO_GRAPH")) != 0;
+  if (fuse && count >= 4 && !no_graph && !ctx->profiling) {
+    uint64_t bits;
+    memcpy(&bits, &dtau, 8);
+    for (auto& t : s->trains)
+      if (t.dtau_bits == bits && t.first == first_index && t.count == count && t.exec) {
+        OCN_HIP_CHECK(ctx, hipGraphLaunch((hipGraphExec_t)t.exec, ctx->stream));
+        s->graph_replays += 1;
+        return api_done(ctx, OCN_OK);
+      }
+    // record the train (kernel arguments are captured by value: field pointers, dtau and the weights of each substep)
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      issue();
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+      if (e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess && exec) {
+        hipGraphDestroy(graph);
+        if (s->trains.size() >= 8) {
+          hipGraphExecDestroy((hipGraphExec_t)s->trains.front().exec);
+          s->trains.erase(s->trains.begin());
+        }
+        s->trains.push_back({bits, first_index, count, (void*)exec});
+        OCN_HIP_CHECK(ctx, hipGraphLaunch(exec, ctx->stream));
+        s->graph_replays += 1;
+        return api_done(ctx, OCN_OK);
+      }
+      if (graph) hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      g_ocn_launch_err.err = hipSuccess;
+    }
+  }
+#endif
+  issue();
+  return api_done(ctx, OCN_OK);
+}
+
+int ocn_sefs_graph_replays(const ocn_sefs* s, int64_t* replays) {
+  if (!s || !replays) return OCN_EINVAL;
+  *replays = s->graph_replays;
+  return OCN_OK;
+}
+
+int ocn_sefs_barotropic_mode(ocn_sefs* s, const ocn_hfield* u, const ocn_hfield* v, int into_forcing) {
+  if (!s || !u || !v) return OCN_EINVAL;
+  ocn_hfield *U = into_forcing ? s->GU : s->U, *V = into_forcing ? s->GV : s->V;
+  if (u->g != s->g || v->g != s->g || u->loc[2] != OCN_CENTER || v->loc[2] != OCN_CENTER || u->T[0] != U->T[0] || u->T[1] != U->T[1] ||
+      v->T[0] != V->T[0] || v->T[1] != V->T[1]) {
+    ocn_set_error(s->g->ctx, "ocn_sefs_barotropic_mode: u must be a (Face, Center, Center) and v a (Center, Face, Center) field of the free surface's grid");
+    return OCN_EINVAL;
+  }
+  vsum(s, U, u, nullptr, 0, 0);
+  vsum(s, V, v, nullptr, 0, 0);
+  hfield_fill(U);
+  hfield_fill(V);
+  return api_done(s->g->ctx, OCN_OK);
+}
+
+int ocn_sefs_set_average_to_zero(ocn_sefs* s) {
+  if (!s) return OCN_EINVAL;
+  for (ocn_hfield* f : {s->etabar, s->Ubar, s->Vbar}) OCN_ASYNC(hipMemsetAsync(f->d, 0, f->n * sizeof(double), s->g->ctx->stream));
+  return api_done(s->g->ctx, OCN_OK);
+}
+
+int ocn_sefs_corrector(ocn_sefs* s, ocn_hfield* u, ocn_hfield* v) {
+  if (!s || !u || !v) return OCN_EINVAL;
+  int rc = ocn_sefs_barotropic_mode(s, u, v, 0);
+  if (rc) return rc;
+  const ocn_hgrid* g = s->g;
+  dim3 blk(64, 4, 1), gr((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, g->N[2]);
+  ocn_launch(k_se_correct, gr, blk, g->ctx->stream, u->d, v->d, (const double*)s->U->d, (const double*)s->V->d, (const double*)s->Ubar->d,
+             (const double*)s->Vbar->d, (const double*)s->Hfc->d, (const double*)s->Hcf->d, g->N[0], g->N[1], g->N[2], g->H[0], g->H[1], g->H[2],
+             (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)s->U->T[0], (long)s->V->T[0]);
+  return api_done(g->ctx, OCN_OK);
+}
+
+int ocn_sefs_step(ocn_sefs* s, const ocn_hfield* Gnu, const ocn_hfield* Gnv, const ocn_hfield* Gmu, const ocn_hfield* Gmv, double dt, double chi) {
+  if (!s || !Gnu || !Gnv || !Gmu || !Gmv) return OCN_EINVAL;
+  if (!same_shape(Gnu, Gmu) || !same_shape(Gnv, Gmv) || Gnu->g != s->g || Gnu->loc[2] != OCN_CENTER || Gnu->T[0] != s->GU->T[0] ||
+      Gnu->T[1] != s->GU->T[1] || Gnv->T[0] != s->GV->T[0] || Gnv->T[1] != s->GV->T[1])
+    return OCN_EINVAL;
+  ocn_ctx* ctx = s->g->ctx;
+  const double dtau = 2 * dt / s->substeps;                        // "we evolve for two times the dt" (:137)
+  int rc = ocn_sefs_set_average_to_zero(s);
+  if (rc) return rc;
+  // barotropic_mode!(G^U, G^V, grid, Gu, Gv) with Gu = (1.5 + chi) G^n - (0.5 + chi) G^- formed inside the sum
+  vsum(s, s->GU, Gnu, Gmu, 1.5 + chi, 0.5 + chi);
+  vsum(s, s->GV, Gnv, Gmv, 1.5 + chi, 0.5 + chi);
+  hfield_fill(s->GU);
+  hfield_fill(s->GV);
+  if ((rc = ocn_sefs_substeps(s, dtau, 1, s->substeps, 1))) return rc;
+  // set!(eta, etabar) copies the parent array (Fields/set!.jl:41-44); then fill_halo_regions!(eta)
+  ocn_launch(k_se_copy, dim3((unsigned)((s->eta->n + 255) / 256), 1, 1), dim3(256, 1, 1), ctx->stream, s->eta->d, (const double*)s->etabar->d, s->eta->n);
+  hfield_fill(s->eta);
+  return api_done(ctx, OCN_OK);
+}
+
+}  // extern "C"

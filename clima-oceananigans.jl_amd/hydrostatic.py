@@ -1,0 +1,238 @@
+"""Host-side mirror of the HydrostaticFreeSurfaceModel pieces the library carries so far (BASELINE config 5, first slice):
+``LatitudeLongitudeGrid`` / ``RectilinearGrid`` as the free surface sees them, ``Field{LX, LY, LZ}`` on them, and
+``SplitExplicitFreeSurface`` with the reference's verbs -- ``split_explicit_free_surface_substep!``, ``barotropic_mode!``,
+``set_average_to_zero!``, ``barotropic_split_explicit_corrector!``, ``split_explicit_free_surface_step!``
+(Models/HydrostaticFreeSurfaceModels/split_explicit_free_surface.jl, split_explicit_free_surface_kernels.jl).
+Everything numerical happens in libocnhip.so (csrc/splitexplicit.hip); this file only marshals.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import check
+from .api import Bounded, Center, Face, Periodic, default_context
+
+Nothing = "Nothing"
+_TOPO = {Periodic: L.PERIODIC, Bounded: L.BOUNDED}
+_LOC = {Center: L.CENTER, Face: L.FACE, Nothing: L.NOTHING, None: L.NOTHING}
+R_Earth = 6371.0e3
+g_Earth = 9.80665
+
+
+class _HGrid:
+    def _create(self, ctx, kind, size, halo, topology, lo, ext, z, radius):
+        self.ctx = ctx or default_context()
+        self.lib = self.ctx.lib
+        d = L.HGridDesc()
+        d.kind = kind
+        self.topology = tuple(topology)
+        self.Nx, self.Ny, self.Nz = (int(n) for n in size)
+        self.Hx, self.Hy, self.Hz = (int(h) for h in halo)
+        for q in range(3):
+            d.N[q], d.H[q], d.topology[q] = int(size[q]), int(halo[q]), _TOPO[topology[q]]
+            d.x0[q], d.L[q] = float(lo[q]), float(ext[q])
+        self._zf = None
+        if z is not None and len(z) != 2:
+            self._zf = np.ascontiguousarray(z, dtype=np.float64)
+            if self._zf.size != self.Nz + 1:
+                raise ValueError("z must be (z1, z2) or hold Nz + 1 faces")
+            d.z_faces = self._zf.ctypes.data_as(C.POINTER(C.c_double))
+        d.radius = float(radius)
+        self.h = C.c_void_p()
+        check(self.lib.ocn_hgrid_create(self.ctx.h, C.byref(d), C.byref(self.h)), self.ctx.h)
+
+    def metric(self, which):
+        n = self.lib.ocn_hgrid_metric(self.h, int(which), (C.c_double * 1)(), 0)
+        out = np.zeros(n)
+        self.lib.ocn_hgrid_metric(self.h, int(which), out.ctypes.data_as(C.POINTER(C.c_double)), n)
+        return out
+
+    # the grid's own arrays, reference names; rows / nodes include halos (first entry = index 1 - H)
+    Δxᶠᶜᵃ = property(lambda s: s.metric(0)); Δxᶜᶠᵃ = property(lambda s: s.metric(1))
+    Δyᶠᶜᵃ = property(lambda s: s.metric(2)); Δyᶜᶠᵃ = property(lambda s: s.metric(3))
+    Azᶜᶜᵃ = property(lambda s: s.metric(4)); Δzᵃᵃᶜ = property(lambda s: s.metric(5))
+
+    def nodes(self, loc, d):
+        """interior nodes along x (d = 0) or y (d = 1)"""
+        a = self.metric((6 if loc == Face else 7) + 2 * d)
+        N, H = (self.Nx, self.Ny)[d], (self.Hx, self.Hy)[d]
+        n = N + 1 if (loc == Face and self.topology[d] == Bounded) else N
+        return a[H:H + n]
+
+    def znodes(self):
+        if self._zf is not None:
+            return 0.5 * (self._zf[1:] + self._zf[:-1])
+        dz = self.Δzᵃᵃᶜ
+        return self._z0 + np.cumsum(dz) - dz / 2
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.ocn_hgrid_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+
+class HRectilinearGrid(_HGrid):
+    """RectilinearGrid(size, x, y, z, halo, topology) with regular x and y, for the hydrostatic pieces"""
+
+    def __init__(self, size, x, y, z, halo=(3, 3, 3), topology=(Periodic, Periodic, Bounded), arch=None):
+        zr = z if len(z) == 2 else (z[0], z[-1])
+        self._z0 = float(zr[0])
+        self._create(arch, L.HGRID_RECTILINEAR, size, halo, topology, (x[0], y[0], zr[0]), (x[1] - x[0], y[1] - y[0], zr[1] - zr[0]), z, 0.0)
+
+
+class LatitudeLongitudeGrid(_HGrid):
+    """LatitudeLongitudeGrid(size, longitude, latitude, z, halo, radius) -- Grids/latitude_longitude_grid.jl:174-213; regular
+    longitude and latitude, metrics precomputed.  Topology as the reference chooses it: Periodic longitude iff it spans 360."""
+
+    def __init__(self, size, longitude, latitude, z, halo=(3, 3, 3), radius=R_Earth, topology=None, arch=None):
+        l1, l2 = longitude
+        p1, p2 = latitude
+        if not (l1 <= l2 and l2 - l1 <= 360 and -90 <= p1 <= p2 <= 90):
+            raise ValueError("longitude must span at most 360 degrees and latitude lie within [-90, 90]")
+        if topology is None:
+            topology = (Periodic if (l2 - l1) == 360 else Bounded, Bounded, Bounded)
+        zr = z if len(z) == 2 else (z[0], z[-1])
+        self._z0 = float(zr[0])
+        self.radius = float(radius)
+        self._create(arch, L.HGRID_LATLON, size, halo, topology, (l1, p1, zr[0]), (l2 - l1, p2 - p1, zr[1] - zr[0]), z, radius)
+
+
+class HField:
+    """Field{LX, LY, LZ}(grid), LZ = Center or Nothing: a dense parent array on the device"""
+
+    def __init__(self, grid, loc, handle=None):
+        self.grid, self.loc, self.lib = grid, tuple(loc), grid.lib
+        self._owned = handle is None
+        if handle is None:
+            self.h = C.c_void_p()
+            check(self.lib.ocn_hfield_create(grid.h, _LOC[loc[0]], _LOC[loc[1]], _LOC[loc[2]], C.byref(self.h)), grid.ctx.h)
+        else:
+            self.h = C.c_void_p(handle)
+        T, S, H = (C.c_int32 * 3)(), (C.c_int32 * 3)(), (C.c_int32 * 3)()
+        check(self.lib.ocn_hfield_shape(self.h, C.byref(T), C.byref(S), C.byref(H)), grid.ctx.h)
+        self.total, self.size, self.halo = tuple(T), tuple(S), tuple(H)
+
+    def parent(self):
+        a = np.zeros(self.total, order="F")
+        check(self.lib.ocn_hfield_download(self.h, a.ctypes.data_as(C.POINTER(C.c_double))), self.grid.ctx.h)
+        return a
+
+    def set_parent(self, a):
+        a = np.asarray(a, dtype=np.float64)
+        a = np.full(self.total, float(a)) if a.ndim == 0 else a.reshape(self.total)
+        a = np.asfortranarray(a)
+        check(self.lib.ocn_hfield_upload(self.h, a.ctypes.data_as(C.POINTER(C.c_double))), self.grid.ctx.h)
+
+    def _interior_slices(self):
+        return tuple(slice(h, h + s) for h, s in zip(self.halo, self.size))
+
+    def interior(self):
+        return self.parent()[self._interior_slices()]
+
+    def set(self, value):
+        """set!(field, number | array | function of the nodes): the interior; halos untouched (Fields/set!.jl)"""
+        p = self.parent()
+        it = p[self._interior_slices()]
+        if callable(value):
+            g = self.grid
+            X = g.nodes(self.loc[0], 0).reshape(-1, 1, 1)
+            Y = g.nodes(self.loc[1], 1).reshape(1, -1, 1)
+            if self.loc[2] in (Nothing, None):
+                it[...] = value(X, Y) + 0 * (X + Y)
+            else:
+                Z = g.znodes().reshape(1, 1, -1)
+                it[...] = value(X, Y, Z) + 0 * (X + Y + Z)
+        else:
+            it[...] = np.asarray(value, dtype=np.float64).reshape(it.shape) if np.ndim(value) else value
+        self.set_parent(p)
+
+    def fill(self, value):
+        """`field .= value` on the WHOLE parent array"""
+        self.set_parent(np.full(self.total, float(value)))
+
+    def fill_halo_regions(self):
+        check(self.lib.ocn_hfield_fill_halos(self.h), self.grid.ctx.h)
+
+    def device_ptr(self):
+        return self.lib.ocn_hfield_ptr(self.h)
+
+    def __del__(self):
+        try:
+            if self._owned and self.h:
+                self.lib.ocn_hfield_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+
+_SEFS_FIELDS = (("η", (Center, Center)), ("U", (Face, Center)), ("V", (Center, Face)), ("η̅", (Center, Center)),
+                ("U̅", (Face, Center)), ("V̅", (Center, Face)), ("Gᵁ", (Face, Center)), ("Gⱽ", (Center, Face)),
+                ("Hᶠᶜ", (Face, Center)), ("Hᶜᶠ", (Center, Face)), ("Hᶜᶜ", (Center, Center)))
+_ASCII = {"η": "eta", "U": "U", "V": "V", "η̅": "etabar", "U̅": "Ubar", "V̅": "Vbar", "Gᵁ": "GU", "Gⱽ": "GV",
+          "Hᶠᶜ": "Hfc", "Hᶜᶠ": "Hcf", "Hᶜᶜ": "Hcc"}
+
+
+class SplitExplicitFreeSurface:
+    """SplitExplicitFreeSurface(grid; gravitational_acceleration = g_Earth, settings = SplitExplicitSettings(substeps))"""
+
+    def __init__(self, grid, gravitational_acceleration=g_Earth, substeps=200):
+        self.grid, self.lib = grid, grid.lib
+        self.gravitational_acceleration = float(gravitational_acceleration)
+        self.h = C.c_void_p()
+        check(self.lib.ocn_sefs_create(grid.h, self.gravitational_acceleration, int(substeps), C.byref(self.h)), grid.ctx.h)
+        self.substeps = int(substeps)
+        self.fields = {}
+        for q, (name, loc) in enumerate(_SEFS_FIELDS):
+            f = HField(grid, loc + (Nothing,), handle=self.lib.ocn_sefs_field(self.h, q))
+            self.fields[name] = f
+            setattr(self, _ASCII[name], f)
+
+    def set_weights(self, velocity_weights, free_surface_weights):
+        vw = np.ascontiguousarray(velocity_weights, dtype=np.float64)
+        fw = np.ascontiguousarray(free_surface_weights, dtype=np.float64)
+        PD = C.POINTER(C.c_double)
+        check(self.lib.ocn_sefs_set_weights(self.h, vw.size, vw.ctypes.data_as(PD), fw.ctypes.data_as(PD)), self.grid.ctx.h)
+        self.substeps = vw.size
+
+    def substep(self, dtau, substep_index):
+        check(self.lib.ocn_sefs_substep(self.h, float(dtau), int(substep_index)), self.grid.ctx.h)
+
+    def substeps_train(self, dtau, first, count, fused=True):
+        check(self.lib.ocn_sefs_substeps(self.h, float(dtau), int(first), int(count), int(bool(fused))), self.grid.ctx.h)
+
+    @property
+    def graph_replays(self):
+        n = C.c_int64()
+        check(self.lib.ocn_sefs_graph_replays(self.h, C.byref(n)), self.grid.ctx.h)
+        return n.value
+
+    def barotropic_mode(self, U, V, u, v):
+        """barotropic_mode!(U, V, grid, u, v); (U, V) must be this free surface's (state.U, state.V) or (auxiliary.Gᵁ, Gⱽ)"""
+        if U is self.U and V is self.V:
+            into = 0
+        elif U is self.GU and V is self.GV:
+            into = 1
+        else:
+            raise ValueError("barotropic_mode: targets must be (state.U, state.V) or (auxiliary.Gᵁ, auxiliary.Gⱽ)")
+        check(self.lib.ocn_sefs_barotropic_mode(self.h, u.h, v.h, into), self.grid.ctx.h)
+
+    def set_average_to_zero(self):
+        check(self.lib.ocn_sefs_set_average_to_zero(self.h), self.grid.ctx.h)
+
+    def corrector(self, u, v):
+        check(self.lib.ocn_sefs_corrector(self.h, u.h, v.h), self.grid.ctx.h)
+
+    def step(self, Gnu, Gnv, Gmu, Gmv, dt, chi):
+        check(self.lib.ocn_sefs_step(self.h, Gnu.h, Gnv.h, Gmu.h, Gmv.h, float(dt), float(chi)), self.grid.ctx.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.ocn_sefs_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass

@@ -244,6 +244,66 @@ int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* unique_id128);
 int ocn_comm_probe(ocn_ctx* ctx, int rank, int nranks, const void* unique_id128, double timeout_s);
 int ocn_comm_rank(const ocn_ctx* ctx, int* rank, int* nranks);
 
+/* ---- HydrostaticFreeSurfaceModel, first slice: SplitExplicitFreeSurface on a RectilinearGrid or LatitudeLongitudeGrid
+ * (BASELINE config 5; Models/HydrostaticFreeSurfaceModels/split_explicit_free_surface.jl, split_explicit_free_surface_kernels.jl,
+ * Grids/latitude_longitude_grid.jl).  The 3-D momentum tendencies of that model are not part of this library yet: the caller
+ * hands their arrays in (ocn_hfield) exactly as ab2_step_free_surface! receives them from the time stepper. ------------------ */
+enum { OCN_NOTHING = 2 };   /* third field location: reduced along that direction (Field{LX, LY, Nothing}, Fields/field.jl:441-449) */
+enum { OCN_HGRID_RECTILINEAR = 0, OCN_HGRID_LATLON = 1 };
+typedef struct ocn_hgrid ocn_hgrid;     /* the grid as the free surface sees it: sizes, halos, topology, per-row metrics, level thicknesses */
+typedef struct ocn_hfield ocn_hfield;   /* a field on it: (Face|Center, Face|Center, Center|Nothing), dense parent array incl. halos          */
+typedef struct ocn_sefs ocn_sefs;       /* SplitExplicitFreeSurface(grid; gravitational_acceleration, settings)                            */
+
+/* RectilinearGrid(size, x, y, z, halo, topology) with regular x, y (metres), or
+ * LatitudeLongitudeGrid(size, longitude, latitude, z, halo, radius, precompute_metrics = true) with regular longitude / latitude
+ * (degrees; latitude_longitude_grid.jl:174-213: pass Periodic for x when the longitude spans 360 degrees, else Bounded; y Bounded).
+ * z is Bounded, regular (z_faces == NULL, x0[2] .. x0[2] + L[2]) or given by its Nz + 1 faces. */
+typedef struct ocn_hgrid_desc {
+  int32_t kind;          /* OCN_HGRID_*                                  */
+  int32_t N[3], H[3], topology[3];
+  double x0[3], L[3];
+  const double* z_faces; /* NULL or Nz + 1 doubles (host)                */
+  double radius;         /* lat-lon: sphere radius (<= 0: R_Earth, latitude_longitude_grid.jl:3) */
+} ocn_hgrid_desc;
+int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* desc, ocn_hgrid** out);
+void ocn_hgrid_destroy(ocn_hgrid* g);
+/* metrics and nodes as the grid object holds them (grid.Δxᶠᶜᵃ ... latitude_longitude_grid.jl:418-445; grid.φᵃᶠᵃ ...): which =
+ * 0 Δx^fc, 1 Δx^cf, 2 Δy^fc, 3 Δy^cf, 4 Az^cc (per row, first entry = row 1 - Hy), 5 Δz^c (levels 1..Nz), 6 / 7 x nodes Face /
+ * Center, 8 / 9 y nodes Face / Center (incl. halos).  Copies min(n, entries) doubles, returns the number of entries. */
+int ocn_hgrid_metric(const ocn_hgrid* g, int which, double* host, int n);
+/* Field{LX, LY, LZ}(grid), LZ = OCN_CENTER or OCN_NOTHING; zero-filled dense parent array (Grids/new_data.jl:16-61) */
+int ocn_hfield_create(ocn_hgrid* g, int locx, int locy, int locz, ocn_hfield** out);
+void ocn_hfield_destroy(ocn_hfield* f);
+int ocn_hfield_shape(const ocn_hfield* f, int32_t total[3], int32_t interior[3], int32_t halo[3]);
+void* ocn_hfield_ptr(ocn_hfield* f);                       /* device pointer of the parent array (Julia: unsafe_wrap)     */
+int ocn_hfield_upload(ocn_hfield* f, const double* host_parent);
+int ocn_hfield_download(const ocn_hfield* f, double* host_parent);
+int ocn_hfield_fill_halos(ocn_hfield* f);                  /* fill_halo_regions!(field) in x and y, default conditions      */
+/* SplitExplicitFreeSurface(grid; gravitational_acceleration, settings = SplitExplicitSettings(substeps))
+ * (split_explicit_free_surface.jl:46-60; H^fc, H^cf, H^cc = sum of dz :103-110; uniform weights :137-154) */
+int ocn_sefs_create(ocn_hgrid* g, double gravitational_acceleration, int substeps, ocn_sefs** out);
+void ocn_sefs_destroy(ocn_sefs* s);
+/* the free surface's own fields (owned by it): 0 η, 1 U, 2 V, 3 η̅, 4 U̅, 5 V̅, 6 Gᵁ, 7 Gⱽ, 8 Hᶠᶜ, 9 Hᶜᶠ, 10 Hᶜᶜ */
+ocn_hfield* ocn_sefs_field(ocn_sefs* s, int which);
+/* SplitExplicitSettings(substeps, velocity_weights, free_surface_weights)  (:130-135) */
+int ocn_sefs_set_weights(ocn_sefs* s, int n, const double* velocity_weights, const double* free_surface_weights);
+/* split_explicit_free_surface_substep!(η, state, auxiliary, settings, arch, grid, g, Δτ, substep_index)  (kernels.jl:31-58) */
+int ocn_sefs_substep(ocn_sefs* s, double dtau, int substep_index);
+/* `for substep in first:first+count-1 substep!(...) end` (kernels.jl:154-156).  fused != 0: two launches per substep instead
+ * of five, the whole train replayed from a hipGraph -- the same bits in every parent array, halos included. */
+int ocn_sefs_substeps(ocn_sefs* s, double dtau, int first_index, int count, int fused);
+int ocn_sefs_graph_replays(const ocn_sefs* s, int64_t* replays);
+/* barotropic_mode!(U, V, grid, u, v) (:76-81): into_forcing == 0 -> state.U, state.V; != 0 -> auxiliary.Gᵁ, Gⱽ */
+int ocn_sefs_barotropic_mode(ocn_sefs* s, const ocn_hfield* u, const ocn_hfield* v, int into_forcing);
+int ocn_sefs_set_average_to_zero(ocn_sefs* s);             /* (:83-87) */
+/* barotropic_split_explicit_corrector!(u, v, free_surface, grid) (:97-113) */
+int ocn_sefs_corrector(ocn_sefs* s, ocn_hfield* u, ocn_hfield* v);
+/* split_explicit_free_surface_step!(free_surface, model, Δt, χ, velocities_update) (:124-171) given timestepper.Gⁿ.u / .v and
+ * G⁻.u / .v: averages reset, barotropic mode of the AB2-combined tendencies, `substeps` substeps of Δτ = 2Δt / substeps,
+ * η ← η̅, halos of η filled */
+int ocn_sefs_step(ocn_sefs* s, const ocn_hfield* Gn_u, const ocn_hfield* Gn_v, const ocn_hfield* Gm_u, const ocn_hfield* Gm_v,
+                  double dt, double chi);
+
 /* ---- measurement helpers (bench.py) -------------------------------------------------------------- */
 /* average device time [ms] of the `n` most recent launches of the named phase, measured with HIP
  * events on the context stream when profiling is enabled */

@@ -30,3 +30,4 @@ from .model import (NonhydrostaticModel, WENO5, CenteredSecondOrder, CenteredFou
                     SeawaterBuoyancy, AnisotropicMinimumDissipation,
                     FluxBC, ValueBC, GradientBC, time_step, set_model)
 from . import poisson  # noqa: F401
+from . import split_explicit  # noqa: F401

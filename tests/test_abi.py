@@ -48,3 +48,19 @@ def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
 def test_python_binding_matches_header(ocn):
     sig = ocn._lib.load()._signatures
     assert sorted(sig) == declared_symbols()
+
+
+def test_build_entry_point_returns():
+    """__graft_entry__.build(): `make` of the product, the host emulation and the oracle's C pieces (no-ops when nothing changed),
+    then the product library is loaded and its ABI version compared with the binding's -- the driver's "does it build" step."""
+    import __graft_entry__ as ge
+    prev = os.environ.pop("OCNHIP_LIB", None)      # build() checks the PRODUCT library, not the emulation this test run uses
+    pkg = ge.load_package()
+    saved = pkg._lib._lib
+    pkg._lib._lib = None
+    try:
+        assert ge.build() is None
+    finally:
+        pkg._lib._lib = saved
+        if prev is not None:
+            os.environ["OCNHIP_LIB"] = prev
