@@ -16,6 +16,7 @@ thread_local ocn_launch_error g_ocn_launch_err = {hipSuccess, {0}};
 thread_local int g_ocn_capturing = 0, g_ocn_capture_poison = 0;
 
 static char g_last_error[512] = {0};
+static int pnhs_refresh(ocn_model* m);
 
 void ocn_set_error(ocn_ctx* ctx, const char* fmt, ...) {
   va_list ap;
@@ -102,8 +103,10 @@ void ocn_destroy(ocn_ctx* ctx) {
 
 int ocn_sync(ocn_ctx* ctx) {
   if (!ctx) return OCN_EINVAL;
-  for (ocn_model* m : ctx->models)   // exchanges still travelling on the communication stream belong to the step too
+  for (ocn_model* m : ctx->models) {   // exchanges still travelling on the communication stream belong to the step too,
     if (halo_settle(m)) return OCN_EHIP;
+    if (int rc = pnhs_refresh(m)) return rc;   // and so does the deferred one of pNHS
+  }
   OCN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   OCN_HIP_CHECK(ctx, hipGetLastError());
   return api_ret(ctx, OCN_OK);
@@ -548,6 +551,14 @@ int halo_settle(ocn_model* m) {
     if (int rc = halo_settle_one(o)) return rc;
   return OCN_OK;
 }
+// deferred z-halo exchange of pNHS (see ocn_model::pnhs_halo_stale); collective
+static int pnhs_refresh(ocn_model* m) {
+  if (!m->pnhs_halo_stale) return OCN_OK;
+  if (int rc = halo_settle(m)) return rc;
+  m->pnhs_halo_stale = false;
+  Field* fs[1] = {&m->pNHS};
+  return comm_halo_exchange_z(m, fs, 1);
+}
 static int halo_settle_others(ocn_model* m) {
   for (ocn_model* o : m->ctx->models)
     if (o != m)
@@ -611,20 +622,18 @@ static int fused_substep(ocn_model* m, double dt_full, double cn, double cm, int
       Field* fa[3 + OCN_MAX_TRACERS] = {&m->u, &m->v, &m->w};
       int na = 3;
       for (int t = 0; t < m->nt; ++t) fa[na++] = &m->tr[t];
-      Field* fb[1] = {&m->pNHS};
       OCN_HIP_CHECK(c, hipEventRecord(c->ev_main, c->stream));
       OCN_HIP_CHECK(c, hipStreamWaitEvent(c->comm_stream, c->ev_main, 0));
       if ((rc = comm_halo_exchange_z(m, fa, na, c->comm_stream))) return rc;
       OCN_HIP_CHECK(c, hipEventRecord(c->ev_halo, c->comm_stream));
-      if ((rc = comm_halo_exchange_z(m, fb, 1, c->comm_stream))) return rc;
-      OCN_HIP_CHECK(c, hipEventRecord(c->ev_halo2, c->comm_stream));
-      m->halo_inflight = m->halo2_inflight = true;
+      m->halo_inflight = true;
     } else {
-      Field* fs[4 + OCN_MAX_TRACERS] = {&m->u, &m->v, &m->w, &m->pNHS};
-      int nf = 4;
+      Field* fs[3 + OCN_MAX_TRACERS] = {&m->u, &m->v, &m->w};
+      int nf = 3;
       for (int t = 0; t < m->nt; ++t) fs[nf++] = &m->tr[t];
       if ((rc = comm_halo_exchange_z(m, fs, nf))) return rc;
     }
+    m->pnhs_halo_stale = true;   // the z halos of pNHS: exchanged when somebody can look at them (pnhs_refresh)
   }
   if (swap)
     for (int f = 0; f < 3 + m->nt; ++f) std::swap(m->Gn[f], m->Gm[f]);   // store_tendencies! as a pointer swap
@@ -1140,6 +1149,8 @@ int ocn_field_upload(ocn_model* m, int field_id, const double* host) {
 
 int ocn_field_download(const ocn_model* m, int field_id, double* host) {
   if (m && halo_settle(const_cast<ocn_model*>(m))) return OCN_EHIP;
+  if (m && field_id == OCN_F_PNHS)
+    if (int rc = pnhs_refresh(const_cast<ocn_model*>(m))) return rc;
   Field* f = model_field(const_cast<ocn_model*>(m), field_id);
   if (!f || !host) return OCN_EINVAL;
   return parent_download(m->ctx, f, host);
@@ -1255,6 +1266,7 @@ int ocn_fill_halos(ocn_model* m, uint32_t mask) {
   for (int t = 0; t < m->nt; ++t)
     if (mask & (1u << (8 + t))) fs[n++] = &m->tr[t];
   // fields of one call share one batched launch; aux fields (pressures) use their own z conditions
+  if (mask & (1u << 4)) m->pnhs_halo_stale = false;   // filled right here
   return api_ret(m->ctx, fill_fields(m, fs, n));
 }
 

@@ -129,7 +129,11 @@ struct ocn_model {
   std::vector<StepGraph> graphs;
   int knob_overlap_cus = 16; // CUs the interior tendency launch leaves to the communication kernels (OCNHIP_OVERLAP_CUS)
   int knob_overlap = -1;     // OCNHIP_OVERLAP=0|1: z-slab halo exchange overlapped with the next tendency launch (default: with > 1 rank)
-  bool halo_inflight = false, halo2_inflight = false;   // exchange of (u, v, w, tracers) / of pNHS started, not yet waited for
+  bool halo_inflight = false, halo2_inflight = false;   // exchange of (u, v, w, tracers) started, not yet waited for (halo2: unused since round 3)
+  // z-slab runs of the all-in-one path: nothing inside a time step reads the z halos of pNHS (the projection takes the one plane
+  // it needs through fused_exchange_phi), so their exchange -- 2 x H planes per step -- is deferred until somebody can look:
+  // ocn_sync, ocn_fill_halos(pNHS) and ocn_field_download(pNHS), all collective on slab runs (api.hip pnhs_refresh)
+  bool pnhs_halo_stale = false;
   int knob_xfft_team = 0;    // OCNHIP_XFFT_TEAM=1: the fused rhs + x transform loads in team order (the older variant; tests)
   int knob_graph = 1;        // OCNHIP_NO_GRAPH=1 clears it (model creation)
   bool graph_off = false;    // a capture failed: this model steps launch by launch from then on

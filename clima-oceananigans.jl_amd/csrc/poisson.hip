@@ -42,6 +42,7 @@ struct PoissonSolver {
   void* zsl = nullptr;                     // slab runs: transpose-free z stage (zslab.hip)
   double dz2 = 0;
   bool cxy = false;                        // custom x / y passes (zfft.hip): rhs fused into the x transform
+  bool cxy_bz = false;                     // Bounded z: the same passes around the tridiagonal sweeps (poisson_run_from_predictor_bz)
   void* tw = nullptr;                      // twiddle holder for the custom passes
   double* rhs = nullptr;      // real (Nx,Ny,Nz)
   double2_* spec = nullptr;   // complex (Nxh,Ny,Nz)
@@ -204,6 +205,16 @@ PoissonSolver* poisson_create(ocn_model* m) {
     s->tw = zsolve_create(m->ctx, one, one);
     s->cxy = s->tw != nullptr && (s->zs || s->zsl);
   }
+  // Bounded z (Fourier-tridiagonal solver) with 128-, 256- or 512-point periodic x and y: the same fused right-hand side + x
+  // pass and custom y passes in front of and behind the batched Thomas sweeps (round 3: config 3 spent 0.22 ms per stage in
+  // k_rhs + four rocFFT kernels where these passes take 0.15)
+  if (g->topo[2] == OCN_BOUNDED && s->kind == 1 && fft_size_ok(s->Nx) && fft_size_ok(s->Ny) && g->topo[0] == OCN_PERIODIC &&
+      g->topo[1] == OCN_PERIODIC && s->Nx + 2 * g->PH[0] == (int)m->gd.sy &&
+      !(getenv("OCNHIP_NO_CUSTOM_XY") && atoi(getenv("OCNHIP_NO_CUSTOM_XY")) != 0)) {
+    std::vector<double> one(1, 0.0);
+    s->tw = zsolve_create(m->ctx, one, one);
+    s->cxy_bz = s->tw != nullptr;
+  }
   s->lx = upload(eigenvalues_periodic(s->Nx, g->L[0]));
   s->ly = upload(eigenvalues_periodic(s->Ny, g->L[1]));
   if (g->topo[2] == OCN_PERIODIC) s->lz = upload(eigenvalues_periodic(g->dist ? g->Nzg : s->Nz, g->L[2]));
@@ -244,7 +255,7 @@ PoissonSolver* poisson_create(ocn_model* m) {
   }
   hipfftSetStream(s->fwd, m->ctx->stream);
   hipfftSetStream(s->inv, m->ctx->stream);
-  if (s->cxy) {
+  if (s->cxy || s->cxy_bz) {
     int nx[1] = {s->Nx}, ie[1] = {s->Nxh}, oe[1] = {s->Nx};
     if (hipfftPlanMany(&s->xinv, 1, nx, ie, 1, s->Nxh, oe, 1, s->Nx, HIPFFT_Z2D, s->Ny * s->Nz) != HIPFFT_SUCCESS) {
       ocn_set_error(m->ctx, "hipfft x-inverse plan creation failed");
@@ -1155,11 +1166,42 @@ int poisson_run_from_predictor(ocn_model* m, double dt) {
   return OCN_OK;
 }
 
+// Bounded z: rhs (times dz) + x transform fused, custom y transform, batched Thomas sweeps, custom inverse y, library inverse x
+static int poisson_run_from_predictor_bz(ocn_model* m, double dt) {
+  PoissonSolver* s = m->solver;
+  {
+    ProfScope ps(m->ctx, "fft_forward");
+    xfft_rhs_run(m, s->tw, s->spec, dt);
+    yfft_run(m->ctx, s->tw, s->spec, s->Nxh, s->Ny, s->Nz, 0);
+  }
+  {
+    ProfScope ps(m->ctx, "spectral_solve");
+    tridiag_run(m, s, s->Nxh, s->Ny, s->lx, s->ly, 1.0 / ((double)s->Nx * s->Ny), s->spec, 1);
+  }
+  {
+    ProfScope ps(m->ctx, "fft_backward");
+    yfft_run(m->ctx, s->tw, s->spec, s->Nxh, s->Ny, s->Nz, 1);
+#ifndef OCN_HOST_EMU
+    if (dry_hipfftExecZ2D(s->xinv, (hipfftDoubleComplex*)s->spec, s->rhs) != HIPFFT_SUCCESS) {
+      ocn_set_error(m->ctx, "hipfftExecZ2D (x inverse) failed");
+      return OCN_EHIP;
+    }
+#else
+    emu_xinv(s);
+#endif
+  }
+  return OCN_OK;
+}
+
 // solve_for_pressure!(pNHS, solver, dt, U*)  (solve_for_pressure.jl:55-89)
 int poisson_solve(ocn_model* m, double dt) {
   PoissonSolver* s = m->solver;
-  launch_rhs(m, dt, s->rhs, m->g->topo[2] == OCN_BOUNDED ? 1 : 0);
-  int rc = run_solver(m);
+  int rc;
+  if (s->cxy_bz) rc = poisson_run_from_predictor_bz(m, dt);
+  else {
+    launch_rhs(m, dt, s->rhs, m->g->topo[2] == OCN_BOUNDED ? 1 : 0);
+    rc = run_solver(m);
+  }
   if (rc) return rc;
   ProfScope ps(m->ctx, "copy_pressure");
   launch_copy_to_field(m, s->rhs, m->pNHS);

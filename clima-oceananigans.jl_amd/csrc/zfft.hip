@@ -395,6 +395,10 @@ __global__ void __launch_bounds__(256) k_xfft_rhs(GridDev g, const double* __res
         const long rown = ((j + 1 == g.Ny) ? 0 : j + 1) * sy + k * sz;
         const long rowt = (zwrap && k + 1 == g.Nz) ? j * sy : j * sy + (k + 1) * sz;
         const int ie = (i + 1 == g.Nx) ? 0 : i + 1;
+        if (g.zb) {   // Bounded z (Fourier-tridiagonal solver): k_rhs's expression, term for term -- div with / dz^c[k], times rdt, times dz^c[k]
+          const double dzc = g_dzc(g, k);
+          d = ((us[row + ie] - us[row + i]) * g.rdx + (vs[rown + i] - vs[row + i]) * g.rdy + (ws[rowt + i] - ws[row + i]) / dzc) * rdt * dzc;
+        } else
         d = ((us[row + ie] - us[row + i]) * g.rdx + (vs[rown + i] - vs[row + i]) * g.rdy + (ws[rowt + i] - ws[row + i]) * rdz) * rdt;
       }
       sm[l2 * LP + i] = d;
@@ -413,7 +417,10 @@ __global__ void __launch_bounds__(256) k_xfft_rhs(GridDev g, const double* __res
       const int i = pos_in<N>(r, c, n1);
       const int ie = (i + 1 == g.Nx) ? 0 : i + 1;
       double d = 0.0;
-      if (ok) d = ((us[row + ie] - us[row + i]) * g.rdx + (vs[rown + i] - vs[row + i]) * g.rdy + (ws[rowt + i] - ws[row + i]) * rdz) * rdt;
+      if (ok && g.zb) {
+        const double dzc = g_dzc(g, k);
+        d = ((us[row + ie] - us[row + i]) * g.rdx + (vs[rown + i] - vs[row + i]) * g.rdy + (ws[rowt + i] - ws[row + i]) / dzc) * rdt * dzc;
+      } else if (ok) d = ((us[row + ie] - us[row + i]) * g.rdx + (vs[rown + i] - vs[row + i]) * g.rdy + (ws[rowt + i] - ws[row + i]) * rdz) * rdt;
       v[n1] = {d, 0.0};
     }
   }
@@ -497,10 +504,11 @@ void xfft_rhs_run(ocn_model* m, void* p, void* spec, double dt) {
   const long nlines = (long)g.Ny * g.Nz;
   const int C = 256 / (g.Nx / 16);
   dim3 b(256, 1, 1), gr((unsigned)((nlines + C - 1) / C), 1, 1);
-  const double* us = m->us.interior();
-  const double* vs = m->vs.interior();
-  const double* ws = m->ws.interior();
-  const int zw = m->g->dist ? 0 : 1;
+  // the predictor: us / vs / ws on the all-in-one path and between update and projection of the tiled Bounded-z path, else u, v, w
+  const double* us = (m->fast_path ? m->us : pred_u(m)).interior();
+  const double* vs = (m->fast_path ? m->vs : pred_v(m)).interior();
+  const double* ws = (m->fast_path ? m->ws : pred_w(m)).interior();
+  const int zw = (m->g->dist || m->g->topo[2] != OCN_PERIODIC) ? 0 : 1;
   hipStream_t s = m->ctx->stream;
   cd* sp = (cd*)spec;
   const cd* tw = (const cd*)z->tw;

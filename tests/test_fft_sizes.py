@@ -43,3 +43,47 @@ GPU_SHAPES = [(128, 128, 128), (128, 256, 12), (256, 128, 512), (512, 512, 8), (
 @pytest.mark.parametrize("N", GPU_SHAPES, ids=lambda n: "x".join(map(str, n)))
 def test_transform_sizes_gpu(ocn, N):
     _steps_match_oracle(ocn, N)
+
+
+# ---- the same passes around the batched Thomas sweeps of the Fourier-tridiagonal solver (Bounded z; round 3) ------------------
+def _bounded_steps_match_oracle(ocn, N, stretched, steps=2, tol=2e-11, stepper="RungeKutta3"):
+    """(Periodic, Periodic, Bounded) with 128- / 256- / 512-point x and y: the right-hand side (times dz) is formed inside the x
+    pass from the predictor, custom y passes, tridiagonal sweeps, custom inverse y, library inverse x -- whole RK3 steps with a
+    buoyant tracer against the oracle (the BASELINE config 3 solver at its own row width)."""
+    rng = np.random.default_rng(6)
+    Nz = N[2]
+    kw = dict(size=N, topology=(P, P, "Bounded"))
+    if stretched:
+        zf = -np.cumsum(np.concatenate([[0.0], np.linspace(1.0, 2.0, Nz)]))[::-1] / Nz
+        kw.update(x=(0, 4.0), y=(0, 4.0), z=zf)
+    else:
+        kw.update(extent=(4.0, 4.0, 1.0))
+    mk = lambda mod: mod.NonhydrostaticModel(mod.RectilinearGrid(**kw), advection=mod.WENO5(), timestepper=stepper,   # noqa: E731
+                                             tracers=("b",), buoyancy=mod.BuoyancyTracer(), closure=mod.ScalarDiffusivity(nu=1e-3, kappa=1e-3))
+    m, om = mk(ocn), mk(O)
+    init = {n: 0.1 * (rng.random(getattr(om, n).interior().shape) - 0.5) for n in "uvw"}
+    init["w"][:, :, 0] = 0
+    init["w"][:, :, -1] = 0
+    init["b"] = rng.random(N)
+    ocn.set_model(m, **init)
+    O.set_model(om, **init)
+    for _ in range(steps):
+        ocn.time_step(m, 2e-3)
+        O.time_step(om, 2e-3)
+    for a, b in ((m.u, om.u), (m.v, om.v), (m.w, om.w), (m.pNHS, om.pNHS), (m.tracers["b"], om.tracers["b"])):
+        assert np.abs(a.parent() - b.data).max() <= tol * np.abs(b.data).max()
+    assert m.max_abs_divergence() <= 1e-9
+
+
+def test_bounded_z_custom_passes_hostemu(ocn, backend):
+    """one AB2 step on a stretched grid (the emulation runs one OS thread per lane: `-m gpu` covers RK3, regular z and the sizes)"""
+    if backend != "hostemu":
+        pytest.skip("host-emulation run")
+    _bounded_steps_match_oracle(ocn, (128, 128, 6), True, steps=1, stepper="QuasiAdamsBashforth2")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,stretched", [((128, 128, 16), True), ((256, 256, 12), True), ((256, 128, 10), False), ((512, 256, 8), True)],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_bounded_z_custom_passes_gpu(ocn, N, stretched):
+    _bounded_steps_match_oracle(ocn, N, stretched)

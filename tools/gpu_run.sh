@@ -16,7 +16,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd "$R"
 LIMIT=${STEP_LIMIT:-500}
-finish() { rc=$1; name=$2; echo "[$name] rc=$rc"; if [ "$rc" = 124 ] || [ "$rc" = 137 ]; then echo "[$name] hit its time limit: stopping"; exit 1; fi; }
+finish() { local frc=$1 fname=$2; echo "[$fname] rc=$frc"; if [ "$frc" = 124 ] || [ "$frc" = 137 ]; then echo "[$fname] hit its time limit: stopping"; exit 1; fi; }
 summ() { python - "$1" <<'PY'
 import json, sys
 try:
