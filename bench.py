@@ -27,7 +27,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_FILE = "r02_traffic.json"
+TRAFFIC_FILE = "r03_traffic.json"
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 # algorithmic bytes per cell: whole AB2 step and per phase
 B_ALG_STEP = 336.0          # config 2 / 4: AB2, no tracers; +49 per passive tracer; RK3 = 3 stages

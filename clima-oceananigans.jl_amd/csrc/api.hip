@@ -767,8 +767,11 @@ static bool graph_eligible(const ocn_model* m) {
   (void)m;
   return false;
 #else
-  return m->knob_graph && !m->graph_off && !m->fast_path && !m->ctx->profiling && m->ctx->nranks == 1 && !m->g->dist &&
-         !m->g->dist_y;
+  // the all-in-one periodic path is seven long launches at 256^3 (nothing to gain), but below ~96^3 its step is launch bound
+  // too (64^3: 0.16 of the step roofline in round 2): small boxes replay from a graph like the general path
+  const bool small_box = (long)m->gd.Nx * m->gd.Ny * m->gd.Nz <= 96L * 96L * 96L;
+  return m->knob_graph && !m->graph_off && (!m->fast_path || small_box) && !m->ctx->profiling && m->ctx->nranks == 1 &&
+         !m->g->dist && !m->g->dist_y;
 #endif
 }
 

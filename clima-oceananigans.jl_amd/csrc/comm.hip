@@ -342,6 +342,7 @@ int ocn_comm_init(ocn_ctx* ctx, int rank, int nranks, const void* id128) {
 bool comm_can_overlap(const ocn_ctx* c) { (void)c; return true; }
 
 int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs, hipStream_t st_in) {
+  if (g_ocn_dry) return OCN_OK;   // a step replayed from its hipGraph (one rank: self copies recorded in the graph)
   hipStream_t st = st_in ? st_in : c->stream;
 #ifndef OCN_HOST_EMU
   if (c->nranks == 1 && c->comm) {   // one-rank communicator (OCNHIP_RCCL_SELF): self messages through RCCL itself

@@ -165,7 +165,7 @@ void ocn_model_destroy(ocn_model* m);
 /* which kernels serve this model, and if not the fastest ones, why (e.g. "general kernels: parent arrays of 2 GiB or
  * more exceed the tiled kernels' 32-bit byte offsets").  Writes at most n bytes incl. the terminating 0. */
 int ocn_model_path(const ocn_model* m, char* buf, size_t n);
-/* Whole-step hipGraphs: models on the general kernels (not the all-in-one periodic path, not slab-decomposed) replay the
+/* Whole-step hipGraphs: models on the general kernels and all-in-one periodic boxes of up to 96^3 cells (not slab-decomposed) replay the
  * launches of a step from a hipGraph once a (dt, stepper state) pair repeats -- the launch train of a small model is
  * latency-bound (time_step! of the reference issues the same ~50 launches from Julia: TimeSteppers/quasi_adams_bashforth_2.jl:70-104).
  * *replays = steps served by a graph so far; *active = 1 while the model may use graphs.  OCNHIP_NO_GRAPH=1 disables. */

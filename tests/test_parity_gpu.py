@@ -304,7 +304,10 @@ def test_forced_slab_through_rccl_self(ocn, monkeypatch):
 
 # ---- whole-step hipGraphs of the general path (csrc/api.hip step_graphed) ------------------------------------------------
 GRAPH_CASES = ["ppf_weno_rk3", "ppb_amd_config3", "ppb_weno_noslip", "ppp_c4", "regr_thermal_bubble_regular",
-               "ppb_c4_ab2_varying_dt", "bbb_weno_walls", "ppp_weno_amd_coriolis", "bfb_weno_slice"]
+               "ppb_c4_ab2_varying_dt", "bbb_weno_walls", "ppp_weno_amd_coriolis", "bfb_weno_slice",
+               # the all-in-one periodic path (small boxes only; round 3): AB2 with its G^n / G^- pointer rotation, RK3 + tracers,
+               # ScalarDiffusivity, a changing dt
+               "ppp_weno_ab2", "ppp_weno_rk3_2tracers", "ppp_weno_visc_ab2", "ppp_weno_ab2_varying_dt"]
 
 
 @pytest.mark.gpu
