@@ -598,7 +598,9 @@ static int fused_substep(ocn_model* m, double dt_full, double cn, double cm, int
     m->halo2_inflight = false;
   }
   int rc = OCN_OK;
-  if (m->g->dist && (rc = fused_exchange_ws(m))) return rc;        // w* of the level above the slab
+  // w* of the level above the slab, for the divergence at the top level: exchanged as a plane, or -- Green's-function z stage
+  // with the custom passes -- left at zero here and brought in by its owner in spectral space (poisson.hip bplane): no exchange
+  if (m->g->dist && !poisson_local_wstar(m) && (rc = fused_exchange_ws(m))) return rc;
   if (poisson_custom_xy(m)) {
     rc = poisson_run_from_predictor(m, dt_stage);                  // rhs fused into the x transform
   } else {

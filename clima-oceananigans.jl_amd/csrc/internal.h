@@ -199,6 +199,8 @@ void zsolve_destroy(void* z);
 void zsolve_run(ocn_ctx* ctx, void* z, void* spec, int Nz, const double* lz, double norm, long zero_col);
 void yfft_run(ocn_ctx* ctx, void* z, void* spec, int Nxh, int Ny, int Nz, int inverse);
 void xfft_rhs_run(ocn_model* m, void* z, void* spec, double dt);
+void xfft_plane_run(ocn_model* m, void* z, void* spec_plane, const double* zero_plane, const double* w_plane_minus_one_level, double dt);
+bool poisson_local_wstar(const ocn_model* m);   // z-slab runs: the w* term above the slab enters in spectral space, no w* plane exchange
 bool fft_size_ok(int n);   // 128, 256, 512: sizes of the custom transform passes
 bool poisson_custom_xy(const ocn_model* m);
 int poisson_run_from_predictor(ocn_model* m, double dt);   // fused rhs + custom x/y passes (fast path)
@@ -206,7 +208,7 @@ int poisson_run_from_predictor(ocn_model* m, double dt);   // fused rhs + custom
 // ---- zslab.hip --------------------------------------------------------------------------------------------
 void* zslab_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::vector<double>& ly, int n, int R, int rank);
 void zslab_destroy(void* z);
-int zslab_run(ocn_ctx* ctx, void* z, void* spec, double dz2, double scale);
+int zslab_run(ocn_ctx* ctx, void* z, void* spec, double dz2, double scale, const void* below = nullptr);
 
 // ---- comm.hip ---------------------------------------------------------------------------------------------
 int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs, hipStream_t st = nullptr);   // st: default the context's stream

@@ -631,6 +631,54 @@ __global__ void k_hydrostatic(GridDev g, Phys ph, const double* __restrict__ b0,
   }
 }
 
+// The same downward recurrence cut into SEG segments per column: one thread per (column, segment) sums its levels from the
+// segment's top with a zero carry, the segment totals meet in LDS, and every thread adds the sum of the segments above its own
+// before it stores.  The serial kernel keeps one wave per SIMD busy for 128 dependent steps (2.4 TB/s at 256 x 256 x 128); this
+// one has SEG times the waves and 1 / SEG of the chain.  The association differs from the reference's top-to-bottom sum by the
+// one addition of the carry (a few ulp of pHY'): used for columns of 64 levels or more, the serial kernel below that.
+template <int SEG, int LPS>
+__global__ void __launch_bounds__(64 * SEG) k_hydrostatic_seg(GridDev g, Phys ph, const double* __restrict__ b0, const double* __restrict__ T,
+                                                               const double* __restrict__ S, double* __restrict__ pH) {
+  OCN_SHARED double tot[SEG][64];
+  const int tx = threadIdx.x, s = threadIdx.y;                 // s = 0: the top segment
+  const int col = blockIdx.x * 64 + tx;                        // flattened (i, j): i fastest
+  const int ncol = g.Nx * g.Ny;
+  const bool ok = col < ncol;
+  const int j = ok ? col / g.Nx : 0, i = ok ? col - j * g.Nx : 0;
+  const long c = i + (long)j * g.sy, sz = g.sz;
+  auto bz = [&](long p) -> double {
+    if (ph.buoyancy == OCN_BUOYANCY_TRACER) return b0[p];
+    if (ph.buoyancy == OCN_BUOYANCY_LINEAR_TS) return ph.g * (ph.alpha * T[p] - ph.beta * S[p]);
+    return 0.0;
+  };
+  const int Nz = g.Nz;
+  const int ktop = Nz - 1 - s * LPS;                           // this segment: levels ktop, ktop - 1, ..., ktop - LPS + 1 (>= 0)
+  double bk[LPS + 1], loc[LPS];
+#pragma unroll
+  for (int q = 0; q <= LPS; ++q) {
+    const int k = ktop + 1 - q;                                // the level above the segment first
+    bk[q] = (ok && k >= 0 && k <= Nz) ? bz(c + (long)k * sz) : 0.0;
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int q = 0; q < LPS; ++q) {
+    const int k = ktop - q;
+    double term = 0.0;
+    if (k >= 0) term = 0.5 * (bk[q + 1] + bk[q]) * g_dzf(g, k + 1);
+    acc = (q == 0) ? -term : acc - term;
+    loc[q] = acc;
+  }
+  tot[s][tx] = acc;
+  __syncthreads();
+  double carry = 0.0;
+  for (int r = 0; r < s; ++r) carry = (r == 0) ? tot[0][tx] : carry + tot[r][tx];
+#pragma unroll
+  for (int q = 0; q < LPS; ++q) {
+    const int k = ktop - q;
+    if (ok && k >= 0) pH[c + (long)k * sz] = s == 0 ? loc[q] : carry + loc[q];
+  }
+}
+
 void launch_hydrostatic(ocn_model* m) {
   if (!m->pHY.present || m->d.buoyancy == OCN_BUOYANCY_NONE) return;  // pHY' stays identically zero
   ProfScope ps(m->ctx, "hydrostatic");
@@ -644,6 +692,14 @@ void launch_hydrostatic(ocn_model* m) {
   const double* b0 = m->d.b_index >= 0 ? m->tr[m->d.b_index].interior() : nullptr;
   const double* T = m->d.T_index >= 0 ? m->tr[m->d.T_index].interior() : nullptr;
   const double* S = m->d.S_index >= 0 ? m->tr[m->d.S_index].interior() : nullptr;
+  if (g.Nz >= 64 && g.Nz <= 8 * 32) {   // segmented form: 8 segments of 8 / 16 / 32 levels
+    const int ncol = g.Nx * g.Ny;
+    dim3 bs(64, 8, 1), gs((ncol + 63) / 64, 1, 1);
+    if (g.Nz <= 64) ocn_launch_sync(k_hydrostatic_seg<8, 8>, gs, bs, m->ctx->stream, g, ph, b0, T, S, m->pHY.interior());
+    else if (g.Nz <= 128) ocn_launch_sync(k_hydrostatic_seg<8, 16>, gs, bs, m->ctx->stream, g, ph, b0, T, S, m->pHY.interior());
+    else ocn_launch_sync(k_hydrostatic_seg<8, 32>, gs, bs, m->ctx->stream, g, ph, b0, T, S, m->pHY.interior());
+    return;
+  }
   dim3 b(64, 4, 1), gr((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
   ocn_launch(k_hydrostatic, gr, b, m->ctx->stream, g, ph, b0, T, S, m->pHY.interior());
 }

@@ -43,6 +43,10 @@ struct PoissonSolver {
   double dz2 = 0;
   bool cxy = false;                        // custom x / y passes (zfft.hip): rhs fused into the x transform
   bool cxy_bz = false;                     // Bounded z: the same passes around the tridiagonal sweeps (poisson_run_from_predictor_bz)
+  // z-slabs, Green's-function z stage, custom x / y passes: the w* plane of this rank's first level is transformed here and
+  // enters the convolution as a source one level below the slab (zslab.hip `bel`) -- the lower neighbour never needs the plane
+  double* zero_plane = nullptr;            // (sy x Ny) zeros: the "u" and "v" of the one-plane right-hand side
+  double2_* bplane = nullptr;              // (Nxh x Ny) spectrum of w*[level 0] / (dz dt)
   void* tw = nullptr;                      // twiddle holder for the custom passes
   double* rhs = nullptr;      // real (Nx,Ny,Nz)
   double2_* spec = nullptr;   // complex (Nxh,Ny,Nz)
@@ -204,6 +208,15 @@ PoissonSolver* poisson_create(ocn_model* m) {
     std::vector<double> one(1, 0.0);
     s->tw = zsolve_create(m->ctx, one, one);
     s->cxy = s->tw != nullptr && (s->zs || s->zsl);
+    if (s->cxy && g->dist && s->zsl && !(getenv("OCNHIP_WSTAR_EXCHANGE") && atoi(getenv("OCNHIP_WSTAR_EXCHANGE")) != 0)) {
+      const size_t nz0 = (size_t)m->gd.sy * (s->Ny + 1);
+      if (hipMalloc((void**)&s->zero_plane, nz0 * sizeof(double)) != hipSuccess ||
+          hipMalloc((void**)&s->bplane, (size_t)s->Nxh * s->Ny * sizeof(double2_)) != hipSuccess) {
+        poisson_destroy(s);
+        return nullptr;
+      }
+      hipMemset(s->zero_plane, 0, nz0 * sizeof(double));
+    }
   }
   // Bounded z (Fourier-tridiagonal solver) with 128-, 256- or 512-point periodic x and y: the same fused right-hand side + x
   // pass and custom y passes in front of and behind the batched Thomas sweeps (round 3: config 3 spent 0.22 ms per stage in
@@ -277,6 +290,8 @@ void poisson_destroy(PoissonSolver* s) {
   if (s->xinv) hipfftDestroy(s->xinv);
 #endif
   zsolve_destroy(s->tw);
+  hipFree(s->zero_plane);
+  hipFree(s->bplane);
   hipFree(s->ta);
   hipFree(s->tb);
   hipFree(s->ga);
@@ -1111,6 +1126,7 @@ static int run_solver(ocn_model* m) {
 int poisson_run(ocn_model* m) { return run_solver(m); }
 
 bool poisson_custom_xy(const ocn_model* m) { return m->solver && m->solver->cxy; }
+bool poisson_local_wstar(const ocn_model* m) { return m->solver && m->solver->bplane != nullptr; }
 
 #ifdef OCN_HOST_EMU
 // x-inverse of the half spectrum, line by line (emulation of the batched 1-D Z2D plan)
@@ -1148,7 +1164,12 @@ int poisson_run_from_predictor(ocn_model* m, double dt) {
     ProfScope ps(m->ctx, "spectral_solve");
     zsolve_run(m->ctx, s->zs, s->spec, s->Nz, s->lz, 1.0 / ((double)s->Nx * s->Ny * s->Nz), 0);
   } else {
-    int rc = zslab_run(m->ctx, s->zsl, s->spec, s->dz2, 1.0 / ((double)s->Nx * s->Ny));
+    if (s->bplane) {   // the plane above the slab was left at zero in the right-hand side: its term comes from the rank that owns it
+      ProfScope ps(m->ctx, "fft_forward");
+      xfft_plane_run(m, s->tw, s->bplane, s->zero_plane, m->ws.interior() - m->ws.sz, dt);
+      yfft_run(m->ctx, s->tw, s->bplane, s->Nxh, s->Ny, 1, 0);
+    }
+    int rc = zslab_run(m->ctx, s->zsl, s->spec, s->dz2, 1.0 / ((double)s->Nx * s->Ny), s->bplane);
     if (rc) return rc;
   }
   {

@@ -498,6 +498,25 @@ void yfft_run(ocn_ctx* ctx, void* p, void* spec, int Nxh, int Ny, int Nz, int in
   }
 }
 
+// One plane: spec_plane = x transform of  w_plane / (dz dt)  -- the term the divergence of the level BELOW w_plane's level
+// lacks when that level belongs to another slab (zslab.hip `bel`).  The same kernel with a one-level grid: u and v read a zero
+// plane, "w one level up" is w_plane and "w at the level" the plane under it, which the caller keeps at zero.
+void xfft_plane_run(ocn_model* m, void* p, void* spec_plane, const double* zero_plane, const double* w_plane_minus_one_level, double dt) {
+  ZSolve* z = (ZSolve*)p;
+  GridDev g = m->gd;
+  g.Nz = 1;
+  g.zb = 0;
+  const int C = 256 / (g.Nx / 16);
+  dim3 b(256, 1, 1), gr((unsigned)((g.Ny + C - 1) / C), 1, 1);
+  hipStream_t s = m->ctx->stream;
+  cd* sp = (cd*)spec_plane;
+  const cd* tw = (const cd*)z->tw;
+  const double *us = zero_plane, *ws = w_plane_minus_one_level;
+  FFT_BY_N(g.Nx, ocn_launch_sync(k_xfft_rhs<128, true>, gr, b, s, g, us, us, ws, 1.0 / dt, 0, sp, tw),
+           ocn_launch_sync(k_xfft_rhs<256, true>, gr, b, s, g, us, us, ws, 1.0 / dt, 0, sp, tw),
+           ocn_launch_sync(k_xfft_rhs<512, true>, gr, b, s, g, us, us, ws, 1.0 / dt, 0, sp, tw))
+}
+
 void xfft_rhs_run(ocn_model* m, void* p, void* spec, double dt) {
   ZSolve* z = (ZSolve*)p;
   const GridDev& g = m->gd;

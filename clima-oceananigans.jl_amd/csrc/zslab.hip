@@ -72,14 +72,21 @@ __global__ void k_zslab_up(zc* __restrict__ a, long ncol, int m, int SZ, const d
 }
 
 // rank sums from the segment sums: SP_r = sum_s rho^((SZ-1-s) m) SP_s,  SQ_r = sum_s rho^(s m) SQ_s
+//
+// `bel` (may be null): a source this rank holds for the level just BELOW its slab -- local index -1, i.e. the top level of the
+// lower neighbour (round 3: the w* term of that level's divergence, transformed here instead of shipping the w* plane down
+// before the right-hand side can be formed).  The convolution with C rho^|d| does not care who owns a source as long as it
+// is counted once at its position: in this rank's message it weighs rho^n in SP (distance to the level above the slab's top)
+// and rho^-1 in SQ; in this rank's own sweep it is the first term of the carry from below (k_zslab_down*).
 __global__ void k_zslab_ranksums(long ncol, int m, int SZ, const double* __restrict__ lxy, double dz2,
-                                 const zc* __restrict__ segs, zc* __restrict__ sums /* [2][ncol] */) {
+                                 const zc* __restrict__ segs, zc* __restrict__ sums /* [2][ncol] */, const zc* __restrict__ bel) {
   const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= ncol) return;
   const double lam = lxy[col] * dz2;
   zc SP = {0, 0}, SQ = {0, 0};
   if (lam != 0.0) {
-    const double rm = exp(log(col_rho(lam)) * m);
+    const double rho1 = col_rho(lam);
+    const double rm = exp(log(rho1) * m);
     double w = 1.0;
     for (int s = 0; s < SZ; ++s) {      // Horner for SP, running power for SQ
       zc sp = segs[((size_t)s * 2 + 0) * ncol + col], sq = segs[((size_t)s * 2 + 1) * ncol + col];
@@ -88,6 +95,14 @@ __global__ void k_zslab_ranksums(long ncol, int m, int SZ, const double* __restr
       SQ.x = fma(w, sq.x, SQ.x);
       SQ.y = fma(w, sq.y, SQ.y);
       w *= rm;
+    }
+    if (bel) {
+      const zc d = bel[col];
+      const double rn = exp(log(rho1) * ((double)m * SZ)), ri = 1.0 / rho1;
+      SP.x = fma(rn, d.x, SP.x);
+      SP.y = fma(rn, d.y, SP.y);
+      SQ.x = fma(ri, d.x, SQ.x);
+      SQ.y = fma(ri, d.y, SQ.y);
     }
   }
   sums[col] = SP;
@@ -99,7 +114,7 @@ __global__ void k_zslab_ranksums(long ncol, int m, int SZ, const double* __restr
 // gathered rank sums [R][2][ncol], every other slab with all periodic images.
 __global__ void k_zslab_down(zc* __restrict__ a, long ncol, int m, int SZ, int R, int rank, const double* __restrict__ lxy,
                              double dz2, double scale, const zc* __restrict__ segs, const zc* __restrict__ gathered,
-                             size_t msg) {
+                             size_t msg, const zc* __restrict__ bel) {
   const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
   if (col >= ncol) return;
@@ -125,6 +140,7 @@ __global__ void k_zslab_down(zc* __restrict__ a, long ncol, int m, int SZ, int R
     w *= rn;
   }
   cP.x *= geo; cP.y *= geo; cQ.x *= geo; cQ.y *= geo;
+  if (bel) { cP.x += bel[col].x; cP.y += bel[col].y; }   // this rank's source at index -1 (its periodic images came with the own-rank term)
   // segment-level: add the rank's own segments below / above this one
   {
     zc lo = {cP.x, cP.y};                         // carry entering segment 0 from below
@@ -184,7 +200,7 @@ __global__ void k_zslab_down(zc* __restrict__ a, long ncol, int m, int SZ, int R
 template <int MR>
 __global__ void k_zslab_down_reg(zc* __restrict__ a, long ncol, int m, int SZ, int R, int rank, const double* __restrict__ lxy,
                                  double dz2, double scale, const zc* __restrict__ segs, const zc* __restrict__ gathered,
-                                 size_t msg) {
+                                 size_t msg, const zc* __restrict__ bel) {
   const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
   if (col >= ncol) return;
@@ -214,6 +230,7 @@ __global__ void k_zslab_down_reg(zc* __restrict__ a, long ncol, int m, int SZ, i
     w *= rn;
   }
   cP.x *= geo; cP.y *= geo; cQ.x *= geo; cQ.y *= geo;
+  if (bel) { cP.x += bel[col].x; cP.y += bel[col].y; }
   for (int t = 0; t < s; ++t) {
     zc sp = segs[((size_t)t * 2 + 0) * ncol + col];
     cP.x = fma(rm, cP.x, sp.x);
@@ -282,7 +299,15 @@ __global__ void __launch_bounds__(ZM_T) k_zslab_mean(zc* __restrict__ a, long nc
   const int N = n * R;
   const int chunk = (N + ZM_T - 1) / ZM_T;
   const int k0 = t * chunk, k1 = (k0 + chunk < N) ? k0 + chunk : N;
-  auto F = [&](int k) { return gathered[(size_t)(k / n) * msg + 2 * (size_t)ncol + (k % n)]; };
+  auto F = [&](int k) {
+    const int q = k / n, i = k - q * n;
+    zc f = gathered[(size_t)q * msg + 2 * (size_t)ncol + i];
+    if (i == n - 1) {   // the source rank q + 1 holds for the level below its slab = this level
+      const zc d = gathered[(size_t)((q + 1) % R) * msg + 2 * (size_t)ncol + n];
+      f = {f.x + d.x, f.y + d.y};
+    }
+    return f;
+  };
   // mean of f
   zc part = {0, 0}, tot;
   for (int k = k0; k < k1; ++k) part = zadd(part, F(k));
@@ -325,9 +350,10 @@ __global__ void __launch_bounds__(ZM_T) k_zslab_mean(zc* __restrict__ a, long nc
 }
 
 // copy column col0 of this rank's slab to a contiguous buffer (before pass 1 overwrites it)
-__global__ void k_zslab_getcol(const zc* __restrict__ a, long ncol, long col0, int n, zc* __restrict__ out) {
+__global__ void k_zslab_getcol(const zc* __restrict__ a, long ncol, long col0, int n, zc* __restrict__ out, const zc* __restrict__ bel) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[col0 + ncol * (size_t)i];
+  else if (i == n) out[n] = bel ? bel[col0] : zc{0, 0};   // entry n of the column message: the source below the slab
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
@@ -335,7 +361,7 @@ struct ZSlab {
   long ncol = 0;
   int n = 0, R = 1, rank = 0;
   double* lxy = nullptr;
-  zc* send = nullptr;      // [2][ncol] sums + [n] singular column
+  zc* send = nullptr;      // [2][ncol] sums + [n] singular column + [1] its source below the slab
   zc* gathered = nullptr;  // [R] x that
   zc* gsums = nullptr;     // [R][2][ncol] (compact view used by pass 2)
   zc* fcol = nullptr;      // [R][n]
@@ -357,7 +383,7 @@ void* zslab_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::
   for (int cand : {64, 32, 16, 8, 4, 2})      // segments of 8 levels when possible (register kernel), never shorter
     if (n % cand == 0 && n / cand >= 8) { z->SZ = cand; break; }
   z->m = n / z->SZ;
-  z->msg = 2 * (size_t)z->ncol + (size_t)n;
+  z->msg = 2 * (size_t)z->ncol + (size_t)n + 1;   // two sums per column, the singular column's levels, its source below the slab
   bool ok = hipMalloc((void**)&z->lxy, sizeof(double) * lxy.size()) == hipSuccess &&
             hipMalloc((void**)&z->send, sizeof(zc) * z->msg) == hipSuccess &&
             hipMalloc((void**)&z->gathered, sizeof(zc) * z->msg * R) == hipSuccess &&
@@ -382,7 +408,7 @@ void zslab_destroy(void* p) {
 }
 
 // in place on this rank's (ncol, n) half spectrum.  dz2 = dz^2, scale = FFT normalisation 1/(Nx Ny).
-int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale) {
+int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale, const void* below) {
   ZSlab* z = (ZSlab*)p;
   hipStream_t st = ctx->stream;
   zc* a = (zc*)spec;
@@ -390,9 +416,10 @@ int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale) {
   dim3 b(TB, 1, 1), g((unsigned)((z->ncol + TB - 1) / TB), (unsigned)z->SZ, 1), g1((unsigned)((z->ncol + TB - 1) / TB), 1, 1);
   {
     ProfScope ps(ctx, "spectral_solve");
-    ocn_launch(k_zslab_getcol, dim3((z->n + 63) / 64), dim3(64), st, (const zc*)a, z->ncol, 0L, z->n, z->send + 2 * z->ncol);
+    const zc* bel = (const zc*)below;
+    ocn_launch(k_zslab_getcol, dim3((z->n + 1 + 63) / 64), dim3(64), st, (const zc*)a, z->ncol, 0L, z->n, z->send + 2 * z->ncol, bel);
     ocn_launch(k_zslab_up, g, b, st, a, z->ncol, z->m, z->SZ, (const double*)z->lxy, dz2, z->segs, z->m > ZS_MR ? 1 : 0);
-    ocn_launch(k_zslab_ranksums, g1, b, st, z->ncol, z->m, z->SZ, (const double*)z->lxy, dz2, (const zc*)z->segs, z->send);
+    ocn_launch(k_zslab_ranksums, g1, b, st, z->ncol, z->m, z->SZ, (const double*)z->lxy, dz2, (const zc*)z->segs, z->send, bel);
   }
   // all-gather (the same message to every peer)
   {
@@ -410,10 +437,10 @@ int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale) {
     ProfScope ps(ctx, "spectral_solve");
     if (z->m > ZS_MR)
       ocn_launch(k_zslab_down, g, b, st, a, z->ncol, z->m, z->SZ, z->R, z->rank, (const double*)z->lxy, dz2, scale * dz2,
-                 (const zc*)z->segs, (const zc*)z->gathered, z->msg);
+                 (const zc*)z->segs, (const zc*)z->gathered, z->msg, (const zc*)below);
     else
       ocn_launch(k_zslab_down_reg<ZS_MR>, g, b, st, a, z->ncol, z->m, z->SZ, z->R, z->rank, (const double*)z->lxy, dz2,
-                 scale * dz2, (const zc*)z->segs, (const zc*)z->gathered, z->msg);
+                 scale * dz2, (const zc*)z->segs, (const zc*)z->gathered, z->msg, (const zc*)below);
     ocn_launch_sync(k_zslab_mean, dim3(1), dim3(ZM_T), st, a, z->ncol, 0L, z->n, z->R, z->rank, (const zc*)z->gathered, z->msg,
                     scale * dz2, z->work);
   }

@@ -135,6 +135,12 @@ CASES = {
                                tol=2e-9,
                                bcs={"u": {"top": ("flux", -2e-5)}, "T": {"top": ("flux", 5e-5), "bottom": ("gradient", 0.005)},
                                     "S": {"top": ("flux", 5e-8)}}),
+    # columns of 64 / 96 levels: the segmented hydrostatic-pressure kernel (8 segments per column; kernels.hip k_hydrostatic_seg)
+    "ppb_weno_tall64": dict(size=(8, 6, 64), topo=(P, P, B), xy=((0, 1), (0, 1)), zfaces=list(-np.linspace(1.0, 0.0, 65) ** 1.5),
+                            adv="WENO5", stepper="RK3", steps=1, dt=1e-3, tracers=("T", "S"), closure=(1e-3, 1e-3), coriolis=1e-2,
+                            buoyancy="TS", bcs={"T": {"top": ("flux", 2e-3), "bottom": ("gradient", 0.01)}}),
+    "ppb_c2_tall96_btracer": dict(size=(6, 8, 96), topo=(P, P, B), extent=(1, 1, 2), adv="C2", stepper="AB2", steps=2, dt=2e-3,
+                                  tracers=("b",), buoyancy="b", halo=(1, 1, 1)),
     # two-dimensional turbulence (BASELINE config 1): Flat z
     "ppf_weno_rk3": dict(size=(16, 16), topo=(P, P, F), extent=(2 * np.pi, 2 * np.pi), adv="WENO5", stepper="RK3",
                          steps=2, dt=0.05, closure=(1e-5, 0.0)),

@@ -51,7 +51,8 @@ def run_world(case, backend, world, timeout=900, extra_env=None):
 
 CPU_CASES = [("zslab_ab2", 2, {}), ("zslab_ab2", 2, {"OCNHIP_DIST_SOLVER": "transpose"}), ("zslab_rk3_tracer", 2, {}),
              ("poisson", 2, {}), ("poisson", 2, {"OCNHIP_DIST_SOLVER": "transpose"}), ("yslab_amd", 2, {}),
-             ("yslab_scalar", 3, {})]
+             ("yslab_scalar", 3, {}),
+             ("zslab_custom", 2, {"OCNHIP_OVERLAP": "1"})]     # 128 x 128 x 16 on two processes: the local w* term (three exchanges per step)
 
 
 @pytest.mark.parametrize("case,world,env", CPU_CASES, ids=[f"{c}-{w}-{'-'.join(e.values()) or 'green'}" for c, w, e in CPU_CASES])
@@ -110,12 +111,12 @@ def test_bench_falls_back_to_shm_when_rccl_cannot_start():
 
 
 GPU_CASES = [("zslab_ab2", {"OCNHIP_OVERLAP": "1"}), ("zslab_rk3_tracer", {"OCNHIP_DIST_SOLVER": "transpose", "OCNHIP_OVERLAP": "1"}),
-             ("zslab_wide", {}),
+             ("zslab_wide", {}), ("zslab_custom", {"OCNHIP_OVERLAP": "1"}), ("zslab_custom", {"OCNHIP_WSTAR_EXCHANGE": "1"}),
              ("yslab_amd", {}), ("poisson", {})]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,env", GPU_CASES, ids=[c for c, _ in GPU_CASES])
+@pytest.mark.parametrize("case,env", GPU_CASES, ids=[c + "".join("-" + k[7:].lower() for k in e) for c, e in GPU_CASES])
 def test_library_two_ranks_one_gpu(case, env):
     """two processes, one MI355X, host shared-memory transport: slab kernels, pack / unpack, exchange order and the
     distributed solvers of the product library against the single-domain oracle"""
