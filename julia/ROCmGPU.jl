@@ -207,6 +207,17 @@ kernel_path(model::RM) = (buf = Vector{UInt8}(undef, 256);
 
 # Distributed: MultiArch(ROCmGPU(); ranks=(1, 1, R)) -> ocn_comm_init(ctx, rank, R, id) with the 128-byte id of
 # ocn_comm_unique_id broadcast over MPI (Distributed/multi_architectures.jl:20-47); everything else is unchanged.
+# Before the blocking ocn_comm_init every rank calls ocn_comm_probe(ctx, rank, R, id0, timeout_s) with an id of its own and the
+# ranks MPI.Allreduce(min) the return codes: a rank whose RCCL cannot start then stops everybody instead of hanging them.
+#
+# HydrostaticFreeSurfaceModel, first slice (Models/HydrostaticFreeSurfaceModels/split_explicit_free_surface*.jl):
+#   struct ROCmSplitExplicit; grid::Ptr{Cvoid}; sefs::Ptr{Cvoid}; end                      # ocn_hgrid_create + ocn_sefs_create
+#   FreeSurface(fs::SplitExplicitFreeSurface, velocities, grid) on a ROCmGPU grid -> fields aliased from ocn_sefs_field(sefs, 0:10)
+#   ab2_step_free_surface!(fs, model, Δt, χ, _) = check(ccall((:ocn_sefs_step, libocnhip), Cint,
+#       (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble), fs.sefs, Gⁿ.u, Gⁿ.v, G⁻.u, G⁻.v, Δt, χ))
+#   barotropic_split_explicit_corrector!(u, v, fs, grid) = check(ccall((:ocn_sefs_corrector, libocnhip), Cint,
+#       (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), fs.sefs, hfield(u), hfield(v)))
+#
 # Launch-bound models (config 1) are replayed from hipGraphs inside ocn_time_step; ocn_model_graph_replays(handle, n, active)
 # reports it.  The library reports OCN_ABI_VERSION through ocn_abi_version(): __init__ compares it with 4.
 function __init__()
