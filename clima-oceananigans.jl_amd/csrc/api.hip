@@ -608,7 +608,9 @@ static int fused_substep(ocn_model* m, double dt_full, double cn, double cm, int
     rc = poisson_run(m);
   }
   if (rc) return rc;
-  if (m->g->dist && (rc = fused_exchange_phi(m, poisson_rhs_buffer(m->solver)))) return rc;   // p below the slab
+  // p of the level below the slab, for d_z p at the first level: computed by this rank with one more level of the Green's-function
+  // convolution (poisson.hip pbelow), or received from the lower neighbour
+  if (m->g->dist && !poisson_local_phi_below(m) && (rc = fused_exchange_phi(m, poisson_rhs_buffer(m->solver)))) return rc;
   launch_project(m, dt_stage, poisson_rhs_buffer(m->solver));
   if (m->g->dist) {
     ocn_ctx* c = m->ctx;

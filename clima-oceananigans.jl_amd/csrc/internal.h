@@ -208,7 +208,8 @@ int poisson_run_from_predictor(ocn_model* m, double dt);   // fused rhs + custom
 // ---- zslab.hip --------------------------------------------------------------------------------------------
 void* zslab_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::vector<double>& ly, int n, int R, int rank);
 void zslab_destroy(void* z);
-int zslab_run(ocn_ctx* ctx, void* z, void* spec, double dz2, double scale, const void* below = nullptr);
+int zslab_run(ocn_ctx* ctx, void* z, void* spec, double dz2, double scale, const void* below = nullptr, void* phi_below = nullptr);
+bool poisson_local_phi_below(const ocn_model* m);   // z-slab runs: the pressure plane below the slab is computed by this rank (no exchange)
 
 // ---- comm.hip ---------------------------------------------------------------------------------------------
 int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs, hipStream_t st = nullptr);   // st: default the context's stream

@@ -47,6 +47,7 @@ struct PoissonSolver {
   // enters the convolution as a source one level below the slab (zslab.hip `bel`) -- the lower neighbour never needs the plane
   double* zero_plane = nullptr;            // (sy x Ny) zeros: the "u" and "v" of the one-plane right-hand side
   double2_* bplane = nullptr;              // (Nxh x Ny) spectrum of w*[level 0] / (dz dt)
+  double2_* pbelow = nullptr;              // (Nxh x Ny) spectrum of the solution one level below the slab (zslab.hip k_zslab_below)
   void* tw = nullptr;                      // twiddle holder for the custom passes
   double* rhs = nullptr;      // real (Nx,Ny,Nz)
   double2_* spec = nullptr;   // complex (Nxh,Ny,Nz)
@@ -66,7 +67,7 @@ struct PoissonSolver {
   int yw = 0, Nyg = 0;                      // kx columns per rank (padded), global Ny
   double2_ *ysend = nullptr, *yrecv = nullptr, *yT = nullptr;
 #ifndef OCN_HOST_EMU
-  hipfftHandle fwd = 0, inv = 0, zplan = 0, xinv = 0;
+  hipfftHandle fwd = 0, inv = 0, zplan = 0, xinv = 0, xinv1 = 0;   // xinv1: x inverse of ONE plane (the level below a slab)
   hipfftHandle wxf = 0, wxi = 0, wz = 0;    // kind 4: batched 1-D x (R2C / C2R) and z (C2C) plans
   hipfftHandle yfft = 0;                    // kind 5: contiguous 1-D complex transforms along the global y
 #endif
@@ -216,6 +217,11 @@ PoissonSolver* poisson_create(ocn_model* m) {
         return nullptr;
       }
       hipMemset(s->zero_plane, 0, nz0 * sizeof(double));
+      if (!(getenv("OCNHIP_PHI_EXCHANGE") && atoi(getenv("OCNHIP_PHI_EXCHANGE")) != 0) &&
+          hipMalloc((void**)&s->pbelow, (size_t)s->Nxh * s->Ny * sizeof(double2_)) != hipSuccess) {
+        poisson_destroy(s);
+        return nullptr;
+      }
     }
   }
   // Bounded z (Fourier-tridiagonal solver) with 128-, 256- or 512-point periodic x and y: the same fused right-hand side + x
@@ -276,6 +282,14 @@ PoissonSolver* poisson_create(ocn_model* m) {
       return nullptr;
     }
     hipfftSetStream(s->xinv, m->ctx->stream);
+    if (s->pbelow) {
+      if (hipfftPlanMany(&s->xinv1, 1, nx, ie, 1, s->Nxh, oe, 1, s->Nx, HIPFFT_Z2D, s->Ny) != HIPFFT_SUCCESS) {
+        ocn_set_error(m->ctx, "hipfft x-inverse plan (one plane) creation failed");
+        poisson_destroy(s);
+        return nullptr;
+      }
+      hipfftSetStream(s->xinv1, m->ctx->stream);
+    }
   }
 #endif
   return s;
@@ -288,10 +302,12 @@ void poisson_destroy(PoissonSolver* s) {
   if (s->inv) hipfftDestroy(s->inv);
   if (s->zplan) hipfftDestroy(s->zplan);
   if (s->xinv) hipfftDestroy(s->xinv);
+  if (s->xinv1) hipfftDestroy(s->xinv1);
 #endif
   zsolve_destroy(s->tw);
   hipFree(s->zero_plane);
   hipFree(s->bplane);
+  hipFree(s->pbelow);
   hipFree(s->ta);
   hipFree(s->tb);
   hipFree(s->ga);
@@ -1127,16 +1143,19 @@ int poisson_run(ocn_model* m) { return run_solver(m); }
 
 bool poisson_custom_xy(const ocn_model* m) { return m->solver && m->solver->cxy; }
 bool poisson_local_wstar(const ocn_model* m) { return m->solver && m->solver->bplane != nullptr; }
+bool poisson_local_phi_below(const ocn_model* m) { return m->solver && m->solver->pbelow != nullptr; }
 
 #ifdef OCN_HOST_EMU
 // x-inverse of the half spectrum, line by line (emulation of the batched 1-D Z2D plan)
-static void emu_xinv(PoissonSolver* s) {
+static void emu_xinv(PoissonSolver* s, const double2_* spec = nullptr, double* out = nullptr, size_t nlines = 0) {
   const int Nx = s->Nx, Nxh = s->Nxh;
-  const size_t lines = (size_t)s->Ny * s->Nz;
+  const size_t lines = nlines ? nlines : (size_t)s->Ny * s->Nz;
+  if (!spec) spec = s->spec;
+  if (!out) out = s->rhs;
   std::vector<cplx> full(Nx);
   for (size_t L = 0; L < lines; ++L) {
     for (int i = 0; i < Nx; ++i) {
-      double2_ q = s->spec[(i < Nxh ? i : Nx - i) + Nxh * L];
+      double2_ q = spec[(i < Nxh ? i : Nx - i) + Nxh * L];
       full[i] = cplx(q.x, i < Nxh ? q.y : -q.y);
     }
     for (int n = 0; n < Nx; ++n) {
@@ -1145,7 +1164,7 @@ static void emu_xinv(PoissonSolver* s) {
         double ang = 2.0 * M_PI * ((long)i * n % Nx) / Nx;
         acc += full[i] * cplx(cos(ang), sin(ang));
       }
-      s->rhs[n + Nx * L] = acc.real();
+      out[n + Nx * L] = acc.real();
     }
   }
 }
@@ -1169,7 +1188,7 @@ int poisson_run_from_predictor(ocn_model* m, double dt) {
       xfft_plane_run(m, s->tw, s->bplane, s->zero_plane, m->ws.interior() - m->ws.sz, dt);
       yfft_run(m->ctx, s->tw, s->bplane, s->Nxh, s->Ny, 1, 0);
     }
-    int rc = zslab_run(m->ctx, s->zsl, s->spec, s->dz2, 1.0 / ((double)s->Nx * s->Ny), s->bplane);
+    int rc = zslab_run(m->ctx, s->zsl, s->spec, s->dz2, 1.0 / ((double)s->Nx * s->Ny), s->bplane, s->pbelow);
     if (rc) return rc;
   }
   {
@@ -1183,6 +1202,17 @@ int poisson_run_from_predictor(ocn_model* m, double dt) {
 #else
     emu_xinv(s);
 #endif
+    if (s->pbelow) {   // the plane below the slab: inverse y, inverse x -> the model's (Nx, Ny) buffer k_project reads
+      yfft_run(m->ctx, s->tw, s->pbelow, s->Nxh, s->Ny, 1, 1);
+#ifndef OCN_HOST_EMU
+      if (dry_hipfftExecZ2D(s->xinv1, (hipfftDoubleComplex*)s->pbelow, m->phi_below) != HIPFFT_SUCCESS) {
+        ocn_set_error(m->ctx, "hipfftExecZ2D (x inverse of the plane below the slab) failed");
+        return OCN_EHIP;
+      }
+#else
+      emu_xinv(s, s->pbelow, m->phi_below, (size_t)s->Ny);
+#endif
+    }
   }
   return OCN_OK;
 }

@@ -266,6 +266,50 @@ __global__ void k_zslab_down_reg(zc* __restrict__ a, long ncol, int m, int SZ, i
     }
 }
 
+// The solution ONE LEVEL BELOW the slab (local index -1), for d_z p at the slab's first level: x_{-1} = C (P_{-1} + rho Q_0) with
+// P_{-1} = the carry from below (every slab below with its images, plus this rank's own source at -1) and Q_0 = this slab's
+// own sum SQ plus rho^n times the carry from above -- everything is on this rank once the sums are gathered, so the pressure
+// plane the lower neighbour used to send (fused_exchange_phi) is computed here instead (round 3).
+__global__ void k_zslab_below(long ncol, int m, int SZ, int R, int rank, const double* __restrict__ lxy, double dz2, double scale,
+                              const zc* __restrict__ segs, const zc* __restrict__ gathered, size_t msg, const zc* __restrict__ bel,
+                              zc* __restrict__ out) {
+  const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncol) return;
+  const double lam = lxy[col] * dz2;
+  if (lam == 0.0) return;                            // the singular column: k_zslab_mean
+  const double rho = col_rho(lam);
+  const double lnr = log(rho);
+  const int n = m * SZ;
+  const double rm = exp(lnr * m);
+  const double rn = exp(lnr * n);
+  const double geo = 1.0 / (1.0 - exp(lnr * ((double)n * R)));
+  zc cP = {0, 0}, cQ = {0, 0};
+  double w = 1.0;
+  for (int mm = 1; mm <= R; ++mm) {
+    const int rb = ((rank - mm) % R + R) % R, ra = (rank + mm) % R;
+    zc sp = gathered[(size_t)rb * msg + col];
+    zc sq = gathered[(size_t)ra * msg + ncol + col];
+    cP.x = fma(w, sp.x, cP.x);
+    cP.y = fma(w, sp.y, cP.y);
+    cQ.x = fma(w, sq.x, cQ.x);
+    cQ.y = fma(w, sq.y, cQ.y);
+    w *= rn;
+  }
+  cP.x *= geo; cP.y *= geo; cQ.x *= geo; cQ.y *= geo;
+  if (bel) { cP.x += bel[col].x; cP.y += bel[col].y; }
+  zc SQ = {0, 0};                                    // this slab's own levels: sum_j rho^j f_j from the segment sums
+  double ws = 1.0;
+  for (int t = 0; t < SZ; ++t) {
+    zc sq = segs[((size_t)t * 2 + 1) * ncol + col];
+    SQ.x = fma(ws, sq.x, SQ.x);
+    SQ.y = fma(ws, sq.y, SQ.y);
+    ws *= rm;
+  }
+  const double C = rho / (rho * rho - 1.0) * scale;
+  const zc Q0 = {fma(rn, cQ.x, SQ.x), fma(rn, cQ.y, SQ.y)};
+  out[col] = {C * fma(rho, Q0.x, cP.x), C * fma(rho, Q0.y, cP.y)};
+}
+
 // the singular column (lx + ly = 0): second difference of x equals g = f - mean(f), zero-mean solution:
 //   x_k - x_0 = k d_{-1} + sum_{j<k} c_j,  c = inclusive prefix sum of g,  d_{-1} = -mean(c),  x_0 from zero mean.
 // One workgroup; every thread owns a contiguous chunk; the two prefix sums are chunk-local scans plus a
@@ -293,7 +337,7 @@ OCN_DEVFN zc block_scan_excl(zc v, zc* sh /* [2][ZM_T] */, zc* total) {
 
 __global__ void __launch_bounds__(ZM_T) k_zslab_mean(zc* __restrict__ a, long ncol, long col0, int n, int R, int rank,
                                                      const zc* __restrict__ gathered, size_t msg, double scale,
-                                                     zc* __restrict__ work /* [R*n] */) {
+                                                     zc* __restrict__ work /* [R*n] */, zc* __restrict__ below /* may be null */) {
   OCN_SHARED zc sh[2 * ZM_T];
   const int t = threadIdx.x;
   const int N = n * R;
@@ -346,6 +390,10 @@ __global__ void __launch_bounds__(ZM_T) k_zslab_mean(zc* __restrict__ a, long nc
   for (int i = t; i < n; i += ZM_T) {
     zc v = work[rank * n + i];
     a[col0 + ncol * (size_t)i] = {(v.x + x0.x) * scale, (v.y + x0.y) * scale};
+  }
+  if (below && t == 0) {                              // the level below this rank's slab: the whole column is here
+    zc v = work[((rank * n - 1) % N + N) % N];
+    below[col0] = {(v.x + x0.x) * scale, (v.y + x0.y) * scale};
   }
 }
 
@@ -408,7 +456,7 @@ void zslab_destroy(void* p) {
 }
 
 // in place on this rank's (ncol, n) half spectrum.  dz2 = dz^2, scale = FFT normalisation 1/(Nx Ny).
-int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale, const void* below) {
+int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale, const void* below, void* phi_below) {
   ZSlab* z = (ZSlab*)p;
   hipStream_t st = ctx->stream;
   zc* a = (zc*)spec;
@@ -441,8 +489,11 @@ int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale, const
     else
       ocn_launch(k_zslab_down_reg<ZS_MR>, g, b, st, a, z->ncol, z->m, z->SZ, z->R, z->rank, (const double*)z->lxy, dz2,
                  scale * dz2, (const zc*)z->segs, (const zc*)z->gathered, z->msg, (const zc*)below);
+    if (phi_below)   // before the down sweep overwrites nothing it needs: segs and gathered are read-only from here on
+      ocn_launch(k_zslab_below, g1, b, st, z->ncol, z->m, z->SZ, z->R, z->rank, (const double*)z->lxy, dz2, scale * dz2,
+                 (const zc*)z->segs, (const zc*)z->gathered, z->msg, (const zc*)below, (zc*)phi_below);
     ocn_launch_sync(k_zslab_mean, dim3(1), dim3(ZM_T), st, a, z->ncol, 0L, z->n, z->R, z->rank, (const zc*)z->gathered, z->msg,
-                    scale * dz2, z->work);
+                    scale * dz2, z->work, (zc*)phi_below);
   }
   return OCN_OK;
 }

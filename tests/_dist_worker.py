@@ -135,8 +135,8 @@ def main():
     elif case == "zslab_wide":      # rows wider than a workgroup: the x-tiled kernel on slabs (config-4 shape in miniature)
         zslab_case(ocn, O, ctx, rank, world, "AB2", (), (272, 8, 8 * world), steps=1)
     elif case == "zslab_custom":    # 128- / 256-point rows: the custom transform passes on slabs; the w* term above each slab enters
-        # in spectral space through its owner's Green's-function sums -- three exchanges per step (OCNHIP_WSTAR_EXCHANGE=1: the
-        # w* plane is shipped instead, four exchanges)
+        # in spectral space through its owner's Green's-function sums and the pressure plane below each slab is one more level of
+        # its own convolution -- two exchanges per step (OCNHIP_WSTAR_EXCHANGE=1 / OCNHIP_PHI_EXCHANGE=1: the planes are shipped)
         if big:
             zslab_case(ocn, O, ctx, rank, world, "RK3", ("c",), (256, 128, 16 * world), steps=2)
         else:

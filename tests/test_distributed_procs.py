@@ -112,6 +112,7 @@ def test_bench_falls_back_to_shm_when_rccl_cannot_start():
 
 GPU_CASES = [("zslab_ab2", {"OCNHIP_OVERLAP": "1"}), ("zslab_rk3_tracer", {"OCNHIP_DIST_SOLVER": "transpose", "OCNHIP_OVERLAP": "1"}),
              ("zslab_wide", {}), ("zslab_custom", {"OCNHIP_OVERLAP": "1"}), ("zslab_custom", {"OCNHIP_WSTAR_EXCHANGE": "1"}),
+             ("zslab_custom", {"OCNHIP_PHI_EXCHANGE": "1"}),
              ("yslab_amd", {}), ("poisson", {})]
 
 
