@@ -1268,7 +1268,7 @@ void launch_project(ocn_model* m, double dt, const double* phi) {
   a.u = m->u.interior(); a.v = m->v.interior(); a.w = m->w.interior(); a.p = m->pNHS.interior();
   a.dt = dt;
   a.zwrap = m->g->dist ? 0 : 1;
-  a.phi_below = m->phi_below;
+  a.phi_below = poisson_local_phi_below(m) ? poisson_phi_below(m) : m->phi_below;
   dim3 b(256, 1, 1), gr((g.Nx + b.x - 1) / b.x, (g.Ny + b.y - 1) / b.y, g.Nz);
   ocn_launch(k_project, gr, b, m->ctx->stream, g, a);
 }

@@ -198,8 +198,7 @@ void* zsolve_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std:
 void zsolve_destroy(void* z);
 void zsolve_run(ocn_ctx* ctx, void* z, void* spec, int Nz, const double* lz, double norm, long zero_col);
 void yfft_run(ocn_ctx* ctx, void* z, void* spec, int Nxh, int Ny, int Nz, int inverse);
-void xfft_rhs_run(ocn_model* m, void* z, void* spec, double dt);
-void xfft_plane_run(ocn_model* m, void* z, void* spec_plane, const double* zero_plane, const double* w_plane_minus_one_level, double dt);
+void xfft_rhs_run(ocn_model* m, void* z, void* spec, double dt, int extra_plane = 0);
 bool poisson_local_wstar(const ocn_model* m);   // z-slab runs: the w* term above the slab enters in spectral space, no w* plane exchange
 bool fft_size_ok(int n);   // 128, 256, 512: sizes of the custom transform passes
 bool poisson_custom_xy(const ocn_model* m);
@@ -209,7 +208,8 @@ int poisson_run_from_predictor(ocn_model* m, double dt);   // fused rhs + custom
 void* zslab_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::vector<double>& ly, int n, int R, int rank);
 void zslab_destroy(void* z);
 int zslab_run(ocn_ctx* ctx, void* z, void* spec, double dz2, double scale, const void* below = nullptr, void* phi_below = nullptr);
-bool poisson_local_phi_below(const ocn_model* m);   // z-slab runs: the pressure plane below the slab is computed by this rank (no exchange)
+bool poisson_local_phi_below(const ocn_model* m);
+const double* poisson_phi_below(const ocn_model* m);   // that plane, (Nx, Ny), behind the solver's real buffer   // z-slab runs: the pressure plane below the slab is computed by this rank (no exchange)
 
 // ---- comm.hip ---------------------------------------------------------------------------------------------
 int comm_exchange(ocn_ctx* c, const std::vector<CommOp>& sends, const std::vector<CommOp>& recvs, hipStream_t st = nullptr);   // st: default the context's stream

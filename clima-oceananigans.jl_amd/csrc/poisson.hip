@@ -45,9 +45,10 @@ struct PoissonSolver {
   bool cxy_bz = false;                     // Bounded z: the same passes around the tridiagonal sweeps (poisson_run_from_predictor_bz)
   // z-slabs, Green's-function z stage, custom x / y passes: the w* plane of this rank's first level is transformed here and
   // enters the convolution as a source one level below the slab (zslab.hip `bel`) -- the lower neighbour never needs the plane
-  double* zero_plane = nullptr;            // (sy x Ny) zeros: the "u" and "v" of the one-plane right-hand side
-  double2_* bplane = nullptr;              // (Nxh x Ny) spectrum of w*[level 0] / (dz dt)
-  double2_* pbelow = nullptr;              // (Nxh x Ny) spectrum of the solution one level below the slab (zslab.hip k_zslab_below)
+  // Both planes live in "plane Nz" of the solver's arrays (spec and rhs hold Nz + 1 planes on slab runs): the x / y passes
+  // simply run over one plane more, k_zslab_below overwrites the source plane with the solution plane once the sweeps are done.
+  double2_* bplane = nullptr;              // spec + ncol Nz: spectrum of w*[level 0] / (dz dt), later of the solution below the slab
+  bool local_phi = false;                  // that second use is on (OCNHIP_PHI_EXCHANGE=1 keeps the exchange)
   void* tw = nullptr;                      // twiddle holder for the custom passes
   double* rhs = nullptr;      // real (Nx,Ny,Nz)
   double2_* spec = nullptr;   // complex (Nxh,Ny,Nz)
@@ -67,7 +68,7 @@ struct PoissonSolver {
   int yw = 0, Nyg = 0;                      // kx columns per rank (padded), global Ny
   double2_ *ysend = nullptr, *yrecv = nullptr, *yT = nullptr;
 #ifndef OCN_HOST_EMU
-  hipfftHandle fwd = 0, inv = 0, zplan = 0, xinv = 0, xinv1 = 0;   // xinv1: x inverse of ONE plane (the level below a slab)
+  hipfftHandle fwd = 0, inv = 0, zplan = 0, xinv = 0;
   hipfftHandle wxf = 0, wxi = 0, wz = 0;    // kind 4: batched 1-D x (R2C / C2R) and z (C2C) plans
   hipfftHandle yfft = 0;                    // kind 5: contiguous 1-D complex transforms along the global y
 #endif
@@ -156,8 +157,9 @@ PoissonSolver* poisson_create(ocn_model* m) {
     s->Nyl = s->Ny / s->R;
   }
   size_t nr = (size_t)s->Nx * s->Ny * s->Nz, nc = (size_t)s->Nxh * s->Ny * s->Nz;
-  if (hipMalloc((void**)&s->rhs, nr * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&s->spec, nc * sizeof(double2_)) != hipSuccess) {
+  const size_t xr = g->dist ? (size_t)s->Nx * s->Ny : 0, xc = g->dist ? (size_t)s->Nxh * s->Ny : 0;   // one plane more on z-slabs
+  if (hipMalloc((void**)&s->rhs, (nr + xr) * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&s->spec, (nc + xc) * sizeof(double2_)) != hipSuccess) {
     poisson_destroy(s);
     return nullptr;
   }
@@ -210,18 +212,8 @@ PoissonSolver* poisson_create(ocn_model* m) {
     s->tw = zsolve_create(m->ctx, one, one);
     s->cxy = s->tw != nullptr && (s->zs || s->zsl);
     if (s->cxy && g->dist && s->zsl && !(getenv("OCNHIP_WSTAR_EXCHANGE") && atoi(getenv("OCNHIP_WSTAR_EXCHANGE")) != 0)) {
-      const size_t nz0 = (size_t)m->gd.sy * (s->Ny + 1);
-      if (hipMalloc((void**)&s->zero_plane, nz0 * sizeof(double)) != hipSuccess ||
-          hipMalloc((void**)&s->bplane, (size_t)s->Nxh * s->Ny * sizeof(double2_)) != hipSuccess) {
-        poisson_destroy(s);
-        return nullptr;
-      }
-      hipMemset(s->zero_plane, 0, nz0 * sizeof(double));
-      if (!(getenv("OCNHIP_PHI_EXCHANGE") && atoi(getenv("OCNHIP_PHI_EXCHANGE")) != 0) &&
-          hipMalloc((void**)&s->pbelow, (size_t)s->Nxh * s->Ny * sizeof(double2_)) != hipSuccess) {
-        poisson_destroy(s);
-        return nullptr;
-      }
+      s->bplane = s->spec + nc;
+      s->local_phi = !(getenv("OCNHIP_PHI_EXCHANGE") && atoi(getenv("OCNHIP_PHI_EXCHANGE")) != 0);
     }
   }
   // Bounded z (Fourier-tridiagonal solver) with 128-, 256- or 512-point periodic x and y: the same fused right-hand side + x
@@ -276,20 +268,13 @@ PoissonSolver* poisson_create(ocn_model* m) {
   hipfftSetStream(s->inv, m->ctx->stream);
   if (s->cxy || s->cxy_bz) {
     int nx[1] = {s->Nx}, ie[1] = {s->Nxh}, oe[1] = {s->Nx};
-    if (hipfftPlanMany(&s->xinv, 1, nx, ie, 1, s->Nxh, oe, 1, s->Nx, HIPFFT_Z2D, s->Ny * s->Nz) != HIPFFT_SUCCESS) {
+    const int planes = s->Nz + (s->bplane && s->local_phi ? 1 : 0);    // the plane below the slab rides along
+    if (hipfftPlanMany(&s->xinv, 1, nx, ie, 1, s->Nxh, oe, 1, s->Nx, HIPFFT_Z2D, s->Ny * planes) != HIPFFT_SUCCESS) {
       ocn_set_error(m->ctx, "hipfft x-inverse plan creation failed");
       poisson_destroy(s);
       return nullptr;
     }
     hipfftSetStream(s->xinv, m->ctx->stream);
-    if (s->pbelow) {
-      if (hipfftPlanMany(&s->xinv1, 1, nx, ie, 1, s->Nxh, oe, 1, s->Nx, HIPFFT_Z2D, s->Ny) != HIPFFT_SUCCESS) {
-        ocn_set_error(m->ctx, "hipfft x-inverse plan (one plane) creation failed");
-        poisson_destroy(s);
-        return nullptr;
-      }
-      hipfftSetStream(s->xinv1, m->ctx->stream);
-    }
   }
 #endif
   return s;
@@ -302,12 +287,8 @@ void poisson_destroy(PoissonSolver* s) {
   if (s->inv) hipfftDestroy(s->inv);
   if (s->zplan) hipfftDestroy(s->zplan);
   if (s->xinv) hipfftDestroy(s->xinv);
-  if (s->xinv1) hipfftDestroy(s->xinv1);
 #endif
   zsolve_destroy(s->tw);
-  hipFree(s->zero_plane);
-  hipFree(s->bplane);
-  hipFree(s->pbelow);
   hipFree(s->ta);
   hipFree(s->tb);
   hipFree(s->ga);
@@ -1143,7 +1124,8 @@ int poisson_run(ocn_model* m) { return run_solver(m); }
 
 bool poisson_custom_xy(const ocn_model* m) { return m->solver && m->solver->cxy; }
 bool poisson_local_wstar(const ocn_model* m) { return m->solver && m->solver->bplane != nullptr; }
-bool poisson_local_phi_below(const ocn_model* m) { return m->solver && m->solver->pbelow != nullptr; }
+bool poisson_local_phi_below(const ocn_model* m) { return m->solver && m->solver->bplane != nullptr && m->solver->local_phi; }
+const double* poisson_phi_below(const ocn_model* m) { return m->solver->rhs + (size_t)m->solver->Nx * m->solver->Ny * m->solver->Nz; }
 
 #ifdef OCN_HOST_EMU
 // x-inverse of the half spectrum, line by line (emulation of the batched 1-D Z2D plan)
@@ -1174,45 +1156,30 @@ static void emu_xinv(PoissonSolver* s, const double2_* spec = nullptr, double* o
 // Leaves the solution in the solver's real buffer (like run_solver).
 int poisson_run_from_predictor(ocn_model* m, double dt) {
   PoissonSolver* s = m->solver;
+  const int xp = s->bplane ? 1 : 0, ip = (s->bplane && s->local_phi) ? 1 : 0;   // planes more in the forward / inverse passes
   {
     ProfScope ps(m->ctx, "fft_forward");
-    xfft_rhs_run(m, s->tw, s->spec, dt);
-    yfft_run(m->ctx, s->tw, s->spec, s->Nxh, s->Ny, s->Nz, 0);
+    xfft_rhs_run(m, s->tw, s->spec, dt, xp);
+    yfft_run(m->ctx, s->tw, s->spec, s->Nxh, s->Ny, s->Nz + xp, 0);
   }
   if (s->zs) {
     ProfScope ps(m->ctx, "spectral_solve");
     zsolve_run(m->ctx, s->zs, s->spec, s->Nz, s->lz, 1.0 / ((double)s->Nx * s->Ny * s->Nz), 0);
   } else {
-    if (s->bplane) {   // the plane above the slab was left at zero in the right-hand side: its term comes from the rank that owns it
-      ProfScope ps(m->ctx, "fft_forward");
-      xfft_plane_run(m, s->tw, s->bplane, s->zero_plane, m->ws.interior() - m->ws.sz, dt);
-      yfft_run(m->ctx, s->tw, s->bplane, s->Nxh, s->Ny, 1, 0);
-    }
-    int rc = zslab_run(m->ctx, s->zsl, s->spec, s->dz2, 1.0 / ((double)s->Nx * s->Ny), s->bplane, s->pbelow);
+    int rc = zslab_run(m->ctx, s->zsl, s->spec, s->dz2, 1.0 / ((double)s->Nx * s->Ny), s->bplane, ip ? s->bplane : nullptr);
     if (rc) return rc;
   }
   {
     ProfScope ps(m->ctx, "fft_backward");
-    yfft_run(m->ctx, s->tw, s->spec, s->Nxh, s->Ny, s->Nz, 1);
+    yfft_run(m->ctx, s->tw, s->spec, s->Nxh, s->Ny, s->Nz + ip, 1);
 #ifndef OCN_HOST_EMU
     if (dry_hipfftExecZ2D(s->xinv, (hipfftDoubleComplex*)s->spec, s->rhs) != HIPFFT_SUCCESS) {
       ocn_set_error(m->ctx, "hipfftExecZ2D (x inverse) failed");
       return OCN_EHIP;
     }
 #else
-    emu_xinv(s);
+    emu_xinv(s, s->spec, s->rhs, (size_t)s->Ny * (s->Nz + ip));
 #endif
-    if (s->pbelow) {   // the plane below the slab: inverse y, inverse x -> the model's (Nx, Ny) buffer k_project reads
-      yfft_run(m->ctx, s->tw, s->pbelow, s->Nxh, s->Ny, 1, 1);
-#ifndef OCN_HOST_EMU
-      if (dry_hipfftExecZ2D(s->xinv1, (hipfftDoubleComplex*)s->pbelow, m->phi_below) != HIPFFT_SUCCESS) {
-        ocn_set_error(m->ctx, "hipfftExecZ2D (x inverse of the plane below the slab) failed");
-        return OCN_EHIP;
-      }
-#else
-      emu_xinv(s, s->pbelow, m->phi_below, (size_t)s->Ny);
-#endif
-    }
   }
   return OCN_OK;
 }

@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(256) k_yfft(cd* __restrict__ a, int Nxh, int N
 template <int N, bool CO>
 __global__ void __launch_bounds__(256) k_xfft_rhs(GridDev g, const double* __restrict__ us, const double* __restrict__ vs,
                                                   const double* __restrict__ ws, double rdt, int zwrap,
-                                                  cd* __restrict__ spec, const cd* __restrict__ tw) {
+                                                  cd* __restrict__ spec, const cd* __restrict__ tw, int extra) {
   OCN_SHARED double sm[SMN];
   constexpr int M = FftGeo<N>::M, C = FftGeo<N>::C;
   const int t = threadIdx.x;
@@ -369,7 +369,10 @@ __global__ void __launch_bounds__(256) k_xfft_rhs(GridDev g, const double* __res
   const int r = N == 512 ? rr & 15 : rr;
   const int c = N == 512 ? ln + 8 * (rr >> 4) : ln;  // column slot (line + 8 half)
   const long L = (long)blockIdx.x * C + ln;         // line index j + Ny k
-  const long nlines = (long)g.Ny * g.Nz;
+  // extra != 0 (z-slab runs, round 3): Ny more lines behind the slab's own -- "plane Nz" of the spectrum is the x transform of
+  // w*[level 0] / (dz dt), the term the divergence of the level BELOW this slab lacks (its owner forms it with w* above left at
+  // zero); it enters the lower levels' solve through this rank's Green's-function sums (zslab.hip `bel`)
+  const long nlines = (long)g.Ny * (g.Nz + (extra ? 1 : 0));
   const bool ok = L < nlines;
   const long sy = g.sy, sz = g.sz;
   const double rdz = 1.0 / g.dz;
@@ -390,7 +393,8 @@ __global__ void __launch_bounds__(256) k_xfft_rhs(GridDev g, const double* __res
       int j = j0 + l2, k = k0;
       while (j >= g.Ny) { j -= g.Ny; ++k; }
       double d = 0.0;
-      if (k < g.Nz) {
+      if (extra && k == g.Nz) d = ws[j * sy + i] * rdz * rdt;      // the extra plane: w* of level 0 over dz dt
+      else if (k < g.Nz) {
         const long row = j * sy + k * sz;
         const long rown = ((j + 1 == g.Ny) ? 0 : j + 1) * sy + k * sz;
         const long rowt = (zwrap && k + 1 == g.Nz) ? j * sy : j * sy + (k + 1) * sz;
@@ -417,7 +421,8 @@ __global__ void __launch_bounds__(256) k_xfft_rhs(GridDev g, const double* __res
       const int i = pos_in<N>(r, c, n1);
       const int ie = (i + 1 == g.Nx) ? 0 : i + 1;
       double d = 0.0;
-      if (ok && g.zb) {
+      if (ok && extra && k == g.Nz) d = ws[j * sy + i] * rdz * rdt;
+      else if (ok && g.zb) {
         const double dzc = g_dzc(g, k);
         d = ((us[row + ie] - us[row + i]) * g.rdx + (vs[rown + i] - vs[row + i]) * g.rdy + (ws[rowt + i] - ws[row + i]) / dzc) * rdt * dzc;
       } else if (ok) d = ((us[row + ie] - us[row + i]) * g.rdx + (vs[rown + i] - vs[row + i]) * g.rdy + (ws[rowt + i] - ws[row + i]) * rdz) * rdt;
@@ -498,29 +503,11 @@ void yfft_run(ocn_ctx* ctx, void* p, void* spec, int Nxh, int Ny, int Nz, int in
   }
 }
 
-// One plane: spec_plane = x transform of  w_plane / (dz dt)  -- the term the divergence of the level BELOW w_plane's level
-// lacks when that level belongs to another slab (zslab.hip `bel`).  The same kernel with a one-level grid: u and v read a zero
-// plane, "w one level up" is w_plane and "w at the level" the plane under it, which the caller keeps at zero.
-void xfft_plane_run(ocn_model* m, void* p, void* spec_plane, const double* zero_plane, const double* w_plane_minus_one_level, double dt) {
-  ZSolve* z = (ZSolve*)p;
-  GridDev g = m->gd;
-  g.Nz = 1;
-  g.zb = 0;
-  const int C = 256 / (g.Nx / 16);
-  dim3 b(256, 1, 1), gr((unsigned)((g.Ny + C - 1) / C), 1, 1);
-  hipStream_t s = m->ctx->stream;
-  cd* sp = (cd*)spec_plane;
-  const cd* tw = (const cd*)z->tw;
-  const double *us = zero_plane, *ws = w_plane_minus_one_level;
-  FFT_BY_N(g.Nx, ocn_launch_sync(k_xfft_rhs<128, true>, gr, b, s, g, us, us, ws, 1.0 / dt, 0, sp, tw),
-           ocn_launch_sync(k_xfft_rhs<256, true>, gr, b, s, g, us, us, ws, 1.0 / dt, 0, sp, tw),
-           ocn_launch_sync(k_xfft_rhs<512, true>, gr, b, s, g, us, us, ws, 1.0 / dt, 0, sp, tw))
-}
-
-void xfft_rhs_run(ocn_model* m, void* p, void* spec, double dt) {
+void xfft_rhs_run(ocn_model* m, void* p, void* spec, double dt, int extra_plane) {
   ZSolve* z = (ZSolve*)p;
   const GridDev& g = m->gd;
-  const long nlines = (long)g.Ny * g.Nz;
+  const long nlines = (long)g.Ny * (g.Nz + (extra_plane ? 1 : 0));
+  const int ex = extra_plane;
   const int C = 256 / (g.Nx / 16);
   dim3 b(256, 1, 1), gr((unsigned)((nlines + C - 1) / C), 1, 1);
   // the predictor: us / vs / ws on the all-in-one path and between update and projection of the tiled Bounded-z path, else u, v, w
@@ -532,13 +519,13 @@ void xfft_rhs_run(ocn_model* m, void* p, void* spec, double dt) {
   cd* sp = (cd*)spec;
   const cd* tw = (const cd*)z->tw;
   if (m->knob_xfft_team) {
-    FFT_BY_N(g.Nx, ocn_launch_sync(k_xfft_rhs<128, false>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw),
-             ocn_launch_sync(k_xfft_rhs<256, false>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw),
-             ocn_launch_sync(k_xfft_rhs<512, false>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw))
+    FFT_BY_N(g.Nx, ocn_launch_sync(k_xfft_rhs<128, false>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw, ex),
+             ocn_launch_sync(k_xfft_rhs<256, false>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw, ex),
+             ocn_launch_sync(k_xfft_rhs<512, false>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw, ex))
   } else {
-    FFT_BY_N(g.Nx, ocn_launch_sync(k_xfft_rhs<128, true>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw),
-             ocn_launch_sync(k_xfft_rhs<256, true>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw),
-             ocn_launch_sync(k_xfft_rhs<512, true>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw))
+    FFT_BY_N(g.Nx, ocn_launch_sync(k_xfft_rhs<128, true>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw, ex),
+             ocn_launch_sync(k_xfft_rhs<256, true>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw, ex),
+             ocn_launch_sync(k_xfft_rhs<512, true>, gr, b, s, g, us, vs, ws, 1.0 / dt, zw, sp, tw, ex))
   }
 }
 

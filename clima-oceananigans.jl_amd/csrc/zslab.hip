@@ -271,8 +271,8 @@ __global__ void k_zslab_down_reg(zc* __restrict__ a, long ncol, int m, int SZ, i
 // own sum SQ plus rho^n times the carry from above -- everything is on this rank once the sums are gathered, so the pressure
 // plane the lower neighbour used to send (fused_exchange_phi) is computed here instead (round 3).
 __global__ void k_zslab_below(long ncol, int m, int SZ, int R, int rank, const double* __restrict__ lxy, double dz2, double scale,
-                              const zc* __restrict__ segs, const zc* __restrict__ gathered, size_t msg, const zc* __restrict__ bel,
-                              zc* __restrict__ out) {
+                              const zc* __restrict__ segs, const zc* __restrict__ gathered, size_t msg, const zc* bel,
+                              zc* out /* may alias bel */) {
   const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= ncol) return;
   const double lam = lxy[col] * dz2;
@@ -489,7 +489,7 @@ int zslab_run(ocn_ctx* ctx, void* p, void* spec, double dz2, double scale, const
     else
       ocn_launch(k_zslab_down_reg<ZS_MR>, g, b, st, a, z->ncol, z->m, z->SZ, z->R, z->rank, (const double*)z->lxy, dz2,
                  scale * dz2, (const zc*)z->segs, (const zc*)z->gathered, z->msg, (const zc*)below);
-    if (phi_below)   // before the down sweep overwrites nothing it needs: segs and gathered are read-only from here on
+    if (phi_below)   // after the sweeps: phi_below may be the very plane `below` lives in (each thread reads its entry, then writes it)
       ocn_launch(k_zslab_below, g1, b, st, z->ncol, z->m, z->SZ, z->R, z->rank, (const double*)z->lxy, dz2, scale * dz2,
                  (const zc*)z->segs, (const zc*)z->gathered, z->msg, (const zc*)below, (zc*)phi_below);
     ocn_launch_sync(k_zslab_mean, dim3(1), dim3(ZM_T), st, a, z->ncol, 0L, z->n, z->R, z->rank, (const zc*)z->gathered, z->msg,
