@@ -48,9 +48,9 @@ struct ocn_sefs {
   int substeps;
   std::vector<double> wv, wf;
   ocn_hfield *eta, *U, *V, *etabar, *Ubar, *Vbar, *GU, *GV, *Hfc, *Hcf, *Hcc;
-  ocn_hfield *Gu = nullptr, *Gv = nullptr;   // scratch of ocn_sefs_step (AB2-combined tendencies are summed on the fly: unused)
+  double *eta2 = nullptr, *U2 = nullptr, *V2 = nullptr;   // second copies of eta, U, V: the one-launch substep reads one set and writes the other
   // hipGraph of a train of substeps: key = (dtau bits, first index, count)
-  struct Train { uint64_t dtau_bits; int first, count; void* exec; };
+  struct Train { uint64_t dtau_bits; int first, count, mode; void* exec; };
   std::vector<Train> trains;
   int64_t graph_replays = 0;
 };
@@ -228,6 +228,65 @@ __global__ void k_se_uv_fused(SeArgs a) {
   }
 }
 
+// One substep in ONE launch (Periodic x; y Periodic or Bounded): kernel 1 at the thread's own faces AND at its east / north
+// neighbours' (the very expressions those threads evaluate: same operands, same bits), kernel 2 from the four values, the fills
+// as halo images.  Reading and writing the same arrays would race (a thread's new eta against its neighbours' reads of the old
+// one), so eta, U, V exist twice and a substep reads one set and writes the other: 128 B per cell instead of 152, one launch
+// instead of two.  The new set's eta halo takes the images of the OLD eta -- what the reference's eta fill (before kernel 1) left
+// there -- so every parent array keeps the bits of the five-launch substep at every substep.
+struct SeArgs1 {
+  SeArgs a;
+  const double *etaI, *UI, *VI;   // read
+  double *etaO, *UO, *VO;         // written
+};
+__global__ void k_se_substep1(SeArgs1 b) {
+  const SeArgs& a = b.a;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= a.Nx || j >= a.Ny) return;
+  const int Nx = a.Nx, Ny = a.Ny, Hx = a.Hx, Hy = a.Hy;
+  const int iw = i > 0 ? i - 1 : Nx - 1, ie = i + 1 < Nx ? i + 1 : 0;
+  const int js = j > 0 ? j - 1 : (a.yper ? Ny - 1 : 0);
+  const bool north_wall = !a.yper && j == Ny - 1;
+  const int jn = j + 1 < Ny ? j + 1 : (a.yper ? 0 : j);          // unused at a north wall
+  const int r = j + Hy, rn = jn + Hy;
+  auto E = [&](int ii, int jj) { return b.etaI[(ii + Hx) + (long)(jj + Hy) * a.se]; };
+  const long cu = (i + Hx) + (long)r * a.su, cv = (i + Hx) + (long)r * a.sv, ce = (i + Hx) + (long)r * a.se;
+  const long cue = (ie + Hx) + (long)r * a.su, cvn = (i + Hx) + (long)rn * a.sv;
+  const double e0 = E(i, j), ew = E(iw, j), es = E(i, js), ee = E(ie, j);
+  const double u0 = b.UI[cu] + a.dtau * (-a.g * a.Hfc[cu] * ((e0 - ew) / a.dxfc[r]) + a.GU[cu]);
+  const double u1 = b.UI[cue] + a.dtau * (-a.g * a.Hfc[cue] * ((ee - e0) / a.dxfc[r]) + a.GU[cue]);
+  double v0 = b.VI[cv] + a.dtau * (-a.g * a.Hcf[cv] * ((e0 - es) / a.dycf[r]) + a.GV[cv]);
+  if (!a.yper && j == 0) v0 = 0.0;                               // impenetrable south face
+  double v1 = 0.0;                                               // impenetrable north face
+  if (!north_wall) {
+    const double en = E(i, jn);
+    v1 = b.VI[cvn] + a.dtau * (-a.g * a.Hcf[cvn] * ((en - e0) / a.dycf[rn]) + a.GV[cvn]);
+  }
+  const double div = 1.0 / a.azcc[r] * ((a.dyfc[r] * u1 - a.dyfc[r] * u0) + (a.dxcf[r + 1] * v1 - a.dxcf[r] * v0));
+  const double e1 = e0 - a.dtau * div;
+  a.Ubar[cu] += a.wv * u0;
+  a.Vbar[cv] += a.wv * v0;
+  a.etabar[ce] += a.wf * e1;
+  const bool xw = i >= Nx - Hx, xe = i < Hx;
+  auto put = [&](double* p, long pitch, double val, int jj, bool own = true) {
+    const long row = (long)(jj + Hy) * pitch;
+    if (own) p[(i + Hx) + row] = val;
+    if (xw) p[(i - Nx + Hx) + row] = val;
+    if (xe) p[(i + Nx + Hx) + row] = val;
+  };
+  b.etaO[ce] = e1;
+  put(b.etaO, a.se, e0, j, false);                               // halo images of the OLD eta (see above)
+  put(b.UO, a.su, u0, j);
+  put(b.VO, a.sv, v0, j);
+  if (a.yper) {
+    if (j >= Ny - Hy) { put(b.etaO, a.se, e0, j - Ny); put(b.UO, a.su, u0, j - Ny); put(b.VO, a.sv, v0, j - Ny); }
+    if (j < Hy) { put(b.etaO, a.se, e0, j + Ny); put(b.UO, a.su, u0, j + Ny); put(b.VO, a.sv, v0, j + Ny); }
+  } else {
+    if (j == 0) { put(b.etaO, a.se, e0, -1); put(b.UO, a.su, u0, -1); }
+    if (j == Ny - 1) { put(b.etaO, a.se, e0, Ny); put(b.UO, a.su, u0, Ny); put(b.VO, a.sv, 0.0, Ny); }
+  }
+}
+
 // ---- vertical integrals and the corrector ----------------------------------------------------------------------------------
 // sum!(U, u * dz): level 1 first, then level by level (a sequential sum per column; coalesced across i).  With cm != 0 the
 // summand is the AB2 combination (cn G^n + cm G^-) dz of calc_ab2_tendencies (:115) formed on the fly.
@@ -321,6 +380,20 @@ static void sefs_substep_fused(ocn_sefs* s, double dtau, int index) {
   const SeArgs a = se_args(s, dtau, index);
   ocn_launch(k_se_uv_fused, gr, b, st, a);
   ocn_launch(k_se_eta, gr, b, st, a);
+}
+
+// substep `index` in one launch; flip: 0 reads the fields' own arrays and writes the second set, 1 the other way round
+static void sefs_substep_one(ocn_sefs* s, double dtau, int index, int flip) {
+  dim3 b, gr;
+  se_shape(s->g, b, gr);
+  SeArgs1 q;
+  q.a = se_args(s, dtau, index);
+  q.etaI = flip ? s->eta2 : s->eta->d; q.UI = flip ? s->U2 : s->U->d; q.VI = flip ? s->V2 : s->V->d;
+  q.etaO = flip ? s->eta->d : s->eta2; q.UO = flip ? s->U->d : s->U2; q.VO = flip ? s->V->d : s->V2;
+  ocn_launch(k_se_substep1, gr, b, s->g->ctx->stream, q);
+}
+static void se_copy(ocn_ctx* ctx, double* dst, const double* src, size_t n) {
+  ocn_launch(k_se_copy, dim3((unsigned)((n + 255) / 256), 1, 1), dim3(256, 1, 1), ctx->stream, dst, src, n);
 }
 
 static int hfield_new(ocn_hgrid* g, int lx, int ly, int lz, ocn_hfield** out) {
@@ -522,6 +595,11 @@ int ocn_sefs_create(ocn_hgrid* g, double gravitational_acceleration, int substep
       ocn_sefs_destroy(s);
       return rc;
     }
+  if (hipMalloc((void**)&s->eta2, s->eta->n * sizeof(double)) != hipSuccess || hipMalloc((void**)&s->U2, s->U->n * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&s->V2, s->V->n * sizeof(double)) != hipSuccess) {
+    ocn_sefs_destroy(s);
+    return OCN_ENOMEM;
+  }
   // H = sum!(H, dz) over the interior of each depth field (split_explicit_free_surface.jl:103-110)
   double H = 0.0;
   for (int k = 0; k < g->N[2]; ++k) H = k == 0 ? g->h_dzc[0] : H + g->h_dzc[k];
@@ -550,6 +628,7 @@ void ocn_sefs_destroy(ocn_sefs* s) {
       hipFree(f->d);
       delete f;
     }
+  hipFree(s->eta2); hipFree(s->U2); hipFree(s->V2);
   delete s;
 }
 
@@ -584,7 +663,21 @@ int ocn_sefs_substeps(ocn_sefs* s, double dtau, int first_index, int count, int 
   ocn_ctx* ctx = s->g->ctx;
   if (count == 0) return OCN_OK;
   const bool fuse = fused && sefs_fusable(s);
+  const bool one = fuse && fused >= 2;
   auto issue = [&]() {
+    if (one) {
+      // cells neither set ever writes (halo rows behind a wall's first one) must agree between the two sets
+      se_copy(ctx, s->eta2, s->eta->d, s->eta->n);
+      se_copy(ctx, s->U2, s->U->d, s->U->n);
+      se_copy(ctx, s->V2, s->V->d, s->V->n);
+      for (int q = 0; q < count; ++q) sefs_substep_one(s, dtau, first_index + q, q & 1);
+      if (count & 1) {                                 // an odd train ends in the second set: bring it home (the handles' pointers never change)
+        se_copy(ctx, s->eta->d, s->eta2, s->eta->n);
+        se_copy(ctx, s->U->d, s->U2, s->U->n);
+        se_copy(ctx, s->V->d, s->V2, s->V->n);
+      }
+      return;
+    }
     for (int q = 0; q < count; ++q) {
       if (fuse) sefs_substep_fused(s, dtau, first_index + q);
       else sefs_substep_plain(s, dtau, first_index + q);
@@ -596,7 +689,7 @@ int ocn_sefs_substeps(ocn_sefs* s, double dtau, int first_index, int count, int 
     uint64_t bits;
     memcpy(&bits, &dtau, 8);
     for (auto& t : s->trains)
-      if (t.dtau_bits == bits && t.first == first_index && t.count == count && t.exec) {
+      if (t.dtau_bits == bits && t.first == first_index && t.count == count && t.mode == (one ? 2 : 1) && t.exec) {
         OCN_HIP_CHECK(ctx, hipGraphLaunch((hipGraphExec_t)t.exec, ctx->stream));
         s->graph_replays += 1;
         return api_done(ctx, OCN_OK);
@@ -613,7 +706,7 @@ int ocn_sefs_substeps(ocn_sefs* s, double dtau, int first_index, int count, int 
           hipGraphExecDestroy((hipGraphExec_t)s->trains.front().exec);
           s->trains.erase(s->trains.begin());
         }
-        s->trains.push_back({bits, first_index, count, (void*)exec});
+        s->trains.push_back({bits, first_index, count, one ? 2 : 1, (void*)exec});
         OCN_HIP_CHECK(ctx, hipGraphLaunch(exec, ctx->stream));
         s->graph_replays += 1;
         return api_done(ctx, OCN_OK);
@@ -681,7 +774,7 @@ int ocn_sefs_step(ocn_sefs* s, const ocn_hfield* Gnu, const ocn_hfield* Gnv, con
   vsum(s, s->GV, Gnv, Gmv, 1.5 + chi, 0.5 + chi);
   hfield_fill(s->GU);
   hfield_fill(s->GV);
-  if ((rc = ocn_sefs_substeps(s, dtau, 1, s->substeps, 1))) return rc;
+  if ((rc = ocn_sefs_substeps(s, dtau, 1, s->substeps, 2))) return rc;
   // set!(eta, etabar) copies the parent array (Fields/set!.jl:41-44); then fill_halo_regions!(eta)
   ocn_launch(k_se_copy, dim3((unsigned)((s->eta->n + 255) / 256), 1, 1), dim3(256, 1, 1), ctx->stream, s->eta->d, (const double*)s->etabar->d, s->eta->n);
   hfield_fill(s->eta);
