@@ -24,6 +24,10 @@ enum { HG_RECT = 0, HG_LATLON = 1 };
 
 struct ocn_hgrid {
   ocn_ctx* ctx;
+  // Fields and free surfaces keep using their grid (its stream, its metrics) until they are destroyed themselves, and a host
+  // language with a garbage collector finalises a dropped object graph in no particular order: the grid is reference counted,
+  // ocn_hgrid_destroy only gives up the caller's reference.
+  int refs = 1;
   int kind;
   int N[3], H[3], topo[3];
   double x0[3], L[3], radius;
@@ -413,6 +417,7 @@ static int hfield_new(ocn_hgrid* g, int lx, int ly, int lz, ocn_hfield** out) {
     return OCN_ENOMEM;
   }
   OCN_ASYNC(hipMemsetAsync(f->d, 0, f->n * sizeof(double), g->ctx->stream));
+  g->refs += 1;
   *out = f;
   return OCN_OK;
 }
@@ -500,8 +505,10 @@ int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* d, ocn_hgrid** out) {
   return OCN_OK;
 }
 
-void ocn_hgrid_destroy(ocn_hgrid* g) {
-  if (!g) return;
+static void hgrid_release(ocn_hgrid* g);
+void ocn_hgrid_destroy(ocn_hgrid* g) { hgrid_release(g); }
+static void hgrid_release(ocn_hgrid* g) {
+  if (!g || --g->refs > 0) return;
   hipFree(g->dxfc); hipFree(g->dxcf); hipFree(g->dyfc); hipFree(g->dycf); hipFree(g->azcc); hipFree(g->dzc);
   delete g;
 }
@@ -542,7 +549,9 @@ void ocn_hfield_destroy(ocn_hfield* f) {
   if (!f) return;
   hipStreamSynchronize(f->g->ctx->stream);
   if (f->owned) hipFree(f->d);
+  ocn_hgrid* g = f->g;
   delete f;
+  hgrid_release(g);
 }
 
 int ocn_hfield_shape(const ocn_hfield* f, int32_t total[3], int32_t interior[3], int32_t halo[3]) {
@@ -581,6 +590,7 @@ int ocn_sefs_create(ocn_hgrid* g, double gravitational_acceleration, int substep
   if (!g || !out || substeps < 1) return OCN_EINVAL;
   ocn_sefs* s = new ocn_sefs;
   s->g = g;
+  g->refs += 1;
   s->grav = gravitational_acceleration;
   s->substeps = substeps;
   s->wv.assign(substeps, 1.0 / substeps);       // SplitExplicitSettings: ones(substeps) ./ substeps
@@ -623,13 +633,16 @@ void ocn_sefs_destroy(ocn_sefs* s) {
   for (auto& t : s->trains)
     if (t.exec) hipGraphExecDestroy((hipGraphExec_t)t.exec);
 #endif
+  ocn_hgrid* g = s->g;
   for (ocn_hfield* f : {s->eta, s->U, s->V, s->etabar, s->Ubar, s->Vbar, s->GU, s->GV, s->Hfc, s->Hcf, s->Hcc})
     if (f) {
       hipFree(f->d);
       delete f;
+      hgrid_release(g);          // the reference hfield_new took
     }
   hipFree(s->eta2); hipFree(s->U2); hipFree(s->V2);
   delete s;
+  hgrid_release(g);
 }
 
 ocn_hfield* ocn_sefs_field(ocn_sefs* s, int which) {

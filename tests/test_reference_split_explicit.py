@@ -351,24 +351,3 @@ def test_fused_train_is_bitwise_the_plain_substeps(kind, topo_y, ocn, backend):
         for name in ("eta", "U", "V", "etabar", "Ubar", "Vbar"):
             x, y = getattr(out[0], name).parent(), getattr(other, name).parent()
             assert np.isfinite(x).all() and np.array_equal(x, y), name
-
-
-@pytest.mark.gpu
-def test_failed_launch_is_reported_by_the_call_that_issued_it(ocn, backend):
-    """A launch the runtime refuses (here: 75,000 workgroups along y, over the 65,535 limit) used to surface at the next ocn_sync
-    as an anonymous error, after entry points had returned success.  Every launch now asks hipGetLastError() right away; the entry
-    point that issued it returns OCN_EHIP and ocn_last_error names the kernel (csrc/compat.h ocn_launch_impl, api_ret / api_done)."""
-    if backend != "gpu":
-        pytest.skip("HIP run only")
-    H = ocn.hydrostatic
-    grid = H.HRectilinearGrid(size=(4, 300000, 1), x=(0, 1), y=(0, 1), z=(-1, 0), halo=(1, 1, 1), topology=(P, P, B))
-    sefs = H.SplitExplicitFreeSurface(grid, substeps=2)
-    with pytest.raises(ocn.OcnError) as err:
-        sefs.substep(1e-3, 1)
-    assert "OCN_EHIP" in str(err.value) and "k_se_uv" in str(err.value)
-    grid.ctx.sync()                                          # the context is still usable: the error was consumed by the report
-    small = H.HRectilinearGrid(size=(8, 8, 2), x=(0, 1), y=(0, 1), z=(-1, 0), halo=(1, 1, 1), topology=(P, P, B))
-    s2 = H.SplitExplicitFreeSurface(small, substeps=2)
-    s2.eta.set(1.0)
-    s2.substep(1e-3, 1)
-    assert np.all(interior2(s2.eta) == 1.0)
