@@ -48,28 +48,36 @@ def test_eight_rank_slabs_match_single_domain_oracle(ocn, backend, stepper, nzl,
     _slab_trajectory(ocn, backend, 8, stepper, "WENO5", nzl, monkeypatch, overlap=True)
 
 
-def _slab_trajectory(ocn, backend, R, stepper, adv, nzl, monkeypatch, overlap=None):
+def test_four_rank_slabs_with_local_planes(ocn, backend, monkeypatch):
+    """R = 4 slabs of a 128 x 128 x 32 box: 128-point rows put the run on the custom transform passes, where the w* term above a
+    slab and the pressure plane below it are computed by the rank itself (two exchanges per step; csrc/zslab.hip `bel`,
+    k_zslab_below) -- the carries then run over three other ranks and the slab's own periodic image"""
+    _slab_trajectory(ocn, backend, 4, "AB2", "WENO5", 8, monkeypatch, overlap=True, Nxy=(128, 128), nsteps=1)
+
+
+def _slab_trajectory(ocn, backend, R, stepper, adv, nzl, monkeypatch, overlap=None, Nxy=(8, 8), nsteps=None):
     if backend != "hostemu":
         pytest.skip("host-emulation run only")
     if nzl != 8 or overlap:
         monkeypatch.setenv("OCNHIP_OVERLAP", "1")   # by default only with 8 MB or more of halo planes per direction
-    N = (8, 8, nzl * R)
+    N = (Nxy[0], Nxy[1], nzl * R)
     rng = np.random.default_rng(5)
     init = {n: rng.random(N) - 0.5 for n in "uvw"}
     tracers = ("c",) if stepper == "RK3" else ()
     for t in tracers:
         init[t] = rng.random(N)
-    og = O.RectilinearGrid(size=N, extent=(1, 1, float(R)), topology=(P,) * 3)
+    ext = (1, 1, float(R)) if Nxy == (8, 8) else (1.0, N[1] / N[0], N[2] / N[0])
+    og = O.RectilinearGrid(size=N, extent=ext, topology=(P,) * 3)
     om = O.NonhydrostaticModel(og, advection=O.WENO5() if adv == "WENO5" else O.CenteredSecondOrder(), timestepper=stepper,
                                tracers=tracers)
     O.set_model(om, **init)
-    dt = 2e-3
-    nsteps = 2 if nzl == 8 else 3
+    dt = 2e-3 if Nxy == (8, 8) else 0.1 / N[0] / np.abs(om.u.data).max()
+    nsteps = nsteps or (2 if nzl == 8 else 3)
     for _ in range(nsteps):
         O.time_step(om, dt)
 
     def rank_fn(ctx, r):
-        g = ocn.RectilinearGrid(ctx, size=N, extent=(1, 1, float(R)), topology=(P,) * 3)
+        g = ocn.RectilinearGrid(ctx, size=N, extent=ext, topology=(P,) * 3)
         m = ocn.NonhydrostaticModel(g, advection=ocn.WENO5() if adv == "WENO5" else ocn.CenteredSecondOrder(),
                                     timestepper=stepper, tracers=tracers)
         nz = N[2] // R
