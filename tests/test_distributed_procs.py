@@ -122,3 +122,12 @@ def test_library_two_ranks_one_gpu(case, env):
     """two processes, one MI355X, host shared-memory transport: slab kernels, pack / unpack, exchange order and the
     distributed solvers of the product library against the single-domain oracle"""
     run_world(case, "gpu", 2, extra_env=env)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,env", [("zslab_custom", {"OCNHIP_OVERLAP": "1"}), ("zslab_rk3_tracer", {"OCNHIP_OVERLAP": "1"})],
+                         ids=["zslab_custom", "zslab_rk3_tracer"])
+def test_library_four_ranks_one_gpu(case, env):
+    """four processes on the one MI355X (the box allows six): the carries of the slab Poisson solve run over three other ranks and
+    the slab's own periodic image, the halo ring has four members -- closer to config 4's eight than the two-rank runs"""
+    run_world(case, "gpu", 4, extra_env=env)
