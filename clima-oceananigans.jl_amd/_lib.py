@@ -46,6 +46,13 @@ class ModelDesc(C.Structure):
                 ("bcs", (BC * 6) * (3 + MAX_TRACERS)), ("nu_bcs", BC * 6), ("kappa_bcs", (BC * 6) * MAX_TRACERS)]
 
 
+class HydroDesc(C.Structure):
+    _fields_ = [("free_surface", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("w", C.c_void_p), ("pHY", C.c_void_p),
+                ("ntracers", C.c_int32), ("tracers", C.POINTER(C.c_void_p)), ("Gn", C.POINTER(C.c_void_p)), ("Gm", C.POINTER(C.c_void_p)),
+                ("buoyancy_kind", C.c_int32), ("T_index", C.c_int32), ("S_index", C.c_int32),
+                ("gravitational_acceleration", C.c_double), ("thermal_expansion", C.c_double), ("haline_contraction", C.c_double)]
+
+
 class HGridDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("N", C.c_int32 * 3), ("H", C.c_int32 * 3), ("topology", C.c_int32 * 3),
                 ("x0", C.c_double * 3), ("L", C.c_double * 3), ("z_faces", C.POINTER(C.c_double)), ("radius", C.c_double)]
@@ -62,7 +69,7 @@ class OcnError(RuntimeError):
 _lib = None
 
 
-ABI_VERSION = 4   # OCN_ABI_VERSION of include/ocnhip.h
+ABI_VERSION = 5   # OCN_ABI_VERSION of include/ocnhip.h
 
 
 def lib_path():
@@ -147,6 +154,15 @@ def load():
         "ocn_sefs_set_average_to_zero": (I, [P]),
         "ocn_sefs_corrector": (I, [P, P, P]),
         "ocn_sefs_step": (I, [P, P, P, P, P, D, D]),
+        "ocn_hfield_ab2_step": (I, [P, P, P, D, D]),
+        "ocn_hfield_store_tendency": (I, [P, P]),
+        "ocn_hydro_compute_w": (I, [P, P, P]),
+        "ocn_hydro_pressure": (I, [P, I, D, D, D, P, P]),
+        "ocn_hydro_create": (I, [C.POINTER(HydroDesc), C.POINTER(P)]),
+        "ocn_hydro_destroy": (None, [P]),
+        "ocn_hydro_update_state": (I, [P]),
+        "ocn_hydro_ab2_step": (I, [P, D, D]),
+        "ocn_hydro_step_after_tendencies": (I, [P, D, D, I]),
         "ocn_profile_enable": (I, [P, I]),
         "ocn_profile_read": (I, [P, C.c_char_p, PD, C.POINTER(C.c_int64)]),
         "ocn_profile_reset": (I, [P]),

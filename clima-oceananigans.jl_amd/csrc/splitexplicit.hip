@@ -20,6 +20,13 @@
 // the bits the launch-by-launch path leaves, halos included (tests/test_reference_split_explicit.py).
 #include "internal.h"
 
+// kernels whose launch-by-launch and fused forms (and the NumPy oracle) must round identically: no contraction into FMAs
+#if defined(__clang__)
+#define OCN_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define OCN_NO_CONTRACT
+#endif
+
 enum { HG_RECT = 0, HG_LATLON = 1 };
 
 struct ocn_hgrid {
@@ -34,7 +41,8 @@ struct ocn_hgrid {
   bool z_regular;
   std::vector<double> nodeF[3], nodeC[3];          // incl. halos, entry [i - 1 + H] for reference index i
   std::vector<double> h_dxfc, h_dxcf, h_dyfc, h_dycf, h_azcc, h_dzc;   // per row j (entry [j - 1 + Hy]) / per level k (entry [k - 1])
-  double *dxfc = nullptr, *dxcf = nullptr, *dyfc = nullptr, *dycf = nullptr, *azcc = nullptr, *dzc = nullptr;   // device copies
+  std::vector<double> h_dzf;                                           // dz^f[k] = zC[k] - zC[k-1], k = 1..Nz+1 (entry [k - 1]); needs Hz >= 1
+  double *dxfc = nullptr, *dxcf = nullptr, *dyfc = nullptr, *dycf = nullptr, *azcc = nullptr, *dzc = nullptr, *dzf = nullptr;   // device copies
 };
 
 struct ocn_hfield {
@@ -129,9 +137,27 @@ __global__ void k_h_fill_bounded(double* p, int dim, int face, int N, int H, int
   }
 }
 
+// z (always Bounded here), over i = 1..Nx, j = 1..Ny of the grid (the `:xy` launch): Center -> no-flux, Face -> the default
+// impenetrable condition of a ZFaceField zeroes faces 1 and Nz + 1
+__global__ void k_h_fill_z(double* p, int face, int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int Tx, int Ty) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= Nx || j >= Ny) return;
+  const long sz = (long)Tx * Ty, c = (i + Hx) + (long)(j + Hy) * Tx;
+  if (face) {
+    p[c + (long)Hz * sz] = 0.0;
+    p[c + (long)(Hz + Nz) * sz] = 0.0;
+  } else {
+    p[c + (long)(Hz - 1) * sz] = p[c + (long)Hz * sz];
+    p[c + (long)(Hz + Nz) * sz] = p[c + (long)(Hz + Nz - 1) * sz];
+  }
+}
+
 static void hfield_fill(ocn_hfield* f) {
   ocn_hgrid* g = f->g;
   hipStream_t s = g->ctx->stream;
+  if (f->loc[2] != OCN_NOTHING && (g->H[2] > 0 || f->loc[2] == OCN_FACE))
+    ocn_launch(k_h_fill_z, dim3((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, 1), dim3(64, 4, 1), s, f->d, f->loc[2] == OCN_FACE ? 1 : 0, g->N[0], g->N[1],
+               g->N[2], g->H[0], g->H[1], g->H[2], f->T[0], f->T[1]);
   // non-periodic directions first (fill_halo_regions.jl:76-99)
   int order[2] = {0, 1};
   if (g->topo[0] == OCN_PERIODIC && g->topo[1] != OCN_PERIODIC) { order[0] = 1; order[1] = 0; }
@@ -296,6 +322,7 @@ __global__ void k_se_substep1(SeArgs1 b) {
 // summand is the AB2 combination (cn G^n + cm G^-) dz of calc_ab2_tendencies (:115) formed on the fly.
 __global__ void k_se_vsum(double* out, const double* a, const double* b, double cn, double cm, const double* dzc, int Sx, int Sy, int Nz,
                           int Hx, int Hy, int Hz, long sy3, long sz3, long sy2) {
+  OCN_NO_CONTRACT
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= Sx || j >= Sy) return;
   const long c3 = (i + Hx) + (long)(j + Hy) * sy3 + (long)Hz * sz3;
@@ -322,6 +349,163 @@ __global__ void k_se_correct(double* u, double* v, const double* U, const double
 __global__ void k_se_copy(double* dst, const double* src, size_t n) {
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < n) dst[q] = src[q];
+}
+
+
+// ---- second slice of config 5: the AB2 time step of the hydrostatic model around its tendency evaluation ---------------------
+//   TimeSteppers/quasi_adams_bashforth_2.jl:158-166  ab2_step_field!                                   k_hy_ab2
+//   hydrostatic_free_surface_ab2_step.jl:15-48       ab2_step! (barotropic mode, velocities, tracers, free surface)
+//   compute_w_from_continuity.jl:31-36               _compute_w_from_continuity!                       k_hy_w
+//   update_hydrostatic_pressure.jl:10-18             _update_hydrostatic_pressure!                     k_hy_pressure
+//   TimeSteppers/store_tendencies.jl:14-36           G^- <- G^n                                        k_se_copy / fused
+//   update_hydrostatic_free_surface_model_state.jl:21-48  update_state!                                hydro_update_state
+// The arithmetic of these kernels is kept free of contraction so that the launch-by-launch sequence, the fused passes and
+// the NumPy oracle round identically (they are bound by HBM, the FMAs buy nothing).
+
+struct HyBuoy {          // buoyancy_perturbation: 0 none, 1 BuoyancyTracer (b = T), 2 SeawaterBuoyancy with a LinearEquationOfState
+  int kind;
+  double g, alpha, beta;
+};
+__device__ inline double hy_b(const HyBuoy& q, double T, double S) {
+  OCN_NO_CONTRACT
+  if (q.kind == 1) return T;
+  if (q.kind == 2) return q.g * (q.alpha * T - q.beta * S);
+  return 0.0;
+}
+__device__ inline double hy_ab2(double f, double gn, double gm, double dt, double cn, double cm) {
+  OCN_NO_CONTRACT
+  return f + dt * (cn * gn - cm * gm);
+}
+
+// ab2_step_field! over i = 1..Nx, j = 1..Ny, k = 1..Nz of the grid (the boundary face of a Bounded direction is not stepped)
+__global__ void k_hy_ab2(double* f, const double* gn, const double* gm, double dt, double cn, double cm, int Nx, int Ny, int Nz, int Hx, int Hy,
+                         int Hz, long sy, long sz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
+  if (i >= Nx || j >= Ny || k >= Nz) return;
+  const long c = (i + Hx) + (long)(j + Hy) * sy + (long)(k + Hz) * sz;
+  f[c] = hy_ab2(f[c], gn[c], gm[c], dt, cn, cm);
+}
+
+struct HyGrid {
+  const double *dxcf, *dyfc, *azcc, *dzc, *dzf;
+  int Nx, Ny, Nz, Hx, Hy, Hz;
+};
+
+// w[1] = 0, w[k] = w[k-1] - dz^c[k-1] div_xy(k-1): one thread per column, coalesced along x, marching upwards
+__global__ void k_hy_w(HyGrid g, const double* u, const double* v, double* w, long syu, long szu, long syv, long szv, long syw, long szw) {
+  OCN_NO_CONTRACT
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  const int r = j + g.Hy;
+  const double dy = g.dyfc[r], dxs = g.dxcf[r], dxn = g.dxcf[r + 1], ra = 1 / g.azcc[r];
+  long cu = (i + g.Hx) + (long)r * syu + (long)g.Hz * szu, cv = (i + g.Hx) + (long)r * syv + (long)g.Hz * szv;
+  long cw = (i + g.Hx) + (long)r * syw + (long)g.Hz * szw;
+  double acc = 0.0;
+  w[cw] = acc;
+  for (int k = 0; k < g.Nz; ++k) {
+    const double div = ra * ((dy * u[cu + 1] - dy * u[cu]) + (dxn * v[cv + syv] - dxs * v[cv]));
+    acc = acc - g.dzc[k] * div;
+    cw += szw;
+    w[cw] = acc;
+    cu += szu;
+    cv += szv;
+  }
+}
+
+// pHY'[Nz] = -I_z(b)[Nz+1] dz^f[Nz+1]; pHY'[k] = pHY'[k+1] - I_z(b)[k+1] dz^f[k+1]: one thread per column, marching downwards; the
+// buoyancy of level Nz + 1 is read from the tracers' (filled) top halo
+__global__ void k_hy_pressure(HyGrid g, HyBuoy q, const double* T, const double* S, double* p, long sy, long sz) {
+  OCN_NO_CONTRACT
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  long c = (i + g.Hx) + (long)(j + g.Hy) * sy + (long)(g.Hz + g.Nz) * sz;       // level Nz + 1
+  double bup = hy_b(q, T ? T[c] : 0.0, S ? S[c] : 0.0), acc = 0.0;
+  for (int k = g.Nz; k >= 1; --k) {
+    c -= sz;
+    const double b = hy_b(q, T ? T[c] : 0.0, S ? S[c] : 0.0);
+    const double bf = (bup + b) / 2;
+    acc = k == g.Nz ? -bf * g.dzf[k] : acc - bf * g.dzf[k];                        // dzf entry [k] = face k + 1
+    p[c] = acc;
+    bup = b;
+  }
+}
+
+// fused pass over one velocity component: the barotropic mode of the velocity before the step (-> U), the vertical integral of
+// the AB2 tendency (-> G^U), the AB2 step, the barotropic mode of the stepped velocity (-> Un, for the corrector) and G^- <- G^n;
+// sums over the field's interior (incl. the boundary face of a Bounded direction), the step over the grid's cells
+__global__ void k_hy_momentum(double* u, const double* gn, double* gm, double* U, double* GU, double* Un, double dt, double cn, double cm,
+                              const double* dzc, int Sx, int Sy, int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, long sy3, long sz3, long sy2) {
+  OCN_NO_CONTRACT
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= Sx || j >= Sy) return;
+  const bool step = i < Nx && j < Ny;
+  long c = (i + Hx) + (long)(j + Hy) * sy3 + (long)Hz * sz3;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int k = 0; k < Nz; ++k, c += sz3) {
+    const double uo = u[c], n = gn[c], m = gm[c], dz = dzc[k];
+    const double G = cn * n - cm * m;
+    const double un = step ? hy_ab2(uo, n, m, dt, cn, cm) : uo;
+    a0 = k == 0 ? uo * dz : a0 + uo * dz;
+    a1 = k == 0 ? G * dz : a1 + G * dz;
+    a2 = k == 0 ? un * dz : a2 + un * dz;
+    if (step) {
+      u[c] = un;
+      gm[c] = n;
+    }
+  }
+  const long c2 = (i + Hx) + (long)(j + Hy) * sy2;
+  U[c2] = a0;
+  GU[c2] = a1;
+  Un[c2] = a2;
+}
+
+// fused pass over the tracers that make the buoyancy (one or two), marching downwards: AB2 step, G^- <- G^n, and the hydrostatic
+// pressure from the stepped values (the no-flux top halo equals level Nz)
+__global__ void k_hy_tracers(HyGrid g, HyBuoy q, double* T, const double* gnT, double* gmT, double* S, const double* gnS, double* gmS, double* p,
+                             double dt, double cn, double cm, long sy, long sz) {
+  OCN_NO_CONTRACT
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
+  long c = (i + g.Hx) + (long)(j + g.Hy) * sy + (long)(g.Hz + g.Nz) * sz;
+  double bup = 0.0, acc = 0.0;
+  for (int k = g.Nz; k >= 1; --k) {
+    c -= sz;
+    const double nT = gnT[c], t = hy_ab2(T[c], nT, gmT[c], dt, cn, cm);
+    T[c] = t;
+    gmT[c] = nT;
+    double s = 0.0;
+    if (S) {
+      const double nS = gnS[c];
+      s = hy_ab2(S[c], nS, gmS[c], dt, cn, cm);
+      S[c] = s;
+      gmS[c] = nS;
+    }
+    const double b = hy_b(q, t, s);
+    if (k == g.Nz) bup = b;
+    const double bf = (bup + b) / 2;
+    acc = k == g.Nz ? -bf * g.dzf[k] : acc - bf * g.dzf[k];
+    p[c] = acc;
+    bup = b;
+  }
+}
+
+// store_field_tendencies! (TimeSteppers/store_tendencies.jl:8-11): G^-[i, j, k] = G^n[i, j, k] over the grid's cells
+__global__ void k_hy_store(double* gm, const double* gn, int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, long sy, long sz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
+  if (i >= Nx || j >= Ny || k >= Nz) return;
+  const long c = (i + Hx) + (long)(j + Hy) * sy + (long)(k + Hz) * sz;
+  gm[c] = gn[c];
+}
+
+// a tracer that does not enter the buoyancy: AB2 step and G^- <- G^n in one pass
+__global__ void k_hy_ab2_store(double* f, const double* gn, double* gm, double dt, double cn, double cm, int Nx, int Ny, int Nz, int Hx, int Hy,
+                               int Hz, long sy, long sz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
+  if (i >= Nx || j >= Ny || k >= Nz) return;
+  const long c = (i + Hx) + (long)(j + Hy) * sy + (long)(k + Hz) * sz;
+  const double n = gn[c];
+  f[c] = hy_ab2(f[c], n, gm[c], dt, cn, cm);
+  gm[c] = n;
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -429,8 +613,94 @@ static void vsum(ocn_sefs* s, ocn_hfield* out, const ocn_hfield* a, const ocn_hf
              (const double*)g->dzc, out->S[0], out->S[1], g->N[2], g->H[0], g->H[1], g->H[2], (long)a->T[0], (long)a->T[0] * a->T[1], (long)out->T[0]);
 }
 
+
+// ---- the hydrostatic step (second slice) ----------------------------------------------------------------------------------------
+struct ocn_hydro {
+  ocn_sefs* fs;
+  ocn_hfield *u, *v, *w, *pHY;
+  std::vector<ocn_hfield*> c, gn, gm;        // tracers and the tendencies: entries 0, 1 of gn / gm are u, v; 2.. the tracers
+  HyBuoy buoy;
+  int bT, bS;                                // indices (into c) of the tracers the buoyancy reads, -1: none
+  double *Un = nullptr, *Vn = nullptr;       // barotropic mode of the stepped velocities, kept for the corrector
+};
+
+static HyGrid hy_grid(const ocn_hgrid* g) {
+  HyGrid q;
+  q.dxcf = g->dxcf; q.dyfc = g->dyfc; q.azcc = g->azcc; q.dzc = g->dzc; q.dzf = g->dzf;
+  q.Nx = g->N[0]; q.Ny = g->N[1]; q.Nz = g->N[2]; q.Hx = g->H[0]; q.Hy = g->H[1]; q.Hz = g->H[2];
+  return q;
+}
+static void hy_cols(const ocn_hgrid* g, dim3& b, dim3& gr) {
+  b = dim3(64, 4, 1);
+  gr = dim3((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, 1);
+}
+static void hy_ab2_launch(ocn_hfield* f, const ocn_hfield* gn, ocn_hfield* gm, double dt, double chi, bool store) {
+  const ocn_hgrid* g = f->g;
+  dim3 b(64, 4, 1), gr((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, g->N[2]);
+  if (store)
+    ocn_launch(k_hy_ab2_store, gr, b, g->ctx->stream, f->d, (const double*)gn->d, gm->d, dt, 1.5 + chi, 0.5 + chi, g->N[0], g->N[1], g->N[2], g->H[0],
+               g->H[1], g->H[2], (long)f->T[0], (long)f->T[0] * f->T[1]);
+  else
+    ocn_launch(k_hy_ab2, gr, b, g->ctx->stream, f->d, (const double*)gn->d, (const double*)gm->d, dt, 1.5 + chi, 0.5 + chi, g->N[0], g->N[1], g->N[2],
+               g->H[0], g->H[1], g->H[2], (long)f->T[0], (long)f->T[0] * f->T[1]);
+}
+static void hy_store_launch(ocn_hfield* gm, const ocn_hfield* gn) {
+  const ocn_hgrid* g = gm->g;
+  dim3 b(64, 4, 1), gr((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, g->N[2]);
+  ocn_launch(k_hy_store, gr, b, g->ctx->stream, gm->d, (const double*)gn->d, g->N[0], g->N[1], g->N[2], g->H[0], g->H[1], g->H[2], (long)gm->T[0],
+             (long)gm->T[0] * gm->T[1]);
+}
+static void hy_w_launch(const ocn_hfield* u, const ocn_hfield* v, ocn_hfield* w) {
+  const ocn_hgrid* g = w->g;
+  dim3 b, gr;
+  hy_cols(g, b, gr);
+  ocn_launch(k_hy_w, gr, b, g->ctx->stream, hy_grid(g), (const double*)u->d, (const double*)v->d, w->d, (long)u->T[0], (long)u->T[0] * u->T[1],
+             (long)v->T[0], (long)v->T[0] * v->T[1], (long)w->T[0], (long)w->T[0] * w->T[1]);
+}
+static void hy_pressure_launch(ocn_hfield* p, const HyBuoy& q, const ocn_hfield* T, const ocn_hfield* S) {
+  const ocn_hgrid* g = p->g;
+  dim3 b, gr;
+  hy_cols(g, b, gr);
+  ocn_launch(k_hy_pressure, gr, b, g->ctx->stream, hy_grid(g), q, T ? (const double*)T->d : (const double*)nullptr,
+             S ? (const double*)S->d : (const double*)nullptr, p->d, (long)p->T[0], (long)p->T[0] * p->T[1]);
+}
+static bool is_loc(const ocn_hfield* f, const ocn_hgrid* g, int lx, int ly, int lz) {
+  return f && f->g == g && f->loc[0] == lx && f->loc[1] == ly && f->loc[2] == lz;
+}
+// everything of ocn_sefs_step after the vertical integrals of the tendencies
+static int sefs_step_tail(ocn_sefs* s, double dt) {
+  ocn_ctx* ctx = s->g->ctx;
+  const double dtau = 2 * dt / s->substeps;                        // "we evolve for two times the dt" (:137)
+  hfield_fill(s->GU);
+  hfield_fill(s->GV);
+  if (int rc = ocn_sefs_substeps(s, dtau, 1, s->substeps, 2)) return rc;
+  // set!(eta, etabar) copies the parent array (Fields/set!.jl:41-44); then fill_halo_regions!(eta)
+  se_copy(ctx, s->eta->d, s->etabar->d, s->eta->n);
+  hfield_fill(s->eta);
+  return OCN_OK;
+}
+static void sefs_correct_launch(ocn_sefs* s, ocn_hfield* u, ocn_hfield* v) {
+  const ocn_hgrid* g = s->g;
+  dim3 blk(64, 4, 1), gr((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, g->N[2]);
+  ocn_launch(k_se_correct, gr, blk, g->ctx->stream, u->d, v->d, (const double*)s->U->d, (const double*)s->V->d, (const double*)s->Ubar->d,
+             (const double*)s->Vbar->d, (const double*)s->Hfc->d, (const double*)s->Hcf->d, g->N[0], g->N[1], g->N[2], g->H[0], g->H[1], g->H[2],
+             (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)s->U->T[0], (long)s->V->T[0]);
+}
+// update_state!: fills of the prognostic fields, w from continuity, the hydrostatic pressure, fills of w and pHY'
+static void hydro_update_state(ocn_hydro* h, bool pressure_done) {
+  hfield_fill(h->u);
+  hfield_fill(h->v);
+  hfield_fill(h->fs->eta);
+  for (ocn_hfield* c : h->c) hfield_fill(c);
+  hy_w_launch(h->u, h->v, h->w);
+  if (!pressure_done) hy_pressure_launch(h->pHY, h->buoy, h->bT >= 0 ? h->c[h->bT] : nullptr, h->bS >= 0 ? h->c[h->bS] : nullptr);
+  hfield_fill(h->w);
+  hfield_fill(h->pHY);
+}
+
 static bool same_shape(const ocn_hfield* a, const ocn_hfield* b) {
-  return a && b && a->g == b->g && a->T[0] == b->T[0] && a->T[1] == b->T[1] && a->T[2] == b->T[2];
+  return a && b && a->g == b->g && a->T[0] == b->T[0] && a->T[1] == b->T[1] && a->T[2] == b->T[2] && a->loc[0] == b->loc[0] &&
+         a->loc[1] == b->loc[1] && a->loc[2] == b->loc[2];
 }
 
 extern "C" {
@@ -476,6 +746,16 @@ int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* d, ocn_hgrid** out) {
     for (int k = 0; k < g->N[2]; ++k) g->nodeC[2][k] = (d->z_faces[k + 1] + d->z_faces[k]) / 2;
     g->L[2] = d->z_faces[g->N[2]] - d->z_faces[0];
   }
+  // dz^f: regular -> dz; stretched -> differences of the centres, the halo centres built from faces extended by the boundary
+  // cells' widths (grid_generation.jl:28-75)
+  g->h_dzf.assign(g->N[2] + 1, dz);
+  if (!g->z_regular) {
+    const int n = g->N[2];
+    const double* F = d->z_faces;
+    const double cb = ((F[0] - (F[1] - F[0])) + F[0]) / 2, ct = ((F[n] + (F[n] - F[n - 1])) + F[n]) / 2;
+    auto C = [&](int k) { return k < 1 ? cb : k > n ? ct : g->nodeC[2][k - 1]; };          // reference index k
+    for (int k = 1; k <= n + 1; ++k) g->h_dzf[k - 1] = C(k) - C(k - 1);
+  }
   const int ny = g->N[1] + 2 * g->H[1] + 1;
   g->h_dxfc.assign(ny, 0); g->h_dxcf.assign(ny, 0); g->h_dyfc.assign(ny, 0); g->h_dycf.assign(ny, 0); g->h_azcc.assign(ny, 0);
   if (g->kind == HG_RECT) {
@@ -500,6 +780,7 @@ int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* d, ocn_hgrid** out) {
   if (!rc) rc = upload(ctx, g->h_dycf, &g->dycf);
   if (!rc) rc = upload(ctx, g->h_azcc, &g->azcc);
   if (!rc) rc = upload(ctx, g->h_dzc, &g->dzc);
+  if (!rc) rc = upload(ctx, g->h_dzf, &g->dzf);
   if (rc) { ocn_hgrid_destroy(g); return rc; }
   *out = g;
   return OCN_OK;
@@ -509,12 +790,12 @@ static void hgrid_release(ocn_hgrid* g);
 void ocn_hgrid_destroy(ocn_hgrid* g) { hgrid_release(g); }
 static void hgrid_release(ocn_hgrid* g) {
   if (!g || --g->refs > 0) return;
-  hipFree(g->dxfc); hipFree(g->dxcf); hipFree(g->dyfc); hipFree(g->dycf); hipFree(g->azcc); hipFree(g->dzc);
+  hipFree(g->dxfc); hipFree(g->dxcf); hipFree(g->dyfc); hipFree(g->dycf); hipFree(g->azcc); hipFree(g->dzc); hipFree(g->dzf);
   delete g;
 }
 
 /* which: 0 dx^fc, 1 dx^cf, 2 dy^fc, 3 dy^cf, 4 Az^cc (rows j = 1 - Hy ...), 5 dz^c (levels 1..Nz),
- * 6 / 7 x nodes Face / Center, 8 / 9 y nodes Face / Center (incl. halos); returns the number of entries, copies min(n, entries) */
+ * 6 / 7 x nodes Face / Center, 8 / 9 y nodes Face / Center (incl. halos), 10 dz^f (faces 1..Nz+1); returns the number of entries, copies min(n, entries) */
 int ocn_hgrid_metric(const ocn_hgrid* g, int which, double* host, int n) {
   if (!g || !host || n < 0) return OCN_EINVAL;
   const std::vector<double>* v = nullptr;
@@ -529,6 +810,7 @@ int ocn_hgrid_metric(const ocn_hgrid* g, int which, double* host, int n) {
     case 7: v = &g->nodeC[0]; break;
     case 8: v = &g->nodeF[1]; break;
     case 9: v = &g->nodeC[1]; break;
+    case 10: v = &g->h_dzf; break;
     default: return OCN_EINVAL;
   }
   const int m = (int)v->size() < n ? (int)v->size() : n;
@@ -538,8 +820,9 @@ int ocn_hgrid_metric(const ocn_hgrid* g, int which, double* host, int n) {
 
 int ocn_hfield_create(ocn_hgrid* g, int locx, int locy, int locz, ocn_hfield** out) {
   if (!g || !out) return OCN_EINVAL;
-  if ((locx != OCN_CENTER && locx != OCN_FACE) || (locy != OCN_CENTER && locy != OCN_FACE) || (locz != OCN_CENTER && locz != OCN_NOTHING)) {
-    ocn_set_error(g->ctx, "ocn_hfield_create: locations must be Center / Face in x and y, Center or Nothing in z");
+  if ((locx != OCN_CENTER && locx != OCN_FACE) || (locy != OCN_CENTER && locy != OCN_FACE) ||
+      (locz != OCN_CENTER && locz != OCN_FACE && locz != OCN_NOTHING)) {
+    ocn_set_error(g->ctx, "ocn_hfield_create: locations must be Center / Face in x and y, Center, Face or Nothing in z");
     return OCN_EINVAL;
   }
   return hfield_new(g, locx, locy, locz, out);
@@ -765,12 +1048,8 @@ int ocn_sefs_corrector(ocn_sefs* s, ocn_hfield* u, ocn_hfield* v) {
   if (!s || !u || !v) return OCN_EINVAL;
   int rc = ocn_sefs_barotropic_mode(s, u, v, 0);
   if (rc) return rc;
-  const ocn_hgrid* g = s->g;
-  dim3 blk(64, 4, 1), gr((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, g->N[2]);
-  ocn_launch(k_se_correct, gr, blk, g->ctx->stream, u->d, v->d, (const double*)s->U->d, (const double*)s->V->d, (const double*)s->Ubar->d,
-             (const double*)s->Vbar->d, (const double*)s->Hfc->d, (const double*)s->Hcf->d, g->N[0], g->N[1], g->N[2], g->H[0], g->H[1], g->H[2],
-             (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)s->U->T[0], (long)s->V->T[0]);
-  return api_done(g->ctx, OCN_OK);
+  sefs_correct_launch(s, u, v);
+  return api_done(s->g->ctx, OCN_OK);
 }
 
 int ocn_sefs_step(ocn_sefs* s, const ocn_hfield* Gnu, const ocn_hfield* Gnv, const ocn_hfield* Gmu, const ocn_hfield* Gmv, double dt, double chi) {
@@ -779,18 +1058,201 @@ int ocn_sefs_step(ocn_sefs* s, const ocn_hfield* Gnu, const ocn_hfield* Gnv, con
       Gnu->T[1] != s->GU->T[1] || Gnv->T[0] != s->GV->T[0] || Gnv->T[1] != s->GV->T[1])
     return OCN_EINVAL;
   ocn_ctx* ctx = s->g->ctx;
-  const double dtau = 2 * dt / s->substeps;                        // "we evolve for two times the dt" (:137)
   int rc = ocn_sefs_set_average_to_zero(s);
   if (rc) return rc;
   // barotropic_mode!(G^U, G^V, grid, Gu, Gv) with Gu = (1.5 + chi) G^n - (0.5 + chi) G^- formed inside the sum
   vsum(s, s->GU, Gnu, Gmu, 1.5 + chi, 0.5 + chi);
   vsum(s, s->GV, Gnv, Gmv, 1.5 + chi, 0.5 + chi);
-  hfield_fill(s->GU);
-  hfield_fill(s->GV);
-  if ((rc = ocn_sefs_substeps(s, dtau, 1, s->substeps, 2))) return rc;
-  // set!(eta, etabar) copies the parent array (Fields/set!.jl:41-44); then fill_halo_regions!(eta)
-  ocn_launch(k_se_copy, dim3((unsigned)((s->eta->n + 255) / 256), 1, 1), dim3(256, 1, 1), ctx->stream, s->eta->d, (const double*)s->etabar->d, s->eta->n);
-  hfield_fill(s->eta);
+  return api_done(ctx, sefs_step_tail(s, dt));
+}
+
+
+/* ---- second slice: the hydrostatic AB2 step around the tendencies ------------------------------------------------------------ */
+int ocn_hfield_ab2_step(ocn_hfield* f, const ocn_hfield* Gn, const ocn_hfield* Gm, double dt, double chi) {
+  if (!f || !Gn || !Gm) return OCN_EINVAL;
+  if (f->loc[2] != OCN_CENTER || !same_shape(f, Gn) || !same_shape(f, Gm)) {
+    ocn_set_error(f->g->ctx, "ocn_hfield_ab2_step: the field and its two tendencies must be 3-D fields of one location on one grid");
+    return OCN_EINVAL;
+  }
+  hy_ab2_launch(f, Gn, const_cast<ocn_hfield*>(Gm), dt, chi, false);
+  return api_done(f->g->ctx, OCN_OK);
+}
+
+int ocn_hfield_store_tendency(ocn_hfield* Gm, const ocn_hfield* Gn) {
+  if (!Gm || !Gn || !same_shape(Gm, Gn) || Gm->loc[2] != OCN_CENTER) return OCN_EINVAL;
+  hy_store_launch(Gm, Gn);
+  return api_done(Gm->g->ctx, OCN_OK);
+}
+
+int ocn_hydro_compute_w(const ocn_hfield* u, const ocn_hfield* v, ocn_hfield* w) {
+  if (!u || !v || !w) return OCN_EINVAL;
+  const ocn_hgrid* g = w->g;
+  if (!is_loc(u, g, OCN_FACE, OCN_CENTER, OCN_CENTER) || !is_loc(v, g, OCN_CENTER, OCN_FACE, OCN_CENTER) || !is_loc(w, g, OCN_CENTER, OCN_CENTER, OCN_FACE)) {
+    ocn_set_error(g->ctx, "ocn_hydro_compute_w: u, v, w must be (Face, Center, Center), (Center, Face, Center), (Center, Center, Face) fields of one grid");
+    return OCN_EINVAL;
+  }
+  if (g->H[0] < 1 || g->H[1] < 1) {
+    ocn_set_error(g->ctx, "ocn_hydro_compute_w: needs one halo cell in x and y");
+    return OCN_EINVAL;
+  }
+  hy_w_launch(u, v, w);
+  return api_done(g->ctx, OCN_OK);
+}
+
+static int hy_check_buoyancy(const ocn_hgrid* g, int kind, const ocn_hfield* T, const ocn_hfield* S) {
+  if (kind < 0 || kind > 2 || (kind >= 1 && !is_loc(T, g, OCN_CENTER, OCN_CENTER, OCN_CENTER)) || (kind == 2 && !is_loc(S, g, OCN_CENTER, OCN_CENTER, OCN_CENTER))) {
+    ocn_set_error(g->ctx, "buoyancy: kind 0 (none), 1 (BuoyancyTracer: T = b) or 2 (linear equation of state: T and S), on (Center, Center, Center) fields");
+    return OCN_EINVAL;
+  }
+  if (g->H[2] < 1) {
+    ocn_set_error(g->ctx, "the hydrostatic pressure integral reads one halo level in z");
+    return OCN_EINVAL;
+  }
+  return OCN_OK;
+}
+
+int ocn_hydro_pressure(ocn_hfield* pHY, int kind, double g, double alpha, double beta, const ocn_hfield* T, const ocn_hfield* S) {
+  if (!pHY) return OCN_EINVAL;
+  const ocn_hgrid* hg = pHY->g;
+  if (!is_loc(pHY, hg, OCN_CENTER, OCN_CENTER, OCN_CENTER)) return OCN_EINVAL;
+  if (int rc = hy_check_buoyancy(hg, kind, T, S)) return rc;
+  HyBuoy q{kind, g, alpha, beta};
+  hy_pressure_launch(pHY, q, kind >= 1 ? T : nullptr, kind == 2 ? S : nullptr);
+  return api_done(hg->ctx, OCN_OK);
+}
+
+int ocn_hydro_create(const ocn_hydro_desc* d, ocn_hydro** out) {
+  if (!d || !out || !d->free_surface || !d->u || !d->v || !d->w || !d->pHY || d->ntracers < 0 || (d->ntracers > 0 && !d->tracers) || !d->Gn || !d->Gm)
+    return OCN_EINVAL;
+  ocn_hgrid* g = d->free_surface->g;
+  ocn_ctx* ctx = g->ctx;
+  if (!is_loc(d->u, g, OCN_FACE, OCN_CENTER, OCN_CENTER) || !is_loc(d->v, g, OCN_CENTER, OCN_FACE, OCN_CENTER) ||
+      !is_loc(d->w, g, OCN_CENTER, OCN_CENTER, OCN_FACE) || !is_loc(d->pHY, g, OCN_CENTER, OCN_CENTER, OCN_CENTER)) {
+    ocn_set_error(ctx, "ocn_hydro_create: u, v, w, pHY must sit at their staggered locations on the free surface's grid");
+    return OCN_EINVAL;
+  }
+  for (int q = 0; q < d->ntracers; ++q)
+    if (!is_loc(d->tracers[q], g, OCN_CENTER, OCN_CENTER, OCN_CENTER)) {
+      ocn_set_error(ctx, "ocn_hydro_create: tracer %d is not a (Center, Center, Center) field of the grid", q);
+      return OCN_EINVAL;
+    }
+  for (int q = 0; q < 2 + d->ntracers; ++q) {
+    const ocn_hfield* f = q == 0 ? d->u : q == 1 ? d->v : d->tracers[q - 2];
+    if (!d->Gn[q] || !d->Gm[q] || !same_shape(f, d->Gn[q]) || !same_shape(f, d->Gm[q]) || d->Gn[q] == d->Gm[q]) {
+      ocn_set_error(ctx, "ocn_hydro_create: tendency %d does not match its field", q);
+      return OCN_EINVAL;
+    }
+  }
+  const int kind = d->buoyancy_kind;
+  if ((kind >= 1 && (d->T_index < 0 || d->T_index >= d->ntracers)) || (kind == 2 && (d->S_index < 0 || d->S_index >= d->ntracers || d->S_index == d->T_index))) {
+    ocn_set_error(ctx, "ocn_hydro_create: buoyancy tracer indices out of range");
+    return OCN_EINVAL;
+  }
+  if (int rc = hy_check_buoyancy(g, kind, kind >= 1 ? d->tracers[d->T_index] : nullptr, kind == 2 ? d->tracers[d->S_index] : nullptr)) return rc;
+  if (g->H[0] < 1 || g->H[1] < 1) {
+    ocn_set_error(ctx, "ocn_hydro_create: needs one halo cell in x and y");
+    return OCN_EINVAL;
+  }
+  ocn_hydro* h = new ocn_hydro;
+  h->fs = d->free_surface;
+  h->u = d->u; h->v = d->v; h->w = d->w; h->pHY = d->pHY;
+  h->c.assign(d->tracers, d->tracers + d->ntracers);
+  h->gn.assign(d->Gn, d->Gn + 2 + d->ntracers);
+  h->gm.assign(d->Gm, d->Gm + 2 + d->ntracers);
+  h->buoy = HyBuoy{kind, d->gravitational_acceleration, d->thermal_expansion, d->haline_contraction};
+  h->bT = kind >= 1 ? d->T_index : -1;
+  h->bS = kind == 2 ? d->S_index : -1;
+  if (hipMalloc((void**)&h->Un, h->fs->U->n * sizeof(double)) != hipSuccess || hipMalloc((void**)&h->Vn, h->fs->V->n * sizeof(double)) != hipSuccess) {
+    hipFree(h->Un);
+    delete h;
+    return OCN_ENOMEM;
+  }
+  OCN_ASYNC(hipMemsetAsync(h->Un, 0, h->fs->U->n * sizeof(double), ctx->stream));
+  OCN_ASYNC(hipMemsetAsync(h->Vn, 0, h->fs->V->n * sizeof(double), ctx->stream));
+  g->refs += 1;
+  *out = h;
+  return OCN_OK;
+}
+
+void ocn_hydro_destroy(ocn_hydro* h) {
+  if (!h) return;
+  ocn_hgrid* g = h->fs->g;
+  hipStreamSynchronize(g->ctx->stream);
+  hipFree(h->Un);
+  hipFree(h->Vn);
+  delete h;
+  hgrid_release(g);
+}
+
+int ocn_hydro_update_state(ocn_hydro* h) {
+  if (!h) return OCN_EINVAL;
+  hydro_update_state(h, false);
+  return api_done(h->fs->g->ctx, OCN_OK);
+}
+
+/* ab2_step!(model, dt, chi) as the reference issues it: barotropic mode of the velocities, AB2 steps of u, v and the tracers, then
+ * the split-explicit free-surface step */
+int ocn_hydro_ab2_step(ocn_hydro* h, double dt, double chi) {
+  if (!h) return OCN_EINVAL;
+  int rc = ocn_sefs_barotropic_mode(h->fs, h->u, h->v, 0);
+  if (rc) return rc;
+  hy_ab2_launch(h->u, h->gn[0], h->gm[0], dt, chi, false);
+  hy_ab2_launch(h->v, h->gn[1], h->gm[1], dt, chi, false);
+  for (size_t q = 0; q < h->c.size(); ++q) hy_ab2_launch(h->c[q], h->gn[2 + q], h->gm[2 + q], dt, chi, false);
+  return ocn_sefs_step(h->fs, h->gn[0], h->gn[1], h->gm[0], h->gm[1], dt, chi);
+}
+
+/* time_step! from ab2_step! on (quasi_adams_bashforth_2.jl:94-100): the step, the barotropic correction of the velocities,
+ * G^- <- G^n, update_state!.  fused = 0: kernel by kernel as the reference; 1: the passes over the 3-D fields merged
+ * (k_hy_momentum, k_hy_tracers), which leaves the same bits in every field, halos included. */
+int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fused) {
+  if (!h) return OCN_EINVAL;
+  ocn_sefs* s = h->fs;
+  ocn_hgrid* g = s->g;
+  ocn_ctx* ctx = g->ctx;
+  int rc;
+  if (!fused) {
+    if ((rc = ocn_hydro_ab2_step(h, dt, chi))) return rc;
+    if ((rc = ocn_sefs_corrector(s, h->u, h->v))) return rc;
+    for (size_t q = 0; q < h->gn.size(); ++q) hy_store_launch(h->gm[q], h->gn[q]);
+    hydro_update_state(h, false);
+    return api_done(ctx, OCN_OK);
+  }
+  const double cn = 1.5 + chi, cm = 0.5 + chi;
+  dim3 blk(64, 4, 1);
+  for (int q = 0; q < 2; ++q) {
+    ocn_hfield *f = q ? h->v : h->u, *U = q ? s->V : s->U, *GU = q ? s->GV : s->GU;
+    ocn_launch(k_hy_momentum, dim3((U->S[0] + 63) / 64, (U->S[1] + 3) / 4, 1), blk, ctx->stream, f->d, (const double*)h->gn[q]->d, h->gm[q]->d, U->d, GU->d,
+               q ? h->Vn : h->Un, dt, cn, cm, (const double*)g->dzc, U->S[0], U->S[1], g->N[0], g->N[1], g->N[2], g->H[0], g->H[1], g->H[2], (long)f->T[0],
+               (long)f->T[0] * f->T[1], (long)U->T[0]);
+  }
+  hfield_fill(s->U);
+  hfield_fill(s->V);
+  bool pressure_done = false;
+  for (size_t q = 0; q < h->c.size(); ++q) {
+    if ((int)q == h->bS && h->bT >= 0) continue;                   // stepped together with T
+    if ((int)q == h->bT) {
+      dim3 b, gr;
+      hy_cols(g, b, gr);
+      ocn_hfield *T = h->c[q], *S = h->bS >= 0 ? h->c[h->bS] : nullptr;
+      ocn_launch(k_hy_tracers, gr, b, ctx->stream, hy_grid(g), h->buoy, T->d, (const double*)h->gn[2 + q]->d, h->gm[2 + q]->d, S ? S->d : (double*)nullptr,
+                 S ? (const double*)h->gn[2 + h->bS]->d : (const double*)nullptr, S ? h->gm[2 + h->bS]->d : (double*)nullptr, h->pHY->d, dt, cn, cm,
+                 (long)T->T[0], (long)T->T[0] * T->T[1]);
+      pressure_done = true;
+    } else {
+      hy_ab2_launch(h->c[q], h->gn[2 + q], h->gm[2 + q], dt, chi, true);
+    }
+  }
+  // the free surface: G^U, G^V are in place
+  for (ocn_hfield* f : {s->etabar, s->Ubar, s->Vbar}) OCN_ASYNC(hipMemsetAsync(f->d, 0, f->n * sizeof(double), ctx->stream));
+  if ((rc = sefs_step_tail(s, dt))) return api_done(ctx, rc);
+  // corrector: the barotropic mode of the stepped velocities was summed in the first pass
+  se_copy(ctx, s->U->d, h->Un, s->U->n);
+  se_copy(ctx, s->V->d, h->Vn, s->V->n);
+  hfield_fill(s->U);
+  hfield_fill(s->V);
+  sefs_correct_launch(s, h->u, h->v);
+  hydro_update_state(h, pressure_done);
   return api_done(ctx, OCN_OK);
 }
 

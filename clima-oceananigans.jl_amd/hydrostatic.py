@@ -1,8 +1,10 @@
-"""Host-side mirror of the HydrostaticFreeSurfaceModel pieces the library carries so far (BASELINE config 5, first slice):
+"""Host-side mirror of the HydrostaticFreeSurfaceModel pieces the library carries so far (BASELINE config 5, first two slices):
 ``LatitudeLongitudeGrid`` / ``RectilinearGrid`` as the free surface sees them, ``Field{LX, LY, LZ}`` on them, and
 ``SplitExplicitFreeSurface`` with the reference's verbs -- ``split_explicit_free_surface_substep!``, ``barotropic_mode!``,
 ``set_average_to_zero!``, ``barotropic_split_explicit_corrector!``, ``split_explicit_free_surface_step!``
 (Models/HydrostaticFreeSurfaceModels/split_explicit_free_surface.jl, split_explicit_free_surface_kernels.jl).
+Second slice: the AB2 time step around the tendency evaluation -- ``ab2_step!``, the barotropic correction, ``store_tendencies!``
+and ``update_state!`` (``compute_w_from_continuity!``, ``update_hydrostatic_pressure!``, halo fills) on a ``HydrostaticState``.
 Everything numerical happens in libocnhip.so (csrc/splitexplicit.hip); this file only marshals.
 """
 import ctypes as C
@@ -60,11 +62,15 @@ class _HGrid:
         n = N + 1 if (loc == Face and self.topology[d] == Bounded) else N
         return a[H:H + n]
 
-    def znodes(self):
+    def znodes(self, loc=Center):
         if self._zf is not None:
-            return 0.5 * (self._zf[1:] + self._zf[:-1])
+            return self._zf.copy() if loc == Face else 0.5 * (self._zf[1:] + self._zf[:-1])
         dz = self.Δzᵃᵃᶜ
+        if loc == Face:
+            return self._z0 + np.concatenate([[0.0], np.cumsum(dz)])
         return self._z0 + np.cumsum(dz) - dz / 2
+
+    Δzᵃᵃᶠ = property(lambda s: s.metric(10))
 
     def __del__(self):
         try:
@@ -102,7 +108,7 @@ class LatitudeLongitudeGrid(_HGrid):
 
 
 class HField:
-    """Field{LX, LY, LZ}(grid), LZ = Center or Nothing: a dense parent array on the device"""
+    """Field{LX, LY, LZ}(grid), LZ = Center, Face or Nothing: a dense parent array on the device"""
 
     def __init__(self, grid, loc, handle=None):
         self.grid, self.loc, self.lib = grid, tuple(loc), grid.lib
@@ -144,7 +150,7 @@ class HField:
             if self.loc[2] in (Nothing, None):
                 it[...] = value(X, Y) + 0 * (X + Y)
             else:
-                Z = g.znodes().reshape(1, 1, -1)
+                Z = g.znodes(self.loc[2]).reshape(1, 1, -1)
                 it[...] = value(X, Y, Z) + 0 * (X + Y + Z)
         else:
             it[...] = np.asarray(value, dtype=np.float64).reshape(it.shape) if np.ndim(value) else value
@@ -237,3 +243,96 @@ class SplitExplicitFreeSurface:
                 self.h = C.c_void_p()
         except Exception:
             pass
+
+
+# ---- second slice: the AB2 step of the hydrostatic model around its tendencies ----------------------------------------------------
+def Field3(grid, lx, ly, lz=Center):
+    return HField(grid, (lx, ly, lz))
+
+
+def fill_halo_regions(f):
+    f.fill_halo_regions()
+
+
+def ab2_step_field(f, Gn, Gm, dt, chi):
+    """ab2_step_field! (TimeSteppers/quasi_adams_bashforth_2.jl:158-166)"""
+    check(f.lib.ocn_hfield_ab2_step(f.h, Gn.h, Gm.h, float(dt), float(chi)), f.grid.ctx.h)
+
+
+def compute_w_from_continuity(u, v, w):
+    """compute_w_from_continuity! (compute_w_from_continuity.jl:31-36)"""
+    check(w.lib.ocn_hydro_compute_w(u.h, v.h, w.h), w.grid.ctx.h)
+
+
+def _buoyancy_args(buoyancy, tracers):
+    """None | ("b", name) | ("TS", g, alpha, beta, Tname, Sname) -> (kind, g, alpha, beta, T field, S field)"""
+    if buoyancy is None:
+        return 0, 0.0, 0.0, 0.0, None, None
+    if buoyancy[0] == "b":
+        return 1, 0.0, 0.0, 0.0, tracers[buoyancy[1]], None
+    if buoyancy[0] == "TS":
+        _, g, al, be, Tn, Sn = buoyancy
+        return 2, float(g), float(al), float(be), tracers[Tn], tracers[Sn]
+    raise ValueError(f"unsupported buoyancy {buoyancy!r}: None, ('b', name) or ('TS', g, alpha, beta, Tname, Sname)")
+
+
+def update_hydrostatic_pressure(pHY, buoyancy, tracers):
+    """update_hydrostatic_pressure! (Models/NonhydrostaticModels/update_hydrostatic_pressure.jl:10-18)"""
+    kind, g, al, be, T, S = _buoyancy_args(buoyancy, tracers)
+    check(pHY.lib.ocn_hydro_pressure(pHY.h, kind, g, al, be, T.h if T else None, S.h if S else None), pHY.grid.ctx.h)
+
+
+class HydrostaticState:
+    """the fields of a HydrostaticFreeSurfaceModel{SplitExplicitFreeSurface} the step after the tendencies touches: u, v, w, the
+    tracers, G^n and G^- of the prognostic fields, pHY' and the free surface (hydrostatic_free_surface_model.jl:92-211)"""
+
+    def __init__(self, grid, tracers=("T", "S"), buoyancy=None, substeps=20, gravitational_acceleration=g_Earth, free_surface=None):
+        self.grid, self.lib = grid, grid.lib
+        self.u, self.v, self.w = Field3(grid, Face, Center), Field3(grid, Center, Face), Field3(grid, Center, Center, Face)
+        self.tracers = {n: Field3(grid, Center, Center) for n in tracers}
+        names = ["u", "v"] + list(tracers)
+        loc = {"u": (Face, Center), "v": (Center, Face)}
+        self.Gn = {n: Field3(grid, *loc.get(n, (Center, Center))) for n in names}
+        self.Gm = {n: Field3(grid, *loc.get(n, (Center, Center))) for n in names}
+        self.pHY = Field3(grid, Center, Center)
+        self.buoyancy = buoyancy
+        self.free_surface = free_surface or SplitExplicitFreeSurface(grid, gravitational_acceleration, substeps)
+        d = L.HydroDesc()
+        d.free_surface = self.free_surface.h
+        d.u, d.v, d.w, d.pHY = self.u.h, self.v.h, self.w.h, self.pHY.h
+        tl = list(self.tracers.values())
+        d.ntracers = len(tl)
+        self._arr = [(C.c_void_p * max(1, len(tl)))(*[t.h for t in tl]), (C.c_void_p * len(names))(*[self.Gn[n].h for n in names]),
+                     (C.c_void_p * len(names))(*[self.Gm[n].h for n in names])]
+        d.tracers, d.Gn, d.Gm = self._arr
+        kind, g, al, be, T, S = _buoyancy_args(buoyancy, self.tracers)
+        d.buoyancy_kind = kind
+        d.T_index = tl.index(T) if T is not None else -1
+        d.S_index = tl.index(S) if S is not None else -1
+        d.gravitational_acceleration, d.thermal_expansion, d.haline_contraction = g, al, be
+        self.h = C.c_void_p()
+        check(self.lib.ocn_hydro_create(C.byref(d), C.byref(self.h)), grid.ctx.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.ocn_hydro_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def update_state(st):
+    """update_state!(model) (update_hydrostatic_free_surface_model_state.jl:21-48)"""
+    check(st.lib.ocn_hydro_update_state(st.h), st.grid.ctx.h)
+
+
+def ab2_step(st, dt, chi):
+    """ab2_step!(model, dt, chi) (hydrostatic_free_surface_ab2_step.jl:15-48)"""
+    check(st.lib.ocn_hydro_ab2_step(st.h, float(dt), float(chi)), st.grid.ctx.h)
+
+
+def time_step_after_tendencies(st, dt, chi, fused=True):
+    """time_step!(model, dt) from `ab2_step!` on (quasi_adams_bashforth_2.jl:94-100); fused=False issues the reference's kernels
+    one by one, fused=True the merged passes (same bits)"""
+    check(st.lib.ocn_hydro_step_after_tendencies(st.h, float(dt), float(chi), int(bool(fused))), st.grid.ctx.h)

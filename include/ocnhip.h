@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OCN_ABI_VERSION 4
+#define OCN_ABI_VERSION 5
 
 /* error codes */
 enum {
@@ -251,7 +251,7 @@ int ocn_comm_rank(const ocn_ctx* ctx, int* rank, int* nranks);
 enum { OCN_NOTHING = 2 };   /* third field location: reduced along that direction (Field{LX, LY, Nothing}, Fields/field.jl:441-449) */
 enum { OCN_HGRID_RECTILINEAR = 0, OCN_HGRID_LATLON = 1 };
 typedef struct ocn_hgrid ocn_hgrid;     /* the grid as the free surface sees it: sizes, halos, topology, per-row metrics, level thicknesses */
-typedef struct ocn_hfield ocn_hfield;   /* a field on it: (Face|Center, Face|Center, Center|Nothing), dense parent array incl. halos          */
+typedef struct ocn_hfield ocn_hfield;   /* a field on it: (Face|Center, Face|Center, Center|Face|Nothing), dense parent array incl. halos     */
 typedef struct ocn_sefs ocn_sefs;       /* SplitExplicitFreeSurface(grid; gravitational_acceleration, settings)                            */
 
 /* RectilinearGrid(size, x, y, z, halo, topology) with regular x, y (metres), or
@@ -278,7 +278,9 @@ int ocn_hfield_shape(const ocn_hfield* f, int32_t total[3], int32_t interior[3],
 void* ocn_hfield_ptr(ocn_hfield* f);                       /* device pointer of the parent array (Julia: unsafe_wrap)     */
 int ocn_hfield_upload(ocn_hfield* f, const double* host_parent);
 int ocn_hfield_download(const ocn_hfield* f, double* host_parent);
-int ocn_hfield_fill_halos(ocn_hfield* f);                  /* fill_halo_regions!(field) in x and y, default conditions      */
+/* fill_halo_regions!(field) with the default conditions: z (no-flux for Center, faces 1 and Nz + 1 zeroed for a ZFaceField:
+ * fill_halo_regions_open.jl:34-39), then x and y (Bounded directions before Periodic ones, fill_halo_regions.jl:76-99) */
+int ocn_hfield_fill_halos(ocn_hfield* f);
 /* SplitExplicitFreeSurface(grid; gravitational_acceleration, settings = SplitExplicitSettings(substeps))
  * (split_explicit_free_surface.jl:46-60; H^fc, H^cf, H^cc = sum of dz :103-110; uniform weights :137-154) */
 int ocn_sefs_create(ocn_hgrid* g, double gravitational_acceleration, int substeps, ocn_sefs** out);
@@ -304,6 +306,47 @@ int ocn_sefs_corrector(ocn_sefs* s, ocn_hfield* u, ocn_hfield* v);
  * η ← η̅, halos of η filled */
 int ocn_sefs_step(ocn_sefs* s, const ocn_hfield* Gn_u, const ocn_hfield* Gn_v, const ocn_hfield* Gm_u, const ocn_hfield* Gm_v,
                   double dt, double chi);
+
+/* ---- HydrostaticFreeSurfaceModel: the AB2 time step around the tendency evaluation (config 5, second slice) --------------
+ * time_step!(model::HydrostaticFreeSurfaceModel, dt) (TimeSteppers/quasi_adams_bashforth_2.jl:70-104) is
+ *   calculate_tendencies!  ->  ab2_step!  ->  pressure_correct_velocities!  ->  store_tendencies!  ->  update_state!
+ * The entry points below are everything after calculate_tendencies!; the caller (until the tendency kernels are in the
+ * library too) fills G^n.  No closure / implicit vertical solve, no immersed boundary, flat bottom. */
+typedef struct ocn_hydro ocn_hydro;
+/* ab2_step_field! (quasi_adams_bashforth_2.jl:158-166): f += dt ((1.5 + chi) G^n - (0.5 + chi) G^-) over the grid's cells */
+int ocn_hfield_ab2_step(ocn_hfield* f, const ocn_hfield* Gn, const ocn_hfield* Gm, double dt, double chi);
+/* store_field_tendencies! (TimeSteppers/store_tendencies.jl:8-11): G^-[i, j, k] = G^n[i, j, k] over the grid's cells */
+int ocn_hfield_store_tendency(ocn_hfield* Gm, const ocn_hfield* Gn);
+/* compute_w_from_continuity! (compute_w_from_continuity.jl:31-36): w[1] = 0, w[k] = w[k-1] - dz^c[k-1] div_xy(u, v)[k-1];
+ * u, v with filled x / y halos */
+int ocn_hydro_compute_w(const ocn_hfield* u, const ocn_hfield* v, ocn_hfield* w);
+/* update_hydrostatic_pressure! (Models/NonhydrostaticModels/update_hydrostatic_pressure.jl:10-18) with the buoyancy
+ * kind 0: none, 1: BuoyancyTracer (T is b), 2: SeawaterBuoyancy(gravitational_acceleration, LinearEquationOfState(alpha, beta))
+ * (BuoyancyModels/linear_equation_of_state.jl:69-71); T, S with filled z halos */
+int ocn_hydro_pressure(ocn_hfield* pHY, int buoyancy_kind, double gravitational_acceleration, double thermal_expansion,
+                       double haline_contraction, const ocn_hfield* T, const ocn_hfield* S);
+typedef struct ocn_hydro_desc {
+  ocn_sefs* free_surface;
+  ocn_hfield *u, *v, *w, *pHY;                /* (F,C,C), (C,F,C), (C,C,F), (C,C,C)                                   */
+  int32_t ntracers;
+  ocn_hfield** tracers;                       /* ntracers (C,C,C) fields                                              */
+  ocn_hfield **Gn, **Gm;                      /* 2 + ntracers each: u, v, then the tracers in order                   */
+  int32_t buoyancy_kind, T_index, S_index;    /* as ocn_hydro_pressure; indices into `tracers`                        */
+  double gravitational_acceleration, thermal_expansion, haline_contraction;
+} ocn_hydro_desc;
+/* binds the model's fields (borrowed: they must outlive the handle) */
+int ocn_hydro_create(const ocn_hydro_desc* desc, ocn_hydro** out);
+void ocn_hydro_destroy(ocn_hydro* h);
+/* update_state!(model) (update_hydrostatic_free_surface_model_state.jl:21-48): halo fills of u, v, eta and the tracers, w from
+ * continuity, the hydrostatic pressure, halo fills of w and pHY' */
+int ocn_hydro_update_state(ocn_hydro* h);
+/* ab2_step!(model, dt, chi) (hydrostatic_free_surface_ab2_step.jl:15-48): barotropic mode of u, v; AB2 steps of u, v, tracers;
+ * ocn_sefs_step */
+int ocn_hydro_ab2_step(ocn_hydro* h, double dt, double chi);
+/* ab2_step!, barotropic correction of u and v (barotropic_pressure_correction.jl:41-47), G^- <- G^n, update_state!.
+ * fused = 0 issues the reference's kernels one by one; fused = 1 merges the passes over the 3-D fields (about 28 instead of
+ * 40 field sweeps) and leaves the same bits in every field, halos included. */
+int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fused);
 
 /* ---- measurement helpers (bench.py) -------------------------------------------------------------- */
 /* average device time [ms] of the `n` most recent launches of the named phase, measured with HIP

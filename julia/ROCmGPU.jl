@@ -63,7 +63,7 @@ function ocn_grid(arch::ROCmGPU, grid::RectilinearGrid)
     return h[]
 end
 
-# `ocn_model_desc` (include/ocnhip.h; OCN_ABI_VERSION 4), field by field.  isbits, so it crosses ccall by reference.
+# `ocn_model_desc` (include/ocnhip.h; OCN_ABI_VERSION 5), field by field.  isbits, so it crosses ccall by reference.
 const MAXTR = 8
 struct BC; kind::Int32; value::Float64; array::Ptr{Float64}; end                       # ocn_bc
 struct ModelDesc
@@ -219,10 +219,10 @@ kernel_path(model::RM) = (buf = Vector{UInt8}(undef, 256);
 #       (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), fs.sefs, hfield(u), hfield(v)))
 #
 # Launch-bound models (config 1) are replayed from hipGraphs inside ocn_time_step; ocn_model_graph_replays(handle, n, active)
-# reports it.  The library reports OCN_ABI_VERSION through ocn_abi_version(): __init__ compares it with 4.
+# reports it.  The library reports OCN_ABI_VERSION through ocn_abi_version(): __init__ compares it with 5.
 function __init__()
     v = ccall((:ocn_abi_version, libocnhip), Cint, ())
-    v == 4 || error("libocnhip reports ABI version $v; this shim is written for 4")
+    v == 5 || error("libocnhip reports ABI version $v; this shim is written for 5")
 end
 
 end # module

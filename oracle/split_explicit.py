@@ -137,15 +137,16 @@ class ReducedField:
 
 
 class Field3:
-    """Field{LX, LY, Center}(grid) on one of the grids above (u, v and their tendencies)"""
+    """Field{LX, LY, LZ}(grid) on one of the grids above, LZ = Center (u, v, tracers, tendencies, pHY') or Face (w); z is Bounded"""
 
-    def __init__(self, grid, lx, ly):
-        self.grid, self.loc = grid, (lx, ly, Center)
-        self.data = np.zeros(grid.total(lx, ly) + (grid.Nz + 2 * grid.Hz,), order="F")
+    def __init__(self, grid, lx, ly, lz=Center):
+        self.grid, self.loc = grid, (lx, ly, lz)
+        self.data = np.zeros(grid.total(lx, ly) + (grid.Nz + 2 * grid.Hz + (1 if lz == Face else 0),), order="F")
 
     def size(self):
         g = self.grid
-        return tuple(n + 1 if (l == Face and t == Bounded) else n for n, l, t in zip((g.Nx, g.Ny), self.loc, g.topo)) + (g.Nz,)
+        s = tuple(n + 1 if (l == Face and t == Bounded) else n for n, l, t in zip((g.Nx, g.Ny), self.loc, g.topo))
+        return s + (g.Nz + 1 if self.loc[2] == Face else g.Nz,)
 
     def interior(self):
         g, s = self.grid, self.size()
@@ -175,8 +176,20 @@ class Field3:
 
 
 def fill_halo_regions(f):
-    """x and y fills of a reduced (or 3-D: every level, no z fill here) field: Bounded directions first, Periodic last"""
+    """fills of a reduced field (x, y) or a 3-D field (z, x, y) with the default conditions: Bounded directions first, over
+    the interior cells of the other directions; Periodic last, over the whole parent"""
     g = f.grid
+    if len(f.loc) == 3 and (g.Hz > 0 or f.loc[2] == Face):
+        # z (Bounded) over i = 1..Nx, j = 1..Ny: Center -> no-flux, Face -> the two boundary faces are zeroed (the default
+        # impenetrable condition of a ZFaceField, fill_halo_regions_open.jl:34-39)
+        q, Hz, Nz = f.data, g.Hz, g.Nz
+        I, J = slice(g.Hx, g.Hx + g.Nx), slice(g.Hy, g.Hy + g.Ny)
+        if f.loc[2] == Face:
+            q[I, J, Hz] = 0.0
+            q[I, J, Hz + Nz] = 0.0
+        else:
+            q[I, J, Hz - 1] = q[I, J, Hz]
+            q[I, J, Hz + Nz] = q[I, J, Hz + Nz - 1]
     order = sorted((0, 1), key=lambda d: g.topo[d] == Periodic)       # stable: x before y within a class (fill_halo_regions.jl:76-99)
     p = f.data
     for d in order:
@@ -190,6 +203,8 @@ def fill_halo_regions(f):
             idx[d] = i - 1 + H
             if not full:
                 idx[other] = slice(Ho, Ho + No)
+                if len(f.loc) == 3:                       # the `:yz` / `:xz` launch: levels 1..Nz of the grid only
+                    idx[2] = slice(g.Hz, g.Hz + g.Nz)
             return tuple(idx)
         if g.topo[d] == Periodic:
             for i in range(1, H + 1):                     # fill_halo_regions_periodic.jl:37-65, sequential, whole parent extent

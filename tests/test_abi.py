@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert not missing, missing
     L.ocn_abi_version.restype = ctypes.c_int
     import __graft_entry__ as ge
-    assert L.ocn_abi_version() == ge.load_package()._lib.ABI_VERSION == 4
+    assert L.ocn_abi_version() == ge.load_package()._lib.ABI_VERSION == 5
 
 
 def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
