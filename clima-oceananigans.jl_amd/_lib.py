@@ -163,6 +163,9 @@ def load():
         "ocn_hydro_update_state": (I, [P]),
         "ocn_hydro_ab2_step": (I, [P, D, D]),
         "ocn_hydro_step_after_tendencies": (I, [P, D, D, I]),
+        "ocn_hydro_set_physics": (I, [P, I, I, D, I]),
+        "ocn_hydro_calculate_tendencies": (I, [P]),
+        "ocn_hydro_time_step": (I, [P, D, I]),
         "ocn_profile_enable": (I, [P, I]),
         "ocn_profile_read": (I, [P, C.c_char_p, PD, C.POINTER(C.c_int64)]),
         "ocn_profile_reset": (I, [P]),

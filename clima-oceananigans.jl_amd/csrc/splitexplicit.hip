@@ -41,8 +41,9 @@ struct ocn_hgrid {
   bool z_regular;
   std::vector<double> nodeF[3], nodeC[3];          // incl. halos, entry [i - 1 + H] for reference index i
   std::vector<double> h_dxfc, h_dxcf, h_dyfc, h_dycf, h_azcc, h_dzc;   // per row j (entry [j - 1 + Hy]) / per level k (entry [k - 1])
+  std::vector<double> h_azff, h_phif;                                  // Az^ff per row; latitude of the rows of faces [degrees] (lat-lon only)
   std::vector<double> h_dzf;                                           // dz^f[k] = zC[k] - zC[k-1], k = 1..Nz+1 (entry [k - 1]); needs Hz >= 1
-  double *dxfc = nullptr, *dxcf = nullptr, *dyfc = nullptr, *dycf = nullptr, *azcc = nullptr, *dzc = nullptr, *dzf = nullptr;   // device copies
+  double *dxfc = nullptr, *dxcf = nullptr, *dyfc = nullptr, *dycf = nullptr, *azcc = nullptr, *dzc = nullptr, *dzf = nullptr, *azff = nullptr;   // device copies
 };
 
 struct ocn_hfield {
@@ -508,6 +509,116 @@ __global__ void k_hy_ab2_store(double* f, const double* gn, double* gm, double d
   gm[c] = n;
 }
 
+// ---- third slice: calculate_tendencies! (no closure, no forcing, no immersed boundary) ----------------------------------------
+//   hydrostatic_free_surface_tendency_kernel_functions.jl:24-125   G_u, G_v, G_c
+//   Advection/vector_invariant_advection.jl:25-80                  VectorInvariant (enstrophy- / energy-conserving)
+//   Operators/vorticity_operators.jl:2-5                           zeta_3 at (Face, Face, Center)
+//   Coriolis/hydrostatic_spherical_coriolis.jl:29-66, f_plane.jl:42-43
+//   Advection/tracer_advection_operators.jl:33-37, centered_advective_fluxes.jl:31-33   flux-form CenteredSecondOrder
+// One thread per cell; every operator keeps the reference's operand order, without contraction (see OCN_NO_CONTRACT).
+struct HyPhys {
+  int madv;          // 0 none, 1 VectorInvariant enstrophy-conserving, 2 energy-conserving
+  int cor;           // 0 none, 1 HydrostaticSphericalCoriolis enstrophy-conserving, 2 energy-conserving, 3 FPlane
+  int tadv;          // 0 none, 1 CenteredSecondOrder
+  double f0;
+  const double* frow;   // f at the rows of (Face, Face) points
+};
+struct HyMetric {
+  const double *dxfc, *dxcf, *dyfc, *dycf, *azcc, *azff, *dzc, *dzf;
+  int Nx, Ny, Nz, Hx, Hy, Hz;
+};
+
+__global__ void __launch_bounds__(256) k_hy_Guv(HyMetric g, HyPhys ph, const double* __restrict__ u, const double* __restrict__ v,
+                                                const double* __restrict__ w, const double* __restrict__ p, double* __restrict__ Gu,
+                                                double* __restrict__ Gv, long syu, long szu, long syv, long szv, long syc, long szc) {
+  OCN_NO_CONTRACT
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  const int r = j + g.Hy;
+  const long cu = (i + g.Hx) + (long)r * syu + (long)(k + g.Hz) * szu, cv = (i + g.Hx) + (long)r * syv + (long)(k + g.Hz) * szv;
+  const long cc = (i + g.Hx) + (long)r * syc + (long)(k + g.Hz) * szc;       // w and pHY' share the (Center, Center) row pitch
+  const long szw = szc;
+  auto U = [&](int di, int dj, int dk) { return u[cu + di + dj * syu + dk * szu]; };
+  auto V = [&](int di, int dj, int dk) { return v[cv + di + dj * syv + dk * szv]; };
+  auto W = [&](int di, int dj, int dk) { return w[cc + di + dj * syc + dk * szw]; };
+  auto zeta = [&](int di, int dj) {
+    const double circ = (g.dycf[r + dj] * V(di, dj, 0) - g.dycf[r + dj] * V(di - 1, dj, 0)) -
+                        (g.dxfc[r + dj] * U(di, dj, 0) - g.dxfc[r + dj - 1] * U(di, dj - 1, 0));
+    return circ / g.azff[r + dj];
+  };
+  auto sq = [](double x) { return x * x; };
+  auto Kh = [&](int di, int dj) {
+    return (0.5 * (sq(U(di, dj, 0)) + sq(U(di + 1, dj, 0))) + 0.5 * (sq(V(di, dj, 0)) + sq(V(di, dj + 1, 0)))) / 2;
+  };
+  auto Iy_dxv = [&](int di) { return 0.5 * (g.dxcf[r] * V(di, 0, 0) + g.dxcf[r + 1] * V(di, 1, 0)); };
+  auto Ix_dyu = [&](int dj) { return 0.5 * (g.dyfc[r + dj] * U(0, dj, 0) + g.dyfc[r + dj] * U(1, dj, 0)); };
+  auto Ix_dxv = [&](int dj) { return 0.5 * (g.dxcf[r + dj] * V(-1, dj, 0) + g.dxcf[r + dj] * V(0, dj, 0)); };
+  auto Iy_dyu = [&](int di) { return 0.5 * (g.dyfc[r - 1] * U(di, -1, 0) + g.dyfc[r] * U(di, 0, 0)); };
+  const double dxfc = g.dxfc[r], dycf = g.dycf[r];
+  double Au = 0.0, Av = 0.0;
+  if (ph.madv) {
+    double vvU, vvV;
+    if (ph.madv == 1) {
+      const double z00 = zeta(0, 0);
+      vvU = -(0.5 * (z00 + zeta(0, 1))) * (0.5 * (Iy_dxv(-1) + Iy_dxv(0))) / dxfc;
+      vvV = +(0.5 * (z00 + zeta(1, 0))) * (0.5 * (Ix_dyu(-1) + Ix_dyu(0))) / dycf;
+    } else {
+      const double z00 = zeta(0, 0);
+      vvU = -(0.5 * (z00 * Ix_dxv(0) + zeta(0, 1) * Ix_dxv(1))) / dxfc;
+      vvV = +(0.5 * (z00 * Iy_dyu(0) + zeta(1, 0) * Iy_dyu(1))) / dycf;
+    }
+    auto z2w = [&](int dk) {
+      return (0.5 * (g.azcc[r] * W(-1, 0, dk) + g.azcc[r] * W(0, 0, dk))) * ((U(0, 0, dk) - U(0, 0, dk - 1)) / g.dzf[k + dk]);
+    };
+    auto z1w = [&](int dk) {
+      return (0.5 * (g.azcc[r - 1] * W(0, -1, dk) + g.azcc[r] * W(0, 0, dk))) * ((V(0, 0, dk) - V(0, 0, dk - 1)) / g.dzf[k + dk]);
+    };
+    const double vaU = 0.5 * (z2w(0) + z2w(1)) / g.azcc[r];          // Az^fcc = Az^cc (regular x)
+    const double vaV = 0.5 * (z1w(0) + z1w(1)) / g.azff[r];          // Az^cfc = Az^ff
+    const double k00 = Kh(0, 0);
+    const double bhU = (k00 - Kh(-1, 0)) / dxfc, bhV = (k00 - Kh(0, -1)) / dycf;
+    Au = (vvU + vaU) + bhU;
+    Av = (vvV + vaV) + bhV;
+  }
+  double Cu = 0.0, Cv = 0.0;
+  if (ph.cor == 3) {
+    Cu = -ph.f0 * (0.5 * (0.5 * (V(-1, 0, 0) + V(0, 0, 0)) + 0.5 * (V(-1, 1, 0) + V(0, 1, 0))));
+    Cv = ph.f0 * (0.5 * (0.5 * (U(0, -1, 0) + U(1, -1, 0)) + 0.5 * (U(0, 0, 0) + U(1, 0, 0))));
+  } else if (ph.cor == 1) {
+    const double f0 = ph.frow[r], f1 = ph.frow[r + 1];
+    Cu = -(0.5 * (f0 + f1)) * (0.5 * (Iy_dxv(-1) + Iy_dxv(0))) / dxfc;
+    Cv = +(0.5 * (f0 + f0)) * (0.5 * (Ix_dyu(-1) + Ix_dyu(0))) / dycf;
+  } else if (ph.cor == 2) {
+    const double f0 = ph.frow[r], f1 = ph.frow[r + 1];
+    Cu = -(0.5 * (f0 * Ix_dxv(0) + f1 * Ix_dxv(1))) / dxfc;
+    Cv = +(0.5 * (f0 * Iy_dyu(0) + f0 * Iy_dyu(1))) / dycf;
+  }
+  const double px = (p[cc] - p[cc - 1]) / dxfc, py = (p[cc] - p[cc - syc]) / dycf;
+  Gu[cu] = ((-Au - 0.0) - Cu) - px;
+  Gv[cv] = ((-Av - 0.0) - Cv) - py;
+}
+
+__global__ void __launch_bounds__(256) k_hy_Gc(HyMetric g, const double* __restrict__ u, const double* __restrict__ v,
+                                               const double* __restrict__ w, const double* __restrict__ c, double* __restrict__ Gc, int tadv,
+                                               long syu, long szu, long syv, long szv, long syc, long szc) {
+  OCN_NO_CONTRACT
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  const int r = j + g.Hy;
+  const long cu = (i + g.Hx) + (long)r * syu + (long)(k + g.Hz) * szu, cv = (i + g.Hx) + (long)r * syv + (long)(k + g.Hz) * szv;
+  const long cc = (i + g.Hx) + (long)r * syc + (long)(k + g.Hz) * szc;
+  if (!tadv) {
+    Gc[cc] = 0.0;
+    return;
+  }
+  const double dz = g.dzc[k];
+  auto Fx = [&](int di) { return ((g.dyfc[r] * dz) * u[cu + di]) * (0.5 * (c[cc + di - 1] + c[cc + di])); };
+  auto Fy = [&](int dj) { return ((g.dxcf[r + dj] * dz) * v[cv + dj * syv]) * (0.5 * (c[cc + (dj - 1) * syc] + c[cc + dj * syc])); };
+  auto Fz = [&](int dk) { return (g.azcc[r] * w[cc + dk * szc]) * (0.5 * (c[cc + (dk - 1) * szc] + c[cc + dk * szc])); };
+  const double div = 1 / (g.azcc[r] * dz) * (((Fx(1) - Fx(0)) + (Fy(1) - Fy(0))) + (Fz(1) - Fz(0)));
+  Gc[cc] = -div;
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static int api_done(ocn_ctx* ctx, int rc) {
 #ifndef OCN_HOST_EMU
@@ -622,6 +733,9 @@ struct ocn_hydro {
   HyBuoy buoy;
   int bT, bS;                                // indices (into c) of the tracers the buoyancy reads, -1: none
   double *Un = nullptr, *Vn = nullptr;       // barotropic mode of the stepped velocities, kept for the corrector
+  HyPhys phys{1, 0, 1, 0.0, nullptr};        // the model's defaults: VectorInvariant(), no Coriolis, CenteredSecondOrder tracers
+  double* frow = nullptr;
+  double chi = 0.1;                          // QuasiAdamsBashforth2TimeStepper's default
 };
 
 static HyGrid hy_grid(const ocn_hgrid* g) {
@@ -698,6 +812,27 @@ static void hydro_update_state(ocn_hydro* h, bool pressure_done) {
   hfield_fill(h->pHY);
 }
 
+static HyMetric hy_metric(const ocn_hgrid* g) {
+  HyMetric q;
+  q.dxfc = g->dxfc; q.dxcf = g->dxcf; q.dyfc = g->dyfc; q.dycf = g->dycf; q.azcc = g->azcc; q.azff = g->azff; q.dzc = g->dzc; q.dzf = g->dzf;
+  q.Nx = g->N[0]; q.Ny = g->N[1]; q.Nz = g->N[2]; q.Hx = g->H[0]; q.Hy = g->H[1]; q.Hz = g->H[2];
+  return q;
+}
+static void hydro_tendencies(ocn_hydro* h) {
+  const ocn_hgrid* g = h->fs->g;
+  dim3 b(64, 4, 1), gr((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, g->N[2]);
+  const ocn_hfield *u = h->u, *v = h->v, *p = h->pHY;
+  HyPhys ph = h->phys;
+  ph.frow = h->frow;
+  ocn_launch(k_hy_Guv, gr, b, g->ctx->stream, hy_metric(g), ph, (const double*)u->d, (const double*)v->d, (const double*)h->w->d, (const double*)p->d,
+             h->gn[0]->d, h->gn[1]->d, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)p->T[0],
+             (long)p->T[0] * p->T[1]);
+  for (size_t q = 0; q < h->c.size(); ++q)
+    ocn_launch(k_hy_Gc, gr, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d,
+               (const double*)h->c[q]->d, h->gn[2 + q]->d, h->phys.tadv, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0],
+               (long)v->T[0] * v->T[1], (long)p->T[0], (long)p->T[0] * p->T[1]);
+}
+
 static bool same_shape(const ocn_hfield* a, const ocn_hfield* b) {
   return a && b && a->g == b->g && a->T[0] == b->T[0] && a->T[1] == b->T[1] && a->T[2] == b->T[2] && a->loc[0] == b->loc[0] &&
          a->loc[1] == b->loc[1] && a->loc[2] == b->loc[2];
@@ -758,8 +893,9 @@ int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* d, ocn_hgrid** out) {
   }
   const int ny = g->N[1] + 2 * g->H[1] + 1;
   g->h_dxfc.assign(ny, 0); g->h_dxcf.assign(ny, 0); g->h_dyfc.assign(ny, 0); g->h_dycf.assign(ny, 0); g->h_azcc.assign(ny, 0);
+  g->h_azff.assign(ny, 0);
   if (g->kind == HG_RECT) {
-    for (int r = 0; r < ny; ++r) { g->h_dxfc[r] = dx; g->h_dxcf[r] = dx; g->h_dyfc[r] = dy; g->h_dycf[r] = dy; g->h_azcc[r] = dx * dy; }
+    for (int r = 0; r < ny; ++r) { g->h_dxfc[r] = dx; g->h_dxcf[r] = dx; g->h_dyfc[r] = dy; g->h_dycf[r] = dy; g->h_azcc[r] = dx * dy; g->h_azff[r] = dx * dy; }
   } else {
     // latitude_longitude_grid.jl:418-445 (regular longitude and latitude)
     const double R = g->radius, dlam = dx * (M_PI / 180.0), dphi = dy * (M_PI / 180.0);
@@ -771,7 +907,9 @@ int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* d, ocn_hgrid** out) {
       g->h_dxcf[r] = r < (int)Fy.size() ? R * cosd(Fy[r]) * dlam : NAN;
       g->h_dyfc[r] = R * dphi;
       g->h_dycf[r] = R * dphi;
+      if (r < (int)Fy.size()) g->h_phif.resize(r + 1), g->h_phif[r] = Fy[r];
       g->h_azcc[r] = r + 1 < (int)Fy.size() ? R * R * dlam * (sind(Fy[r + 1]) - sind(Fy[r])) : NAN;
+      g->h_azff[r] = (r >= 1 && r < (int)Cy.size()) ? R * R * dlam * (sind(Cy[r]) - sind(Cy[r - 1])) : NAN;   // :444 (regular longitude: = Az^cf)
     }
   }
   int rc = upload(ctx, g->h_dxfc, &g->dxfc);
@@ -781,6 +919,7 @@ int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* d, ocn_hgrid** out) {
   if (!rc) rc = upload(ctx, g->h_azcc, &g->azcc);
   if (!rc) rc = upload(ctx, g->h_dzc, &g->dzc);
   if (!rc) rc = upload(ctx, g->h_dzf, &g->dzf);
+  if (!rc) rc = upload(ctx, g->h_azff, &g->azff);
   if (rc) { ocn_hgrid_destroy(g); return rc; }
   *out = g;
   return OCN_OK;
@@ -790,12 +929,12 @@ static void hgrid_release(ocn_hgrid* g);
 void ocn_hgrid_destroy(ocn_hgrid* g) { hgrid_release(g); }
 static void hgrid_release(ocn_hgrid* g) {
   if (!g || --g->refs > 0) return;
-  hipFree(g->dxfc); hipFree(g->dxcf); hipFree(g->dyfc); hipFree(g->dycf); hipFree(g->azcc); hipFree(g->dzc); hipFree(g->dzf);
+  hipFree(g->dxfc); hipFree(g->dxcf); hipFree(g->dyfc); hipFree(g->dycf); hipFree(g->azcc); hipFree(g->dzc); hipFree(g->dzf); hipFree(g->azff);
   delete g;
 }
 
 /* which: 0 dx^fc, 1 dx^cf, 2 dy^fc, 3 dy^cf, 4 Az^cc (rows j = 1 - Hy ...), 5 dz^c (levels 1..Nz),
- * 6 / 7 x nodes Face / Center, 8 / 9 y nodes Face / Center (incl. halos), 10 dz^f (faces 1..Nz+1); returns the number of entries, copies min(n, entries) */
+ * 6 / 7 x nodes Face / Center, 8 / 9 y nodes Face / Center (incl. halos), 10 dz^f (faces 1..Nz+1), 11 Az^ff (rows); returns the number of entries, copies min(n, entries) */
 int ocn_hgrid_metric(const ocn_hgrid* g, int which, double* host, int n) {
   if (!g || !host || n < 0) return OCN_EINVAL;
   const std::vector<double>* v = nullptr;
@@ -811,6 +950,7 @@ int ocn_hgrid_metric(const ocn_hgrid* g, int which, double* host, int n) {
     case 8: v = &g->nodeF[1]; break;
     case 9: v = &g->nodeC[1]; break;
     case 10: v = &g->h_dzf; break;
+    case 11: v = &g->h_azff; break;
     default: return OCN_EINVAL;
   }
   const int m = (int)v->size() < n ? (int)v->size() : n;
@@ -1180,6 +1320,7 @@ void ocn_hydro_destroy(ocn_hydro* h) {
   hipStreamSynchronize(g->ctx->stream);
   hipFree(h->Un);
   hipFree(h->Vn);
+  hipFree(h->frow);
   delete h;
   hgrid_release(g);
 }
@@ -1254,6 +1395,58 @@ int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fus
   sefs_correct_launch(s, h->u, h->v);
   hydro_update_state(h, pressure_done);
   return api_done(ctx, OCN_OK);
+}
+
+
+/* ---- third slice: calculate_tendencies! and the whole time step ---------------------------------------------------------------- */
+int ocn_hydro_set_physics(ocn_hydro* h, int momentum_advection, int coriolis, double coriolis_parameter, int tracer_advection) {
+  if (!h) return OCN_EINVAL;
+  ocn_hgrid* g = h->fs->g;
+  ocn_ctx* ctx = g->ctx;
+  if (momentum_advection < 0 || momentum_advection > 2 || coriolis < 0 || coriolis > 3 || tracer_advection < 0 || tracer_advection > 1) {
+    ocn_set_error(ctx, "ocn_hydro_set_physics: momentum_advection 0..2, coriolis 0..3, tracer_advection 0..1");
+    return OCN_EINVAL;
+  }
+  if ((coriolis == 1 || coriolis == 2) && g->kind != HG_LATLON) {
+    ocn_set_error(ctx, "ocn_hydro_set_physics: HydrostaticSphericalCoriolis needs a LatitudeLongitudeGrid");
+    return OCN_EINVAL;
+  }
+  if (g->H[0] < 1 || g->H[1] < 1 || g->H[2] < 1) {
+    ocn_set_error(ctx, "ocn_hydro_set_physics: the second-order stencils read one halo cell in every direction");
+    return OCN_EINVAL;
+  }
+  OCN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  hipFree(h->frow);
+  h->frow = nullptr;
+  if (coriolis == 1 || coriolis == 2) {
+    // f^ffa[j] = 2 Omega sin(pi phi^f[j] / 180) (hydrostatic_spherical_coriolis.jl:32-33)
+    std::vector<double> f(g->N[1] + 2 * g->H[1] + 1, NAN);
+    for (size_t r = 0; r < f.size() && r < g->h_phif.size(); ++r) f[r] = 2 * coriolis_parameter * sin(M_PI * g->h_phif[r] / 180.0);
+    if (int rc = upload(ctx, f, &h->frow)) return rc;
+  }
+  h->phys.madv = momentum_advection;
+  h->phys.cor = coriolis;
+  h->phys.tadv = tracer_advection;
+  h->phys.f0 = coriolis_parameter;
+  return OCN_OK;
+}
+
+int ocn_hydro_calculate_tendencies(ocn_hydro* h) {
+  if (!h) return OCN_EINVAL;
+  if (h->fs->g->H[0] < 1 || h->fs->g->H[1] < 1 || h->fs->g->H[2] < 1) return OCN_EINVAL;
+  hydro_tendencies(h);
+  return api_done(h->fs->g->ctx, OCN_OK);
+}
+
+/* time_step!(model, dt; euler) (TimeSteppers/quasi_adams_bashforth_2.jl:70-104) */
+int ocn_hydro_time_step(ocn_hydro* h, double dt, int euler) {
+  if (!h) return OCN_EINVAL;
+  ocn_ctx* ctx = h->fs->g->ctx;
+  const double chi = euler ? -0.5 : h->chi;
+  if (euler)
+    for (ocn_hfield* f : h->gm) OCN_ASYNC(hipMemsetAsync(f->d, 0, f->n * sizeof(double), ctx->stream));
+  hydro_tendencies(h);
+  return ocn_hydro_step_after_tendencies(h, dt, chi, 1);
 }
 
 }  // extern "C"

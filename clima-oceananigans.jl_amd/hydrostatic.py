@@ -19,6 +19,7 @@ Nothing = "Nothing"
 _TOPO = {Periodic: L.PERIODIC, Bounded: L.BOUNDED}
 _LOC = {Center: L.CENTER, Face: L.FACE, Nothing: L.NOTHING, None: L.NOTHING}
 R_Earth = 6371.0e3
+OMEGA_EARTH = 7.292115e-5
 g_Earth = 9.80665
 
 
@@ -286,8 +287,10 @@ class HydrostaticState:
     """the fields of a HydrostaticFreeSurfaceModel{SplitExplicitFreeSurface} the step after the tendencies touches: u, v, w, the
     tracers, G^n and G^- of the prognostic fields, pHY' and the free surface (hydrostatic_free_surface_model.jl:92-211)"""
 
-    def __init__(self, grid, tracers=("T", "S"), buoyancy=None, substeps=20, gravitational_acceleration=g_Earth, free_surface=None):
+    def __init__(self, grid, tracers=("T", "S"), buoyancy=None, substeps=20, gravitational_acceleration=g_Earth, free_surface=None,
+                 momentum_advection="VectorInvariantEnstrophyConserving", coriolis=None, tracer_advection="CenteredSecondOrder"):
         self.grid, self.lib = grid, grid.lib
+        self.chi = 0.1
         self.u, self.v, self.w = Field3(grid, Face, Center), Field3(grid, Center, Face), Field3(grid, Center, Center, Face)
         self.tracers = {n: Field3(grid, Center, Center) for n in tracers}
         names = ["u", "v"] + list(tracers)
@@ -312,6 +315,24 @@ class HydrostaticState:
         d.gravitational_acceleration, d.thermal_expansion, d.haline_contraction = g, al, be
         self.h = C.c_void_p()
         check(self.lib.ocn_hydro_create(C.byref(d), C.byref(self.h)), grid.ctx.h)
+        self.set_physics(momentum_advection, coriolis, tracer_advection)
+
+    def set_physics(self, momentum_advection, coriolis, tracer_advection):
+        """momentum_advection: None | "VectorInvariantEnstrophyConserving" | "VectorInvariantEnergyConserving";
+        coriolis: None | ("HydrostaticSphericalCoriolis", rotation_rate, "EnstrophyConserving" | "EnergyConserving") | ("FPlane", f);
+        tracer_advection: None | "CenteredSecondOrder" """
+        ma = {None: 0, "VectorInvariantEnstrophyConserving": 1, "VectorInvariantEnergyConserving": 2}[momentum_advection]
+        ta = {None: 0, "CenteredSecondOrder": 1}[tracer_advection]
+        if coriolis is None:
+            ck, cp = 0, 0.0
+        elif coriolis[0] == "FPlane":
+            ck, cp = 3, float(coriolis[1])
+        elif coriolis[0] == "HydrostaticSphericalCoriolis":
+            ck, cp = {"EnstrophyConserving": 1, "EnergyConserving": 2}[coriolis[2]], float(coriolis[1])
+        else:
+            raise ValueError(f"unsupported coriolis {coriolis!r}")
+        check(self.lib.ocn_hydro_set_physics(self.h, ma, ck, cp, ta), self.grid.ctx.h)
+        self.momentum_advection, self.coriolis, self.tracer_advection = momentum_advection, coriolis, tracer_advection
 
     def __del__(self):
         try:
@@ -336,3 +357,13 @@ def time_step_after_tendencies(st, dt, chi, fused=True):
     """time_step!(model, dt) from `ab2_step!` on (quasi_adams_bashforth_2.jl:94-100); fused=False issues the reference's kernels
     one by one, fused=True the merged passes (same bits)"""
     check(st.lib.ocn_hydro_step_after_tendencies(st.h, float(dt), float(chi), int(bool(fused))), st.grid.ctx.h)
+
+
+def calculate_tendencies(st):
+    """calculate_tendencies!(model) (calculate_hydrostatic_free_surface_tendencies.jl:15-160)"""
+    check(st.lib.ocn_hydro_calculate_tendencies(st.h), st.grid.ctx.h)
+
+
+def time_step(st, dt, euler=False):
+    """time_step!(model, dt; euler) (TimeSteppers/quasi_adams_bashforth_2.jl:70-104)"""
+    check(st.lib.ocn_hydro_time_step(st.h, float(dt), int(bool(euler))), st.grid.ctx.h)

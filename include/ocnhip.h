@@ -348,6 +348,20 @@ int ocn_hydro_ab2_step(ocn_hydro* h, double dt, double chi);
  * 40 field sweeps) and leaves the same bits in every field, halos included. */
 int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fused);
 
+/* ---- third slice: calculate_tendencies! (no closure, forcing or immersed boundary) and the whole time_step! ---------------
+ * momentum_advection: 0 nothing, 1 VectorInvariant(scheme = EnstrophyConservingScheme()) -- the default --, 2 EnergyConservingScheme
+ *   (Advection/vector_invariant_advection.jl:25-80);
+ * coriolis: 0 nothing, 1 / 2 HydrostaticSphericalCoriolis(rotation_rate = coriolis_parameter) with the Enstrophy- / Energy-
+ *   ConservingScheme (Coriolis/hydrostatic_spherical_coriolis.jl:29-66; LatitudeLongitudeGrid only), 3 FPlane(f = coriolis_parameter);
+ * tracer_advection: 0 nothing, 1 CenteredSecondOrder() (tracer_advection_operators.jl:33-37).
+ * Defaults of a new handle: 1, 0, 1 -- the reference model's. */
+int ocn_hydro_set_physics(ocn_hydro* h, int momentum_advection, int coriolis, double coriolis_parameter, int tracer_advection);
+/* calculate_tendencies!(model) (calculate_hydrostatic_free_surface_tendencies.jl:15-160): G^n of u, v and every tracer over the
+ * grid's cells, from the state update_state! left (filled halos, w, pHY') */
+int ocn_hydro_calculate_tendencies(ocn_hydro* h);
+/* time_step!(model, dt; euler) (TimeSteppers/quasi_adams_bashforth_2.jl:70-104): chi = -1/2 and G^- = 0 when euler, else 0.1 */
+int ocn_hydro_time_step(ocn_hydro* h, double dt, int euler);
+
 /* ---- measurement helpers (bench.py) -------------------------------------------------------------- */
 /* average device time [ms] of the `n` most recent launches of the named phase, measured with HIP
  * events on the context stream when profiling is enabled */

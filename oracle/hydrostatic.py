@@ -85,8 +85,10 @@ class HydrostaticState:
     """the fields of a HydrostaticFreeSurfaceModel{SplitExplicitFreeSurface} this slice touches"""
 
     def __init__(self, grid, tracers=("T", "S"), buoyancy=None, substeps=20, gravitational_acceleration=SE.G_EARTH, F3=Field3,
-                 free_surface=None):
+                 free_surface=None, momentum_advection="VectorInvariantEnstrophyConserving", coriolis=None,
+                 tracer_advection="CenteredSecondOrder"):
         self.grid = grid
+        self.momentum_advection, self.coriolis, self.tracer_advection = momentum_advection, coriolis, tracer_advection
         self.u, self.v, self.w = F3(grid, Face, Center, Center), F3(grid, Center, Face, Center), F3(grid, Center, Center, Face)
         self.tracers = {n: F3(grid, Center, Center, Center) for n in tracers}
         names = ["u", "v"] + list(tracers)
@@ -129,3 +131,168 @@ def time_step_after_tendencies(st, dt, chi, fused=False):
     for n in st.Gn:                                         # store_tendencies!: the grid's cells (store_tendencies.jl:8-11,24-28)
         st.Gm[n].data[idx] = st.Gn[n].data[idx]
     update_state(st)
+
+
+# ---- third slice: calculate_tendencies! ---------------------------------------------------------------------------------------
+# Restates, for a HydrostaticFreeSurfaceModel with a SplitExplicitFreeSurface, no closure, no forcing, no immersed boundary:
+#   * ``hydrostatic_free_surface_tendency_kernel_functions.jl:24-125`` -- G_u, G_v, G_c as sums of the terms below, in that order;
+#   * ``Advection/vector_invariant_advection.jl:25-80`` -- ``VectorInvariant`` momentum advection (the only one a curvilinear grid
+#     accepts), EnstrophyConservingScheme (default) or EnergyConservingScheme: vertical vorticity, vertical advection, Bernoulli head;
+#   * ``Operators/vorticity_operators.jl:2-5`` -- circulation and vertical vorticity at (Face, Face, Center);
+#   * ``Coriolis/hydrostatic_spherical_coriolis.jl:29-66`` -- ``HydrostaticSphericalCoriolis`` (both schemes), and
+#     ``Coriolis/f_plane.jl:42-43`` -- ``FPlane``;
+#   * ``Advection/tracer_advection_operators.jl:33-37`` with ``centered_advective_fluxes.jl:31-33`` -- flux-form tracer advection,
+#     ``CenteredSecondOrder`` (the model's default);
+#   * ``split_explicit_free_surface.jl:178-179`` -- the explicit barotropic pressure gradient is zero for this free surface;
+#   * ``calculate_hydrostatic_free_surface_tendencies.jl:55-160`` -- every kernel runs over i = 1..Nx, j = 1..Ny, k = 1..Nz.
+# Operators: difference / interpolation / derivative / metric-product operators of ``Operators/*.jl`` with their operand order.
+OMEGA_EARTH = 7.292115e-5
+
+
+class _Stencil:
+    """views of parent arrays over the compute region, shifted by (di, dj, dk); metric rows as (1, Ny, 1), levels as (1, 1, Nz)"""
+
+    def __init__(self, g):
+        self.g = g
+        az = g.ax[2]
+        ks = np.arange(1 - g.Hz, g.Nz + g.Hz + 1)
+        self.dzc = np.full(ks.size, az.dc) if az.regular else np.array([float(az.d_center(k)) if 1 - g.Hz <= k <= g.Nz + g.Hz else np.nan for k in ks])
+        kf = np.arange(1 - g.Hz, g.Nz + g.Hz + 2)
+        self.dzf = np.full(kf.size, az.df) if az.regular else np.array([float(az.d_face(k)) if 0 <= k + az.H < az._df.size else np.nan for k in kf])
+
+    def S(self, a, di=0, dj=0, dk=0):
+        g = self.g
+        return a[g.Hx + di:g.Hx + g.Nx + di, g.Hy + dj:g.Hy + g.Ny + dj, g.Hz + dk:g.Hz + g.Nz + dk]
+
+    def R(self, m, dj=0):
+        g = self.g
+        return m[g.Hy + dj:g.Hy + g.Ny + dj].reshape(1, -1, 1)
+
+    def Zc(self, dk=0):
+        g = self.g
+        return self.dzc[g.Hz + dk:g.Hz + g.Nz + dk].reshape(1, 1, -1)
+
+    def Zf(self, dk=0):
+        g = self.g
+        return self.dzf[g.Hz + dk:g.Hz + g.Nz + dk].reshape(1, 1, -1)
+
+
+def coriolis_parameter_rows(grid, coriolis):
+    """f at the rows of (Face, Face) points: 2 Omega sin(phi^f[j]) (hydrostatic_spherical_coriolis.jl:32-33), or the FPlane's f"""
+    if coriolis[0] == "FPlane":
+        return np.full(grid.Ny + 2 * grid.Hy + 1, float(coriolis[1]))
+    if grid.phi_f is None:
+        raise ValueError("HydrostaticSphericalCoriolis needs a LatitudeLongitudeGrid")
+    return 2 * float(coriolis[1]) * np.sin(np.pi * grid.phi_f / 180)
+
+
+def momentum_tendencies(st, momentum_advection="VectorInvariantEnstrophyConserving", coriolis=None):
+    """G^n.u, G^n.v over the grid's cells.  momentum_advection: None | "VectorInvariantEnstrophyConserving" | "VectorInvariantEnergyConserving";
+    coriolis: None | ("HydrostaticSphericalCoriolis", rotation_rate, "EnergyConserving" | "EnstrophyConserving") | ("FPlane", f)"""
+    g = st.grid
+    o = _Stencil(g)
+    S, R = o.S, o.R
+    u, v, w, p = st.u.data, st.v.data, st.w.data, st.pHY.data
+    dxfc, dxcf, dyfc, dycf, azcc, azff = g.dx_fc, g.dx_cf, g.dy_fc, g.dy_cf, g.Az_cc, g.Az_ff
+    azfc, azcf = azcc, azff                                   # regular x: Az^fc = Az^cc and Az^cf = Az^ff (latitude_longitude_grid.jl:442-445)
+
+    def zeta(di=0, dj=0):                                     # zeta_3^ffc at (i + di, j + dj)
+        circ = ((R(dycf, dj) * S(v, di, dj) - R(dycf, dj) * S(v, di - 1, dj))
+                - (R(dxfc, dj) * S(u, di, dj) - R(dxfc, dj - 1) * S(u, di, dj - 1)))
+        return circ / R(azff, dj)
+
+    def Kh(di=0, dj=0):                                       # Kh^ccc at (i + di, j + dj)
+        return (0.5 * (S(u, di, dj) ** 2 + S(u, di + 1, dj) ** 2) + 0.5 * (S(v, di, dj) ** 2 + S(v, di, dj + 1) ** 2)) / 2
+
+    def Iy_dxv(di=0):                                         # I_y^c(dx_q^cfc v) at (i + di, j)
+        return 0.5 * (R(dxcf, 0) * S(v, di, 0) + R(dxcf, 1) * S(v, di, 1))
+
+    def Ix_dyu(dj=0):                                         # I_x^c(dy_q^fcc u) at (i, j + dj)
+        return 0.5 * (R(dyfc, dj) * S(u, 0, dj) + R(dyfc, dj) * S(u, 1, dj))
+
+    def Ix_dxv(dj=0):                                         # I_x^f(dx_q^cfc v) at (i, j + dj)
+        return 0.5 * (R(dxcf, dj) * S(v, -1, dj) + R(dxcf, dj) * S(v, 0, dj))
+
+    def Iy_dyu(di=0):                                         # I_y^f(dy_q^fcc u) at (i + di, j)
+        return 0.5 * (R(dyfc, -1) * S(u, di, -1) + R(dyfc, 0) * S(u, di, 0))
+
+    zero = np.zeros((g.Nx, g.Ny, g.Nz))
+    if momentum_advection is None:
+        Au, Av = zero, zero
+    else:
+        if momentum_advection == "VectorInvariantEnstrophyConserving":
+            vvU = -(0.5 * (zeta(0, 0) + zeta(0, 1))) * (0.5 * (Iy_dxv(-1) + Iy_dxv(0))) / R(dxfc)
+            vvV = +(0.5 * (zeta(0, 0) + zeta(1, 0))) * (0.5 * (Ix_dyu(-1) + Ix_dyu(0))) / R(dycf)
+        elif momentum_advection == "VectorInvariantEnergyConserving":
+            vvU = -(0.5 * (zeta(0, 0) * Ix_dxv(0) + zeta(0, 1) * Ix_dxv(1))) / R(dxfc)
+            vvV = +(0.5 * (zeta(0, 0) * Iy_dyu(0) + zeta(1, 0) * Iy_dyu(1))) / R(dycf)
+        else:
+            raise ValueError(momentum_advection)
+
+        def z2w(dk):                                          # zeta_2 w^fcf at level k + dk
+            return (0.5 * (R(azcc) * S(w, -1, 0, dk) + R(azcc) * S(w, 0, 0, dk))) * ((S(u, 0, 0, dk) - S(u, 0, 0, dk - 1)) / o.Zf(dk))
+
+        def z1w(dk):                                          # zeta_1 w^cff at level k + dk
+            return (0.5 * (R(azcc, -1) * S(w, 0, -1, dk) + R(azcc, 0) * S(w, 0, 0, dk))) * ((S(v, 0, 0, dk) - S(v, 0, 0, dk - 1)) / o.Zf(dk))
+        vaU = 0.5 * (z2w(0) + z2w(1)) / R(azfc)
+        vaV = 0.5 * (z1w(0) + z1w(1)) / R(azcf)
+        bhU = (Kh(0, 0) - Kh(-1, 0)) / R(dxfc)
+        bhV = (Kh(0, 0) - Kh(0, -1)) / R(dycf)
+        Au = (vvU + vaU) + bhU
+        Av = (vvV + vaV) + bhV
+    if coriolis is None:
+        Cu, Cv = zero, zero
+    else:
+        f = coriolis_parameter_rows(g, coriolis)
+        if coriolis[0] == "FPlane":
+            f0 = float(coriolis[1])
+            Cu = -f0 * (0.5 * (0.5 * (S(v, -1, 0) + S(v, 0, 0)) + 0.5 * (S(v, -1, 1) + S(v, 0, 1))))
+            Cv = f0 * (0.5 * (0.5 * (S(u, 0, -1) + S(u, 1, -1)) + 0.5 * (S(u, 0, 0) + S(u, 1, 0))))
+        elif coriolis[2] == "EnstrophyConserving":
+            Cu = -(0.5 * (R(f, 0) + R(f, 1))) * (0.5 * (Iy_dxv(-1) + Iy_dxv(0))) / R(dxfc)
+            Cv = +(0.5 * (R(f, 0) + R(f, 0))) * (0.5 * (Ix_dyu(-1) + Ix_dyu(0))) / R(dycf)
+        elif coriolis[2] == "EnergyConserving":
+            Cu = -(0.5 * (R(f, 0) * Ix_dxv(0) + R(f, 1) * Ix_dxv(1))) / R(dxfc)
+            Cv = +(0.5 * (R(f, 0) * Iy_dyu(0) + R(f, 0) * Iy_dyu(1))) / R(dycf)
+        else:
+            raise ValueError(coriolis)
+    px = (S(p, 0, 0) - S(p, -1, 0)) / R(dxfc)
+    py = (S(p, 0, 0) - S(p, 0, -1)) / R(dycf)
+    S(st.Gn["u"].data)[...] = ((-Au - 0) - Cu) - px
+    S(st.Gn["v"].data)[...] = ((-Av - 0) - Cv) - py
+
+
+def tracer_tendency(st, name, tracer_advection="CenteredSecondOrder"):
+    """G^n.c = -div_Uc over the grid's cells (tracer_advection: None | "CenteredSecondOrder")"""
+    g = st.grid
+    o = _Stencil(g)
+    S, R = o.S, o.R
+    if tracer_advection is None:
+        S(st.Gn[name].data)[...] = 0.0
+        return
+    if tracer_advection != "CenteredSecondOrder":
+        raise ValueError(tracer_advection)
+    u, v, w, c = st.u.data, st.v.data, st.w.data, st.tracers[name].data
+    Fx = lambda di: ((R(g.dy_fc) * o.Zc()) * S(u, di)) * (0.5 * (S(c, di - 1) + S(c, di)))                    # noqa: E731
+    Fy = lambda dj: ((R(g.dx_cf, dj) * o.Zc()) * S(v, 0, dj)) * (0.5 * (S(c, 0, dj - 1) + S(c, 0, dj)))       # noqa: E731
+    Fz = lambda dk: (R(g.Az_cc) * S(w, 0, 0, dk)) * (0.5 * (S(c, 0, 0, dk - 1) + S(c, 0, 0, dk)))             # noqa: E731
+    div = 1 / (R(g.Az_cc) * o.Zc()) * (((Fx(1) - Fx(0)) + (Fy(1) - Fy(0))) + (Fz(1) - Fz(0)))
+    S(st.Gn[name].data)[...] = -div
+
+
+def calculate_tendencies(st):
+    """calculate_tendencies!(model) with st.momentum_advection, st.coriolis, st.tracer_advection"""
+    momentum_tendencies(st, getattr(st, "momentum_advection", "VectorInvariantEnstrophyConserving"), getattr(st, "coriolis", None))
+    for n in st.tracers:
+        tracer_tendency(st, n, getattr(st, "tracer_advection", "CenteredSecondOrder"))
+
+
+def time_step(st, dt, euler=False):
+    """time_step!(model, dt; euler) (TimeSteppers/quasi_adams_bashforth_2.jl:70-104); the caller sets euler on the first step (the
+    reference infers it from dt != previous dt as well)"""
+    chi = -0.5 if euler else st.chi
+    if euler:
+        for f in st.Gm.values():
+            f.data[...] = 0.0
+    calculate_tendencies(st)
+    time_step_after_tendencies(st, dt, chi)

@@ -63,6 +63,8 @@ class HRectilinearGrid(_HGrid):
         self.dx_fc = np.full(ny, dx); self.dx_cf = np.full(ny, dx)
         self.dy_fc = np.full(ny, dy); self.dy_cf = np.full(ny, dy)
         self.Az_cc = np.full(ny, dx * dy)
+        self.Az_ff = np.full(ny, dx * dy)                                       # Az = dx dy at every location
+        self.phi_f = None
 
 
 class LatitudeLongitudeGrid(_HGrid):
@@ -93,6 +95,9 @@ class LatitudeLongitudeGrid(_HGrid):
         self.dy_fc = np.full(ny, R * np.deg2rad(dphi))                         # :441 (YRegLatLonGrid: one number)
         self.dy_cf = np.full(ny, R * np.deg2rad(dphi))                         # :440
         self.Az_cc = R ** 2 * np.deg2rad(dlam) * (hack_sind(phif[1:ny + 1]) - hack_sind(phif[:ny]))   # :445
+        self.Az_ff = np.full(ny, np.nan)                                         # :444; regular longitude: Az^fc = Az^cc, Az^cf = Az^ff
+        self.Az_ff[1:] = R ** 2 * np.deg2rad(dlam) * (hack_sind(phic[1:]) - hack_sind(phic[:-1]))
+        self.phi_f = phif[:ny]                                                   # latitude of the rows of faces (Coriolis)
 
 
 class ReducedField:

@@ -1,0 +1,186 @@
+"""HydrostaticFreeSurfaceModel, `calculate_tendencies!` and the whole `time_step!` (BASELINE config 5, third slice): VectorInvariant
+momentum advection (both schemes), HydrostaticSphericalCoriolis (both schemes) / FPlane, the hydrostatic pressure gradient,
+flux-form CenteredSecondOrder tracer advection; no closure, forcing or immersed boundary.
+
+The reference's tests for this model assert no numbers (test/test_hydrostatic_free_surface_models.jl: "time stepping runs").
+Pins used instead, on the oracle, the host emulation and libocnhip.so:
+  * ANALYTIC: solid-body rotation on the sphere (Williamson et al. 1992, test case 2): u = U0 cos(phi), v = 0 gives
+    G_u = 0 and G_v = -(f u + u^2 tan(phi) / R) -- second-order convergence of G_v, G_u zero to round-off;
+    with eta = -(R Omega U0 + U0^2 / 2) sin^2(phi) / g the flow is a steady state of the whole time step: the drift of u, v
+    after 12 steps falls by 4 when the resolution doubles;
+  * a uniform tracer stays uniform in the non-divergent flow update_state! leaves (G_c = -c div(U) = 0 to round-off);
+  * the library against the oracle on G^n and on the state after whole steps -- bit for bit when the two hold the same grid
+    metrics (they do where libm and NumPy round sin / cos alike), else to 1e-12.
+"""
+import numpy as np
+import pytest
+
+from oracle import hydrostatic as OH
+from oracle import split_explicit as OS
+from test_hydrostatic_step import GRIDS, KINDS, LibBackend, OracleBackend, TS, _backend, all_fields, make_state, parent
+
+OMEGA = 7.292115e-5
+SPHERICAL = ("HydrostaticSphericalCoriolis", OMEGA)
+
+
+def williamson2(be, Ny, Nz=4, substeps=30, scheme="EnstrophyConserving", advection="VectorInvariantEnstrophyConserving", U0=20.0):
+    grid = be.LatitudeLongitudeGrid(size=(2 * Ny, Ny, Nz), longitude=(-180, 180), latitude=(-80, 80), z=(-1000, 0), halo=(3, 3, 3))
+    st = be.H.HydrostaticState(grid, tracers=("c",), buoyancy=None, substeps=substeps, momentum_advection=advection,
+                               coriolis=SPHERICAL + (scheme,))
+    R, g = 6371.0e3, OS.G_EARTH
+    st.u.set(lambda x, y, z: U0 * np.cos(np.pi * y / 180) + 0 * x + 0 * z)
+    st.free_surface.eta.set(lambda x, y: -(R * OMEGA * U0 + U0 ** 2 / 2) * np.sin(np.pi * y / 180) ** 2 / g + 0 * x)
+    st.tracers["c"].set(3.0)
+    be.H.update_state(st)
+    return grid, st
+
+
+@pytest.mark.parametrize("scheme,advection", [("EnstrophyConserving", "VectorInvariantEnstrophyConserving"),
+                                              ("EnergyConserving", "VectorInvariantEnergyConserving")])
+@pytest.mark.parametrize("kind", KINDS)
+def test_solid_body_rotation_tendencies(kind, scheme, advection, ocn, backend):
+    be = _backend(kind, ocn, backend)
+    U0, R = 20.0, 6371.0e3
+    errs = []
+    for Ny in (16, 32):
+        grid, st = williamson2(be, Ny, scheme=scheme, advection=advection)
+        be.H.calculate_tendencies(st)
+        Gu, Gv, Gc = st.Gn["u"].interior(), st.Gn["v"].interior(), st.Gn["c"].interior()
+        assert np.abs(Gu).max() <= 1e-17                                 # exactly zonal: every term of G_u vanishes
+        assert np.abs(Gc).max() <= 1e-12 * 3.0 * U0 / (R * np.deg2rad(160 / Ny))   # c div(U), with div(U) = 0 to round-off
+        phi = np.deg2rad(OS.LatitudeLongitudeGrid(size=(2 * Ny, Ny, 4), longitude=(-180, 180), latitude=(-80, 80), z=(-1000, 0),
+                                                  halo=(3, 3, 3)).nodes("Face", 1))
+        exact = -(2 * OMEGA * np.sin(phi) * U0 * np.cos(phi) + U0 ** 2 * np.cos(phi) * np.sin(phi) / R)
+        num = Gv[0, :, 1]
+        n = min(num.size, exact.size)
+        errs.append(np.abs(num[1:n - 1] - exact[1:n - 1]).max() / np.abs(exact).max())      # the wall rows read filled halos
+    assert errs[0] < 2e-2 and 3.5 < errs[0] / errs[1] < 4.5, errs
+
+
+@pytest.mark.parametrize("kind", ["oracle", "hostemu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def test_solid_body_rotation_is_a_steady_state_of_the_time_step(kind, ocn, backend):
+    be = _backend(kind, ocn, backend)
+    drift = []
+    sizes = (16, 32) if kind != "gpu" else (32, 64)
+    for Ny in sizes:
+        grid, st = williamson2(be, Ny)
+        u0 = st.u.interior().copy()
+        for s in range(12):
+            be.H.time_step(st, 600.0, euler=(s == 0))
+        drift.append((np.abs(st.u.interior() - u0).max(), np.abs(st.v.interior()).max()))
+        # a uniform tracer stays uniform where the flow is non-divergent; the top cell is not: the reference's impenetrable fill
+        # zeroes w at the surface face while the free surface moves (compute_w_from_continuity.jl + hydrostatic_free_surface_field_tuples.jl:7)
+        dc = np.abs(st.tracers["c"].interior() - 3.0)
+        assert dc[:, :, :2].max() < 1e-9 and dc.max() < 1e-2
+    assert drift[0][0] < 0.02 * 16 / sizes[0] and 3.5 < drift[0][0] / drift[1][0] < 4.5, drift
+    assert 3.5 < drift[0][1] / drift[1][1] < 4.5, drift
+
+
+# ---- the library against the oracle -----------------------------------------------------------------------------------------------
+def _metrics_identical(st, gridname):
+    """True when the library's per-row metrics equal the oracle's bit for bit (then every comparison below is exact)"""
+    ctor, kw = GRIDS[gridname]
+    og = getattr(OS, ctor)(**kw)
+    g = st.grid
+    pairs = [(g.metric(0), og.dx_fc), (g.metric(1), og.dx_cf), (g.metric(2), og.dy_fc), (g.metric(3), og.dy_cf), (g.metric(4), og.Az_cc),
+             (g.metric(11), og.Az_ff)]
+    same = True
+    for a, b in pairs:
+        ok = np.isfinite(b) & np.isfinite(a[:b.size])
+        assert np.allclose(a[:b.size][ok], b[ok], rtol=1e-14, atol=0)
+        same &= bool(np.array_equal(a[:b.size][ok], b[ok]))
+    return same
+
+
+def _close(got, want, exact, what):
+    if exact:
+        assert np.array_equal(got, want), f"{what}: max rel {np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)}"
+    else:
+        assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1e-300), what
+
+
+PHYSICS = [("VectorInvariantEnstrophyConserving", "EnstrophyConserving"), ("VectorInvariantEnergyConserving", "EnergyConserving"),
+           ("VectorInvariantEnstrophyConserving", None), (None, "EnergyConserving")]
+TCASES = [("sphere", TS, ("T", "S")), ("sector", ("b", "b"), ("b",)), ("channel", TS, ("S", "e", "T")), ("box", None, ("c",))]
+
+
+def _compare_tendencies(be, gridname, buoyancy, tracers, advection, scheme):
+    latlon = GRIDS[gridname][0] == "LatitudeLongitudeGrid"
+    coriolis = None if scheme is None else (SPHERICAL + (scheme,) if latlon else ("FPlane", 1e-4))
+    states = []
+    for b in (be, OracleBackend):
+        _, st, _ = make_state(b, gridname, buoyancy=buoyancy, tracers=tracers)
+        if b is OracleBackend:
+            st.momentum_advection, st.coriolis = advection, coriolis
+        else:
+            st.set_physics(advection, coriolis, "CenteredSecondOrder")
+        b.H.update_state(st)
+        b.H.calculate_tendencies(st)
+        states.append(st)
+    st, so = states
+    exact = _metrics_identical(st, gridname)
+    for n in so.Gn:
+        _close(parent(st.Gn[n]), so.Gn[n].data, exact, f"G^n.{n} on {gridname}")
+    assert np.abs(so.Gn["u"].interior()).max() > 0
+    return st, so, exact
+
+
+@pytest.mark.parametrize("advection,scheme", PHYSICS, ids=lambda v: str(v).replace("VectorInvariant", "VI"))
+@pytest.mark.parametrize("gridname,buoyancy,tracers", TCASES, ids=[c[0] for c in TCASES])
+def test_tendencies_match_oracle_hostemu(gridname, buoyancy, tracers, advection, scheme, ocn, backend):
+    if backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    _compare_tendencies(LibBackend(ocn), gridname, buoyancy, tracers, advection, scheme)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("advection,scheme", PHYSICS, ids=lambda v: str(v).replace("VectorInvariant", "VI"))
+@pytest.mark.parametrize("gridname,buoyancy,tracers", TCASES, ids=[c[0] for c in TCASES])
+def test_tendencies_match_oracle_gpu(gridname, buoyancy, tracers, advection, scheme, ocn):
+    _compare_tendencies(LibBackend(ocn), gridname, buoyancy, tracers, advection, scheme)
+
+
+def _compare_time_steps(be, gridname, buoyancy, tracers, steps=3):
+    latlon = GRIDS[gridname][0] == "LatitudeLongitudeGrid"
+    coriolis = SPHERICAL + ("EnstrophyConserving",) if latlon else ("FPlane", 1e-4)
+    st, so, exact = None, None, None
+    states = []
+    for b in (be, OracleBackend):
+        _, s, _ = make_state(b, gridname, buoyancy=buoyancy, tracers=tracers, amplitude=0.05)
+        if b is OracleBackend:
+            s.coriolis = coriolis
+        else:
+            s.set_physics("VectorInvariantEnstrophyConserving", coriolis, "CenteredSecondOrder")
+        b.H.update_state(s)
+        for q in range(steps):
+            b.H.time_step(s, 120.0, euler=(q == 0))
+        states.append(s)
+    st, so = states
+    exact = _metrics_identical(st, gridname)
+    got, want = all_fields(st), all_fields(so)
+    for k in want:
+        _close(got[k], want[k], exact, f"{k} after {steps} steps on {gridname}")
+    assert np.isfinite(want["u"]).all() and np.abs(want["w"]).max() > 0
+
+
+@pytest.mark.parametrize("gridname,buoyancy,tracers", TCASES, ids=[c[0] for c in TCASES])
+def test_time_steps_match_oracle_hostemu(gridname, buoyancy, tracers, ocn, backend):
+    if backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    _compare_time_steps(LibBackend(ocn), gridname, buoyancy, tracers)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gridname,buoyancy,tracers", TCASES, ids=[c[0] for c in TCASES])
+def test_time_steps_match_oracle_gpu(gridname, buoyancy, tracers, ocn):
+    _compare_time_steps(LibBackend(ocn), gridname, buoyancy, tracers)
+
+
+@pytest.mark.parametrize("kind", ["hostemu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def test_physics_arguments_are_checked(kind, ocn, backend):
+    be = _backend(kind, ocn, backend)
+    _, st, _ = make_state(be, "box", buoyancy=None, tracers=())
+    with pytest.raises(ocn.OcnError):
+        st.set_physics("VectorInvariantEnstrophyConserving", SPHERICAL + ("EnergyConserving",), "CenteredSecondOrder")   # no latitude on a box
+    with pytest.raises(KeyError):
+        st.set_physics("WENO5", None, "CenteredSecondOrder")

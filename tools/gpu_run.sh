@@ -9,6 +9,7 @@
 #   trace:<name>[=<bench.py args>]      rocprofv3 --kernel-trace --stats -- python3 bench.py <args>   -> <name>_kernel_stats.csv
 #   pmc:<name>[=<bench.py args>]        separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ set) of bench.py <args>
 #   py:<name>=<script and args>         python <script and args>
+#   pytrace:<name>=<script and args>    rocprofv3 --kernel-trace --stats -- python3 <script and args>  -> <name>_kernel_stats.csv
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=$1; shift
@@ -59,6 +60,12 @@ for step in "$@"; do
       done
       python tools/summarize_pmc.py "$O" "$name" > "$O/${name}_pmc_summary.json" 2> "$O/${name}_pmc_summary.err" || true
       head -c 1500 "$O/${name}_pmc_summary.json";;
+    pytrace)
+      set -- $args; script=$1; shift
+      ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 $LIMIT rocprofv3 --kernel-trace --stats -d "$O/$name" -o trace --output-format csv -- \
+          python3 "$R/$script" "$@" > "$O/$name.log" 2>&1 ); rc=$?
+      f=$(find "$O/$name" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$O/${name}_kernel_stats.csv" && head -14 "$f" | cut -c1-200
+      finish $rc "pytrace:$name";;
     py)
       timeout -k 10 $LIMIT python $args > "$O/$name.log" 2>&1; rc=$?; tail -8 "$O/$name.log" | cut -c1-400; finish $rc "py:$name";;
     *) echo "unknown step $step"; exit 2;;
