@@ -190,6 +190,7 @@ struct SeArgs {
 
 // kernel 1 (:14-19):  U += dtau (-g H^fc d_x eta + G^U),  V += dtau (-g H^cf d_y eta + G^V)   over i = 1..Nx, j = 1..Ny
 __global__ void k_se_uv(SeArgs a) {
+  OCN_NO_CONTRACT
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= a.Nx || j >= a.Ny) return;
   const long ce = (i + a.Hx) + (long)(j + a.Hy) * a.se, cu = (i + a.Hx) + (long)(j + a.Hy) * a.su, cv = (i + a.Hx) + (long)(j + a.Hy) * a.sv;
@@ -202,6 +203,7 @@ __global__ void k_se_uv(SeArgs a) {
 
 // kernel 2 (:21-29):  eta -= dtau div_xy(U, V);  averages
 __global__ void k_se_eta(SeArgs a) {
+  OCN_NO_CONTRACT
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= a.Nx || j >= a.Ny) return;
   const long ce = (i + a.Hx) + (long)(j + a.Hy) * a.se, cu = (i + a.Hx) + (long)(j + a.Hy) * a.su, cv = (i + a.Hx) + (long)(j + a.Hy) * a.sv;
@@ -223,6 +225,7 @@ __global__ void k_se_eta(SeArgs a) {
 //   * it writes eta's halo images of its own cell (the fill of eta that precedes kernel 1 in the reference), its new U and
 //     V, and their halo images (the fills that follow kernel 1): value-for-value what the five launches leave.
 __global__ void k_se_uv_fused(SeArgs a) {
+  OCN_NO_CONTRACT
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= a.Nx || j >= a.Ny) return;
   const int Nx = a.Nx, Ny = a.Ny, Hx = a.Hx, Hy = a.Hy;
@@ -271,6 +274,7 @@ struct SeArgs1 {
   double *etaO, *UO, *VO;         // written
 };
 __global__ void k_se_substep1(SeArgs1 b) {
+  OCN_NO_CONTRACT
   const SeArgs& a = b.a;
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= a.Nx || j >= a.Ny) return;
@@ -339,6 +343,7 @@ __global__ void k_se_vsum(double* out, const double* a, const double* b, double 
 __global__ void k_se_correct(double* u, double* v, const double* U, const double* V, const double* Ub, const double* Vb, const double* Hfc,
                              const double* Hcf, int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, long su3, long szu, long sv3, long szv,
                              long su2, long sv2) {
+  OCN_NO_CONTRACT
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
   if (i >= Nx || j >= Ny || k >= Nz) return;
   const long cu2 = (i + Hx) + (long)(j + Hy) * su2, cv2 = (i + Hx) + (long)(j + Hy) * sv2;

@@ -17,7 +17,8 @@ import pytest
 
 from oracle import hydrostatic as OH
 from oracle import split_explicit as OS
-from test_hydrostatic_step import GRIDS, KINDS, LibBackend, OracleBackend, TS, _backend, all_fields, make_state, parent
+from test_hydrostatic_step import (GRIDS, KINDS, LibBackend, OracleBackend, TS, _backend, all_fields, close as _close, make_state,
+                                   metrics_identical as _metrics_identical, parent)
 
 OMEGA = 7.292115e-5
 SPHERICAL = ("HydrostaticSphericalCoriolis", OMEGA)
@@ -77,28 +78,6 @@ def test_solid_body_rotation_is_a_steady_state_of_the_time_step(kind, ocn, backe
 
 
 # ---- the library against the oracle -----------------------------------------------------------------------------------------------
-def _metrics_identical(st, gridname):
-    """True when the library's per-row metrics equal the oracle's bit for bit (then every comparison below is exact)"""
-    ctor, kw = GRIDS[gridname]
-    og = getattr(OS, ctor)(**kw)
-    g = st.grid
-    pairs = [(g.metric(0), og.dx_fc), (g.metric(1), og.dx_cf), (g.metric(2), og.dy_fc), (g.metric(3), og.dy_cf), (g.metric(4), og.Az_cc),
-             (g.metric(11), og.Az_ff)]
-    same = True
-    for a, b in pairs:
-        ok = np.isfinite(b) & np.isfinite(a[:b.size])
-        assert np.allclose(a[:b.size][ok], b[ok], rtol=1e-14, atol=0)
-        same &= bool(np.array_equal(a[:b.size][ok], b[ok]))
-    return same
-
-
-def _close(got, want, exact, what):
-    if exact:
-        assert np.array_equal(got, want), f"{what}: max rel {np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)}"
-    else:
-        assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1e-300), what
-
-
 PHYSICS = [("VectorInvariantEnstrophyConserving", "EnstrophyConserving"), ("VectorInvariantEnergyConserving", "EnergyConserving"),
            ("VectorInvariantEnstrophyConserving", None), (None, "EnergyConserving")]
 TCASES = [("sphere", TS, ("T", "S")), ("sector", ("b", "b"), ("b",)), ("channel", TS, ("S", "e", "T")), ("box", None, ("c",))]
