@@ -55,7 +55,7 @@ class HydroDesc(C.Structure):
 
 class HGridDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("N", C.c_int32 * 3), ("H", C.c_int32 * 3), ("topology", C.c_int32 * 3),
-                ("x0", C.c_double * 3), ("L", C.c_double * 3), ("z_faces", C.POINTER(C.c_double)), ("radius", C.c_double)]
+                ("x0", C.c_double * 3), ("L", C.c_double * 3), ("z_faces", C.POINTER(C.c_double)), ("radius", C.c_double), ("partition", C.c_int32)]
 
 
 NOTHING = 2
@@ -135,6 +135,7 @@ def load():
         "ocn_comm_rank": (I, [P, C.POINTER(I), C.POINTER(I)]),
         "ocn_hgrid_create": (I, [P, C.POINTER(HGridDesc), C.POINTER(P)]),
         "ocn_hgrid_destroy": (None, [P]),
+        "ocn_hgrid_band": (I, [P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "ocn_hgrid_metric": (I, [P, I, PD, I]),
         "ocn_hfield_create": (I, [P, I, I, I, C.POINTER(P)]),
         "ocn_hfield_destroy": (None, [P]),

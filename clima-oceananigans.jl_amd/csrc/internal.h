@@ -33,6 +33,7 @@ struct ocn_ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_main = nullptr, ev_halo = nullptr, ev_halo2 = nullptr;
   std::vector<struct ocn_model*> models;   // live models (ocn_sync settles their exchanges)
+  int sticky_rc = 0;   // first failure of an exchange issued from a helper that cannot return it (splitexplicit.hip hfield_fill); reported by the entry point
 };
 
 void ocn_set_error(ocn_ctx* ctx, const char* fmt, ...);

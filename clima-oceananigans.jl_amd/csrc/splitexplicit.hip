@@ -37,6 +37,13 @@ struct ocn_hgrid {
   int refs = 1;
   int kind;
   int N[3], H[3], topo[3];
+  // latitude bands (y-slabs) over the context's ranks: N[1] is the LOCAL number of rows, rows j0 + 1 .. j0 + N[1] of gNy; a band
+  // keeps the Bounded shape of its fields (Face-y fields hold N[1] + 1 rows: the last one is the upper neighbour's first, or the wall)
+  bool slab = false;
+  int gNy = 0, j0 = 0;
+  bool wall_lo = true, wall_hi = true;      // the band touches the southern / northern wall (Bounded y) -- else a neighbour
+  double *pack_s = nullptr, *pack_r = nullptr;
+  size_t pack_n = 0;
   double x0[3], L[3], radius;
   bool z_regular;
   std::vector<double> nodeF[3], nodeC[3];          // incl. halos, entry [i - 1 + H] for reference index i
@@ -123,19 +130,36 @@ __global__ void k_h_fill_periodic(double* p, int dim, int N, int H, int Tx, int 
 }
 // Bounded: Center -> no-flux (fill_halo_regions_flux.jl:16-35, first halo cell only); Face -> impenetrable
 // (fill_halo_regions_open.jl:34-39: the two boundary faces are zeroed).  Launched over the INTERIOR cells of the other direction.
-__global__ void k_h_fill_bounded(double* p, int dim, int face, int N, int H, int No, int Ho, int Tx, int Ty, int k0, int nk) {
+__global__ void k_h_fill_bounded(double* p, int dim, int face, int N, int H, int No, int Ho, int Tx, int Ty, int k0, int nk, int sides) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x, k = k0 + blockIdx.y;      // interior levels only (the `:xz` / `:yz` launch)
   if (a >= No || (int)blockIdx.y >= nk) return;
   const long sy = Tx, sz = (long)Tx * Ty;
   const long st = dim == 0 ? 1 : sy;
   const long base = (dim == 0 ? (long)(a + Ho) * sy : (long)(a + Ho)) + k * sz;
+  // sides: bit 0 the lower boundary, bit 1 the upper one (a latitude band fills only the walls it touches)
   if (face) {
-    p[base + (long)H * st] = 0.0;            // face 1
-    p[base + (long)(H + N) * st] = 0.0;      // face N + 1
+    if (sides & 1) p[base + (long)H * st] = 0.0;            // face 1
+    if (sides & 2) p[base + (long)(H + N) * st] = 0.0;      // face N + 1
   } else {
-    p[base + (long)(H - 1) * st] = p[base + (long)H * st];               // c[0] = c[1]
-    p[base + (long)(H + N) * st] = p[base + (long)(H + N - 1) * st];     // c[N+1] = c[N]
+    if (sides & 1) p[base + (long)(H - 1) * st] = p[base + (long)H * st];               // c[0] = c[1]
+    if (sides & 2) p[base + (long)(H + N) * st] = p[base + (long)(H + N - 1) * st];     // c[N+1] = c[N]
   }
+}
+
+// rows of a latitude band travelling to / from the neighbouring bands: whole parent rows (x halos included), every parent level.
+// pack: side 0 = the top H interior rows (for the upper neighbour's southern halo), side 1 = the bottom H (+1 for Face-y fields:
+// the neighbour's extra row) interior rows (for the lower neighbour's northern rows); unpack: side 0 = rows below row 1 (from the
+// lower neighbour), side 1 = rows above row N (from the upper one)
+__global__ void k_h_pack_rows(double* p, double* buf, int Tx, int Ty, int Tz, int N, int H, int extra, int side, int unpack) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, h = blockIdx.y, k = blockIdx.z;
+  const int nrow = side == 0 ? H : H + extra;
+  if (x >= Tx || h >= nrow || k >= Tz) return;
+  int row;
+  if (!unpack) row = side == 0 ? N + h : H + h;                     // parent rows [N, N + H) / [H, 2H + extra)
+  else row = side == 0 ? h : N + H + h;                             // parent rows [0, H) / [N + H, N + 2H + extra)
+  const long ip = x + (long)row * Tx + (long)k * Tx * Ty, ib = x + (long)Tx * (h + (long)nrow * k);
+  if (unpack) p[ip] = buf[ib];
+  else buf[ib] = p[ip];
 }
 
 // z (always Bounded here), over i = 1..Nx, j = 1..Ny of the grid (the `:xy` launch): Center -> no-flux, Face -> the default
@@ -153,28 +177,89 @@ __global__ void k_h_fill_z(double* p, int face, int Nx, int Ny, int Nz, int Hx, 
   }
 }
 
+static int hfield_exchange_y(ocn_hfield* f);
+
 static void hfield_fill(ocn_hfield* f) {
   ocn_hgrid* g = f->g;
   hipStream_t s = g->ctx->stream;
   if (f->loc[2] != OCN_NOTHING && (g->H[2] > 0 || f->loc[2] == OCN_FACE))
     ocn_launch(k_h_fill_z, dim3((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, 1), dim3(64, 4, 1), s, f->d, f->loc[2] == OCN_FACE ? 1 : 0, g->N[0], g->N[1],
                g->N[2], g->H[0], g->H[1], g->H[2], f->T[0], f->T[1]);
+  auto bounded = [&](int d, int sides) {
+    const int o = 1 - d;
+    if (!sides || (g->H[d] == 0 && f->loc[d] == OCN_CENTER)) return;
+    const int k0 = f->loc[2] == OCN_NOTHING ? 0 : g->H[2], nk = f->loc[2] == OCN_NOTHING ? 1 : g->N[2];
+    ocn_launch(k_h_fill_bounded, dim3((g->N[o] + 127) / 128, nk, 1), dim3(128, 1, 1), s, f->d, d, f->loc[d] == OCN_FACE ? 1 : 0, g->N[d], g->H[d],
+               g->N[o], g->H[o], f->T[0], f->T[1], k0, nk, sides);
+  };
+  auto periodic = [&](int d) {
+    if (g->H[d] == 0) return;
+    const int na = d == 0 ? f->T[1] : f->T[0];
+    ocn_launch(k_h_fill_periodic, dim3((na + 127) / 128, f->T[2], 1), dim3(128, 1, 1), s, f->d, d, g->N[d], g->H[d], f->T[0], f->T[1], f->T[2]);
+  };
+  if (g->slab) {
+    // a latitude band: Bounded x first (interior rows), then y -- the walls this band touches and whole rows from the neighbouring
+    // bands (their x halos included: fresh where x is Bounded) --, Periodic x last over the whole parent, received rows included
+    if (g->topo[0] != OCN_PERIODIC) bounded(0, 3);
+    bounded(1, (g->wall_lo ? 1 : 0) | (g->wall_hi ? 2 : 0));
+    if (int rc = hfield_exchange_y(f))
+      if (!g->ctx->sticky_rc) g->ctx->sticky_rc = rc;
+    if (g->topo[0] == OCN_PERIODIC) periodic(0);
+    return;
+  }
   // non-periodic directions first (fill_halo_regions.jl:76-99)
   int order[2] = {0, 1};
   if (g->topo[0] == OCN_PERIODIC && g->topo[1] != OCN_PERIODIC) { order[0] = 1; order[1] = 0; }
   for (int t = 0; t < 2; ++t) {
-    const int d = order[t], o = 1 - d;
-    if (g->topo[d] == OCN_PERIODIC) {
-      if (g->H[d] == 0) continue;
-      const int na = d == 0 ? f->T[1] : f->T[0];
-      ocn_launch(k_h_fill_periodic, dim3((na + 127) / 128, f->T[2], 1), dim3(128, 1, 1), s, f->d, d, g->N[d], g->H[d], f->T[0], f->T[1], f->T[2]);
-    } else {
-      if (g->H[d] == 0 && f->loc[d] == OCN_CENTER) continue;
-      const int k0 = f->loc[2] == OCN_NOTHING ? 0 : g->H[2], nk = f->loc[2] == OCN_NOTHING ? 1 : g->N[2];
-      ocn_launch(k_h_fill_bounded, dim3((g->N[o] + 127) / 128, nk, 1), dim3(128, 1, 1), s, f->d, d, f->loc[d] == OCN_FACE ? 1 : 0,
-                 g->N[d], g->H[d], g->N[o], g->H[o], f->T[0], f->T[1], k0, nk);
-    }
+    const int d = order[t];
+    if (g->topo[d] == OCN_PERIODIC) periodic(d);
+    else bounded(d, 3);
   }
+}
+
+// halo rows of a latitude band: one grouped exchange with the two neighbouring bands (collective: every rank of the context calls it)
+static int hfield_exchange_y(ocn_hfield* f) {
+  ocn_hgrid* g = f->g;
+  ocn_ctx* c = g->ctx;
+  const int H = g->H[1], N = g->N[1];
+  if (H == 0 && f->loc[1] != OCN_FACE) return OCN_OK;
+  const int R = c->nranks, r = c->rank;
+  const bool per = g->topo[1] == OCN_PERIODIC;
+  const int up = (r + 1 < R) ? r + 1 : (per ? 0 : -1), dn = (r > 0) ? r - 1 : (per ? R - 1 : -1);
+  const int extra = (f->loc[1] == OCN_FACE && !per) ? 1 : 0;
+  const size_t row = (size_t)f->T[0] * f->T[2];
+  const size_t nA = (size_t)H * row, nB = (size_t)(H + extra) * row;      // block sent upwards / downwards
+  const size_t need = nA + nB;
+  if (need > g->pack_n) {
+    hipStreamSynchronize(c->stream);
+    hipFree(g->pack_s);
+    hipFree(g->pack_r);
+    g->pack_s = g->pack_r = nullptr;
+    g->pack_n = 0;
+    if (hipMalloc((void**)&g->pack_s, need * sizeof(double)) != hipSuccess || hipMalloc((void**)&g->pack_r, need * sizeof(double)) != hipSuccess) {
+      ocn_set_error(c, "band halo staging allocation failed");
+      return OCN_ENOMEM;
+    }
+    g->pack_n = need;
+  }
+  const dim3 b(64, 1, 1);
+  auto grid = [&](int nrow) { return dim3((f->T[0] + 63) / 64, nrow, f->T[2]); };
+  std::vector<CommOp> sends, recvs;
+  if (up >= 0 && H > 0) {
+    ocn_launch(k_h_pack_rows, grid(H), b, c->stream, f->d, g->pack_s, f->T[0], f->T[1], f->T[2], N, H, extra, 0, 0);
+    sends.push_back({g->pack_s, nA * sizeof(double), up, 0});
+  }
+  if (dn >= 0 && H + extra > 0) {
+    ocn_launch(k_h_pack_rows, grid(H + extra), b, c->stream, f->d, g->pack_s + nA, f->T[0], f->T[1], f->T[2], N, H, extra, 1, 0);
+    sends.push_back({g->pack_s + nA, nB * sizeof(double), dn, 1});
+  }
+  if (dn >= 0 && H > 0) recvs.push_back({g->pack_r, nA * sizeof(double), dn, 0});
+  if (up >= 0 && H + extra > 0) recvs.push_back({g->pack_r + nA, nB * sizeof(double), up, 1});
+  if (int rc = comm_exchange(c, sends, recvs)) return rc;
+  if (dn >= 0 && H > 0) ocn_launch(k_h_pack_rows, grid(H), b, c->stream, f->d, g->pack_r, f->T[0], f->T[1], f->T[2], N, H, extra, 0, 1);
+  if (up >= 0 && H + extra > 0)
+    ocn_launch(k_h_pack_rows, grid(H + extra), b, c->stream, f->d, g->pack_r + nA, f->T[0], f->T[1], f->T[2], N, H, extra, 1, 1);
+  return OCN_OK;
 }
 
 // ---- the two substep kernels ---------------------------------------------------------------------------------------------
@@ -626,6 +711,10 @@ __global__ void __launch_bounds__(256) k_hy_Gc(HyMetric g, const double* __restr
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static int api_done(ocn_ctx* ctx, int rc) {
+  if (ctx->sticky_rc) {
+    if (rc == OCN_OK) rc = ctx->sticky_rc;
+    ctx->sticky_rc = 0;
+  }
 #ifndef OCN_HOST_EMU
   if (g_ocn_launch_err.err != hipSuccess) {
     if (rc == OCN_OK) {
@@ -733,6 +822,9 @@ static void vsum(ocn_sefs* s, ocn_hfield* out, const ocn_hfield* a, const ocn_hf
 // ---- the hydrostatic step (second slice) ----------------------------------------------------------------------------------------
 struct ocn_hydro {
   ocn_sefs* fs;
+  ocn_hgrid* lg;                             // the grid of the 3-D fields: the free surface's, or a latitude band of it (the free surface is then
+                                             // replicated: every rank sub-cycles the whole barotropic problem after one all-gather of U, V, G^U, G^V)
+  long offU = 0, offV = 0;                   // first element of the band's rows inside the free surface's (Face, Center) / (Center, Face) arrays
   ocn_hfield *u, *v, *w, *pHY;
   std::vector<ocn_hfield*> c, gn, gm;        // tracers and the tendencies: entries 0, 1 of gn / gm are u, v; 2.. the tracers
   HyBuoy buoy;
@@ -798,12 +890,39 @@ static int sefs_step_tail(ocn_sefs* s, double dt) {
   hfield_fill(s->eta);
   return OCN_OK;
 }
-static void sefs_correct_launch(ocn_sefs* s, ocn_hfield* u, ocn_hfield* v) {
-  const ocn_hgrid* g = s->g;
+// offU / offV: first element of the rows of u's grid inside the free surface's 2-D arrays (a latitude band; 0 otherwise)
+static void sefs_correct_launch(ocn_sefs* s, ocn_hfield* u, ocn_hfield* v, long offU = 0, long offV = 0) {
+  const ocn_hgrid* g = u->g;
   dim3 blk(64, 4, 1), gr((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, g->N[2]);
-  ocn_launch(k_se_correct, gr, blk, g->ctx->stream, u->d, v->d, (const double*)s->U->d, (const double*)s->V->d, (const double*)s->Ubar->d,
-             (const double*)s->Vbar->d, (const double*)s->Hfc->d, (const double*)s->Hcf->d, g->N[0], g->N[1], g->N[2], g->H[0], g->H[1], g->H[2],
-             (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)s->U->T[0], (long)s->V->T[0]);
+  ocn_launch(k_se_correct, gr, blk, g->ctx->stream, u->d, v->d, (const double*)s->U->d + offU, (const double*)s->V->d + offV,
+             (const double*)s->Ubar->d + offU, (const double*)s->Vbar->d + offV, (const double*)s->Hfc->d + offU, (const double*)s->Hcf->d + offV, g->N[0],
+             g->N[1], g->N[2], g->H[0], g->H[1], g->H[2], (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1],
+             (long)s->U->T[0], (long)s->V->T[0]);
+}
+
+// every band's rows of the listed (Face, Center) / (Center, Face) arrays of the replicated free surface to every other rank: rows are
+// contiguous (whole parent rows), so the blocks travel straight out of and into the arrays -- one grouped exchange
+static int hydro_allgather_rows(ocn_hydro* h) {
+  ocn_sefs* s = h->fs;
+  ocn_hgrid* lg = h->lg;
+  ocn_ctx* c = lg->ctx;
+  if (!lg->slab) return OCN_OK;
+  const int R = c->nranks, nl = lg->N[1], Hy = lg->H[1];
+  const bool per = lg->topo[1] == OCN_PERIODIC;
+  ocn_hfield* fl[4] = {s->U, s->GU, s->V, s->GV};
+  std::vector<CommOp> sends, recvs;
+  for (int p = 0; p < R; ++p) {
+    if (p == c->rank) continue;
+    for (int q = 0; q < 4; ++q) {
+      ocn_hfield* f = fl[q];
+      const bool facey = q >= 2 && !per;
+      const size_t T0 = f->T[0];
+      auto rows = [&](int rank) { return (size_t)(nl + ((facey && rank == R - 1) ? 1 : 0)); };   // the wall row belongs to the last band
+      sends.push_back({f->d + (size_t)(Hy + nl * c->rank) * T0, rows(c->rank) * T0 * sizeof(double), p, 10 + q});
+      recvs.push_back({f->d + (size_t)(Hy + nl * p) * T0, rows(p) * T0 * sizeof(double), p, 10 + q});
+    }
+  }
+  return comm_exchange(c, sends, recvs);
 }
 // update_state!: fills of the prognostic fields, w from continuity, the hydrostatic pressure, fills of w and pHY'
 static void hydro_update_state(ocn_hydro* h, bool pressure_done) {
@@ -824,7 +943,7 @@ static HyMetric hy_metric(const ocn_hgrid* g) {
   return q;
 }
 static void hydro_tendencies(ocn_hydro* h) {
-  const ocn_hgrid* g = h->fs->g;
+  const ocn_hgrid* g = h->lg;
   dim3 b(64, 4, 1), gr((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, g->N[2]);
   const ocn_hfield *u = h->u, *v = h->v, *p = h->pHY;
   HyPhys ph = h->phys;
@@ -862,14 +981,37 @@ int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* d, ocn_hgrid** out) {
     ocn_set_error(ctx, "ocn_hgrid_create: longitude must span at most 360 degrees, latitude must lie in [-90, 90] and be Bounded");
     return OCN_EINVAL;
   }
+  if (d->partition != 0 && d->partition != 1) return OCN_EINVAL;
+  const bool slab = d->partition == 1 && ctx->nranks > 1;
+  if (slab && (d->N[1] % ctx->nranks != 0 || d->N[1] / ctx->nranks < d->H[1] + 1)) {
+    ocn_set_error(ctx, "ocn_hgrid_create: %d rows do not split into %d bands of more than H = %d rows", d->N[1], ctx->nranks, d->H[1]);
+    return OCN_EINVAL;
+  }
   ocn_hgrid* g = new ocn_hgrid;
   g->ctx = ctx;
   g->kind = d->kind;
   for (int q = 0; q < 3; ++q) { g->N[q] = d->N[q]; g->H[q] = d->H[q]; g->topo[q] = d->topology[q]; g->x0[q] = d->x0[q]; g->L[q] = d->L[q]; }
   g->radius = d->radius > 0 ? d->radius : 6371.0e3;
+  g->gNy = d->N[1];
   double dx, dy, dz = 0;
   regular_axis(g->x0[0], g->L[0], g->N[0], g->H[0], g->topo[0], g->nodeF[0], g->nodeC[0], dx);
   regular_axis(g->x0[1], g->L[1], g->N[1], g->H[1], g->topo[1], g->nodeF[1], g->nodeC[1], dy);
+  if (slab) {
+    // the band's rows of the GLOBAL node arrays (every metric below is then the global one of the same row, bit for bit)
+    const int nl = d->N[1] / ctx->nranks, j0 = nl * ctx->rank;
+    g->slab = true;
+    g->j0 = j0;
+    g->N[1] = nl;
+    g->wall_lo = g->topo[1] != OCN_PERIODIC && ctx->rank == 0;
+    g->wall_hi = g->topo[1] != OCN_PERIODIC && ctx->rank == ctx->nranks - 1;
+    auto band = [&](std::vector<double>& v, int want) {
+      std::vector<double> w(want);
+      for (int q = 0; q < want; ++q) w[q] = (j0 + q < (int)v.size()) ? v[j0 + q] : NAN;
+      v.swap(w);
+    };
+    band(g->nodeF[1], nl + 1 + 2 * g->H[1]);        // Bounded shape for every band
+    band(g->nodeC[1], nl + 2 * g->H[1]);
+  }
   g->z_regular = d->z_faces == nullptr;
   g->h_dzc.assign(g->N[2], 0.0);
   if (g->z_regular) {
@@ -934,8 +1076,18 @@ static void hgrid_release(ocn_hgrid* g);
 void ocn_hgrid_destroy(ocn_hgrid* g) { hgrid_release(g); }
 static void hgrid_release(ocn_hgrid* g) {
   if (!g || --g->refs > 0) return;
+  hipFree(g->pack_s);
+  hipFree(g->pack_r);
   hipFree(g->dxfc); hipFree(g->dxcf); hipFree(g->dyfc); hipFree(g->dycf); hipFree(g->azcc); hipFree(g->dzc); hipFree(g->dzf); hipFree(g->azff);
   delete g;
+}
+
+int ocn_hgrid_band(const ocn_hgrid* g, int32_t* j0, int32_t* ny_local, int32_t* ny_global) {
+  if (!g) return OCN_EINVAL;
+  if (j0) *j0 = g->j0;
+  if (ny_local) *ny_local = g->N[1];
+  if (ny_global) *ny_global = g->gNy;
+  return OCN_OK;
 }
 
 /* which: 0 dx^fc, 1 dx^cf, 2 dy^fc, 3 dy^cf, 4 Az^cc (rows j = 1 - Hy ...), 5 dz^c (levels 1..Nz),
@@ -1016,6 +1168,10 @@ int ocn_hfield_fill_halos(ocn_hfield* f) {
 
 int ocn_sefs_create(ocn_hgrid* g, double gravitational_acceleration, int substeps, ocn_sefs** out) {
   if (!g || !out || substeps < 1) return OCN_EINVAL;
+  if (g->slab) {
+    ocn_set_error(g->ctx, "ocn_sefs_create: the free surface lives on the whole grid (it is replicated on every rank); pass the unpartitioned grid");
+    return OCN_EINVAL;
+  }
   ocn_sefs* s = new ocn_sefs;
   s->g = g;
   g->refs += 1;
@@ -1269,8 +1425,18 @@ int ocn_hydro_pressure(ocn_hfield* pHY, int kind, double g, double alpha, double
 int ocn_hydro_create(const ocn_hydro_desc* d, ocn_hydro** out) {
   if (!d || !out || !d->free_surface || !d->u || !d->v || !d->w || !d->pHY || d->ntracers < 0 || (d->ntracers > 0 && !d->tracers) || !d->Gn || !d->Gm)
     return OCN_EINVAL;
-  ocn_hgrid* g = d->free_surface->g;
-  ocn_ctx* ctx = g->ctx;
+  ocn_hgrid* fg = d->free_surface->g;
+  ocn_hgrid* g = d->u->g;                        // the grid of the 3-D fields
+  ocn_ctx* ctx = fg->ctx;
+  if (g != fg) {
+    bool ok = g->slab && !fg->slab && g->ctx == fg->ctx && g->kind == fg->kind && g->N[0] == fg->N[0] && g->gNy == fg->N[1] && g->N[2] == fg->N[2] &&
+              g->radius == fg->radius;
+    for (int q = 0; q < 3; ++q) ok = ok && g->H[q] == fg->H[q] && g->topo[q] == fg->topo[q] && g->x0[q] == fg->x0[q] && g->L[q] == fg->L[q];
+    if (!ok) {
+      ocn_set_error(ctx, "ocn_hydro_create: the 3-D fields must live on the free surface's grid or on a latitude band (partition = 1) of that very grid");
+      return OCN_EINVAL;
+    }
+  }
   if (!is_loc(d->u, g, OCN_FACE, OCN_CENTER, OCN_CENTER) || !is_loc(d->v, g, OCN_CENTER, OCN_FACE, OCN_CENTER) ||
       !is_loc(d->w, g, OCN_CENTER, OCN_CENTER, OCN_FACE) || !is_loc(d->pHY, g, OCN_CENTER, OCN_CENTER, OCN_CENTER)) {
     ocn_set_error(ctx, "ocn_hydro_create: u, v, w, pHY must sit at their staggered locations on the free surface's grid");
@@ -1300,6 +1466,9 @@ int ocn_hydro_create(const ocn_hydro_desc* d, ocn_hydro** out) {
   }
   ocn_hydro* h = new ocn_hydro;
   h->fs = d->free_surface;
+  h->lg = g;
+  h->offU = (long)g->j0 * h->fs->U->T[0];
+  h->offV = (long)g->j0 * h->fs->V->T[0];
   h->u = d->u; h->v = d->v; h->w = d->w; h->pHY = d->pHY;
   h->c.assign(d->tracers, d->tracers + d->ntracers);
   h->gn.assign(d->Gn, d->Gn + 2 + d->ntracers);
@@ -1321,7 +1490,7 @@ int ocn_hydro_create(const ocn_hydro_desc* d, ocn_hydro** out) {
 
 void ocn_hydro_destroy(ocn_hydro* h) {
   if (!h) return;
-  ocn_hgrid* g = h->fs->g;
+  ocn_hgrid* g = h->lg;
   hipStreamSynchronize(g->ctx->stream);
   hipFree(h->Un);
   hipFree(h->Vn);
@@ -1340,6 +1509,10 @@ int ocn_hydro_update_state(ocn_hydro* h) {
  * the split-explicit free-surface step */
 int ocn_hydro_ab2_step(ocn_hydro* h, double dt, double chi) {
   if (!h) return OCN_EINVAL;
+  if (h->lg->slab) {
+    ocn_set_error(h->lg->ctx, "a model on latitude bands steps through ocn_hydro_step_after_tendencies(fused = 1) / ocn_hydro_time_step only");
+    return OCN_EUNSUPPORTED;
+  }
   int rc = ocn_sefs_barotropic_mode(h->fs, h->u, h->v, 0);
   if (rc) return rc;
   hy_ab2_launch(h->u, h->gn[0], h->gm[0], dt, chi, false);
@@ -1354,9 +1527,10 @@ int ocn_hydro_ab2_step(ocn_hydro* h, double dt, double chi) {
 int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fused) {
   if (!h) return OCN_EINVAL;
   ocn_sefs* s = h->fs;
-  ocn_hgrid* g = s->g;
+  ocn_hgrid* g = h->lg;
   ocn_ctx* ctx = g->ctx;
   int rc;
+  if (!fused && g->slab) fused = 1;
   if (!fused) {
     if ((rc = ocn_hydro_ab2_step(h, dt, chi))) return rc;
     if ((rc = ocn_sefs_corrector(s, h->u, h->v))) return rc;
@@ -1368,10 +1542,12 @@ int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fus
   dim3 blk(64, 4, 1);
   for (int q = 0; q < 2; ++q) {
     ocn_hfield *f = q ? h->v : h->u, *U = q ? s->V : s->U, *GU = q ? s->GV : s->GU;
-    ocn_launch(k_hy_momentum, dim3((U->S[0] + 63) / 64, (U->S[1] + 3) / 4, 1), blk, ctx->stream, f->d, (const double*)h->gn[q]->d, h->gm[q]->d, U->d, GU->d,
-               q ? h->Vn : h->Un, dt, cn, cm, (const double*)g->dzc, U->S[0], U->S[1], g->N[0], g->N[1], g->N[2], g->H[0], g->H[1], g->H[2], (long)f->T[0],
-               (long)f->T[0] * f->T[1], (long)U->T[0]);
+    const long off = q ? h->offV : h->offU;
+    ocn_launch(k_hy_momentum, dim3((f->S[0] + 63) / 64, (f->S[1] + 3) / 4, 1), blk, ctx->stream, f->d, (const double*)h->gn[q]->d, h->gm[q]->d, U->d + off,
+               GU->d + off, (q ? h->Vn : h->Un) + off, dt, cn, cm, (const double*)g->dzc, f->S[0], f->S[1], g->N[0], g->N[1], g->N[2], g->H[0], g->H[1],
+               g->H[2], (long)f->T[0], (long)f->T[0] * f->T[1], (long)U->T[0]);
   }
+  if ((rc = hydro_allgather_rows(h))) return api_done(ctx, rc);
   hfield_fill(s->U);
   hfield_fill(s->V);
   bool pressure_done = false;
@@ -1397,7 +1573,7 @@ int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fus
   se_copy(ctx, s->V->d, h->Vn, s->V->n);
   hfield_fill(s->U);
   hfield_fill(s->V);
-  sefs_correct_launch(s, h->u, h->v);
+  sefs_correct_launch(s, h->u, h->v, h->offU, h->offV);
   hydro_update_state(h, pressure_done);
   return api_done(ctx, OCN_OK);
 }
@@ -1406,7 +1582,7 @@ int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fus
 /* ---- third slice: calculate_tendencies! and the whole time step ---------------------------------------------------------------- */
 int ocn_hydro_set_physics(ocn_hydro* h, int momentum_advection, int coriolis, double coriolis_parameter, int tracer_advection) {
   if (!h) return OCN_EINVAL;
-  ocn_hgrid* g = h->fs->g;
+  ocn_hgrid* g = h->lg;
   ocn_ctx* ctx = g->ctx;
   if (momentum_advection < 0 || momentum_advection > 2 || coriolis < 0 || coriolis > 3 || tracer_advection < 0 || tracer_advection > 1) {
     ocn_set_error(ctx, "ocn_hydro_set_physics: momentum_advection 0..2, coriolis 0..3, tracer_advection 0..1");
@@ -1438,7 +1614,7 @@ int ocn_hydro_set_physics(ocn_hydro* h, int momentum_advection, int coriolis, do
 
 int ocn_hydro_calculate_tendencies(ocn_hydro* h) {
   if (!h) return OCN_EINVAL;
-  if (h->fs->g->H[0] < 1 || h->fs->g->H[1] < 1 || h->fs->g->H[2] < 1) return OCN_EINVAL;
+  if (h->lg->H[0] < 1 || h->lg->H[1] < 1 || h->lg->H[2] < 1) return OCN_EINVAL;
   hydro_tendencies(h);
   return api_done(h->fs->g->ctx, OCN_OK);
 }

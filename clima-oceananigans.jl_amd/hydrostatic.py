@@ -24,7 +24,7 @@ g_Earth = 9.80665
 
 
 class _HGrid:
-    def _create(self, ctx, kind, size, halo, topology, lo, ext, z, radius):
+    def _create(self, ctx, kind, size, halo, topology, lo, ext, z, radius, partition=None):
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
         d = L.HGridDesc()
@@ -42,8 +42,15 @@ class _HGrid:
                 raise ValueError("z must be (z1, z2) or hold Nz + 1 faces")
             d.z_faces = self._zf.ctypes.data_as(C.POINTER(C.c_double))
         d.radius = float(radius)
+        if partition not in (None, "y"):
+            raise ValueError("partition: None or 'y' (latitude bands over the context's ranks)")
+        d.partition = 1 if partition == "y" else 0
         self.h = C.c_void_p()
         check(self.lib.ocn_hgrid_create(self.ctx.h, C.byref(d), C.byref(self.h)), self.ctx.h)
+        j0, nl, ng = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.lib.ocn_hgrid_band(self.h, C.byref(j0), C.byref(nl), C.byref(ng)), self.ctx.h)
+        self.j0, self.Ny, self.global_Ny = j0.value, nl.value, ng.value      # this handle's rows of the global grid
+        self.partition = partition if self.Ny != self.global_Ny else None
 
     def metric(self, which):
         n = self.lib.ocn_hgrid_metric(self.h, int(which), (C.c_double * 1)(), 0)
@@ -73,6 +80,13 @@ class _HGrid:
 
     Δzᵃᵃᶠ = property(lambda s: s.metric(10))
 
+    def whole(self):
+        """the unpartitioned grid of a latitude band (what the replicated free surface lives on); the grid itself otherwise"""
+        if self.partition is None:
+            return self
+        cls, kw = self._ctor
+        return cls(**kw)
+
     def __del__(self):
         try:
             if self.h:
@@ -85,17 +99,19 @@ class _HGrid:
 class HRectilinearGrid(_HGrid):
     """RectilinearGrid(size, x, y, z, halo, topology) with regular x and y, for the hydrostatic pieces"""
 
-    def __init__(self, size, x, y, z, halo=(3, 3, 3), topology=(Periodic, Periodic, Bounded), arch=None):
+    def __init__(self, size, x, y, z, halo=(3, 3, 3), topology=(Periodic, Periodic, Bounded), arch=None, partition=None):
         zr = z if len(z) == 2 else (z[0], z[-1])
         self._z0 = float(zr[0])
-        self._create(arch, L.HGRID_RECTILINEAR, size, halo, topology, (x[0], y[0], zr[0]), (x[1] - x[0], y[1] - y[0], zr[1] - zr[0]), z, 0.0)
+        self._ctor = (HRectilinearGrid, dict(size=size, x=x, y=y, z=z, halo=halo, topology=topology, arch=arch))
+        self._create(arch, L.HGRID_RECTILINEAR, size, halo, topology, (x[0], y[0], zr[0]), (x[1] - x[0], y[1] - y[0], zr[1] - zr[0]), z, 0.0,
+                     partition)
 
 
 class LatitudeLongitudeGrid(_HGrid):
     """LatitudeLongitudeGrid(size, longitude, latitude, z, halo, radius) -- Grids/latitude_longitude_grid.jl:174-213; regular
     longitude and latitude, metrics precomputed.  Topology as the reference chooses it: Periodic longitude iff it spans 360."""
 
-    def __init__(self, size, longitude, latitude, z, halo=(3, 3, 3), radius=R_Earth, topology=None, arch=None):
+    def __init__(self, size, longitude, latitude, z, halo=(3, 3, 3), radius=R_Earth, topology=None, arch=None, partition=None):
         l1, l2 = longitude
         p1, p2 = latitude
         if not (l1 <= l2 and l2 - l1 <= 360 and -90 <= p1 <= p2 <= 90):
@@ -105,7 +121,9 @@ class LatitudeLongitudeGrid(_HGrid):
         zr = z if len(z) == 2 else (z[0], z[-1])
         self._z0 = float(zr[0])
         self.radius = float(radius)
-        self._create(arch, L.HGRID_LATLON, size, halo, topology, (l1, p1, zr[0]), (l2 - l1, p2 - p1, zr[1] - zr[0]), z, radius)
+        self._ctor = (LatitudeLongitudeGrid, dict(size=size, longitude=longitude, latitude=latitude, z=z, halo=halo, radius=radius,
+                                                  topology=topology, arch=arch))
+        self._create(arch, L.HGRID_LATLON, size, halo, topology, (l1, p1, zr[0]), (l2 - l1, p2 - p1, zr[1] - zr[0]), z, radius, partition)
 
 
 class HField:
@@ -299,7 +317,8 @@ class HydrostaticState:
         self.Gm = {n: Field3(grid, *loc.get(n, (Center, Center))) for n in names}
         self.pHY = Field3(grid, Center, Center)
         self.buoyancy = buoyancy
-        self.free_surface = free_surface or SplitExplicitFreeSurface(grid, gravitational_acceleration, substeps)
+        # on latitude bands the free surface is replicated: it lives on the whole grid, every rank sub-cycles all of it
+        self.free_surface = free_surface or SplitExplicitFreeSurface(grid.whole(), gravitational_acceleration, substeps)
         d = L.HydroDesc()
         d.free_surface = self.free_surface.h
         d.u, d.v, d.w, d.pHY = self.u.h, self.v.h, self.w.h, self.pHY.h

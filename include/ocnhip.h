@@ -264,8 +264,14 @@ typedef struct ocn_hgrid_desc {
   double x0[3], L[3];
   const double* z_faces; /* NULL or Nz + 1 doubles (host)                */
   double radius;         /* lat-lon: sphere radius (<= 0: R_Earth, latitude_longitude_grid.jl:3) */
+  int32_t partition;     /* 0: the whole grid on this context.  1: latitude bands (y-slabs) over the context's ranks (ocn_comm_init
+                          * first): N, x0, L describe the GLOBAL grid, the handle is rank r's band of N[1] / nranks rows (the role
+                          * of Partition(1, R) in the reference's DistributedArch, Distributed/multi_architectures.jl); its fields keep the
+                          * Bounded shape, fill_halos exchanges rows with the neighbouring bands.  ocn_hgrid_band reports the rows. */
 } ocn_hgrid_desc;
 int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* desc, ocn_hgrid** out);
+/* rows of the global grid this handle holds: first row (0-based offset j0) and count; global count; whole grid: 0, Ny, Ny */
+int ocn_hgrid_band(const ocn_hgrid* g, int32_t* j0, int32_t* ny_local, int32_t* ny_global);
 void ocn_hgrid_destroy(ocn_hgrid* g);
 /* metrics and nodes as the grid object holds them (grid.Δxᶠᶜᵃ ... latitude_longitude_grid.jl:418-445; grid.φᵃᶠᵃ ...): which =
  * 0 Δx^fc, 1 Δx^cf, 2 Δy^fc, 3 Δy^cf, 4 Az^cc (per row, first entry = row 1 - Hy), 5 Δz^c (levels 1..Nz), 6 / 7 x nodes Face /
