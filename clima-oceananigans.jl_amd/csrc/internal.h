@@ -202,6 +202,7 @@ void yfft_run(ocn_ctx* ctx, void* z, void* spec, int Nxh, int Ny, int Nz, int in
 void xfft_rhs_run(ocn_model* m, void* z, void* spec, double dt, int extra_plane = 0);
 bool poisson_local_wstar(const ocn_model* m);   // z-slab runs: the w* term above the slab enters in spectral space, no w* plane exchange
 bool fft_size_ok(int n);   // 128, 256, 512: sizes of the custom transform passes
+bool zsolve_size_ok(int n);   // those and 320, 384: sizes of the fused z stage
 bool poisson_custom_xy(const ocn_model* m);
 int poisson_run_from_predictor(ocn_model* m, double dt);   // fused rhs + custom x/y passes (fast path)
 

@@ -183,7 +183,7 @@ PoissonSolver* poisson_create(ocn_model* m) {
     double dz = g->L[2] / g->Nzg;
     s->dz2 = dz * dz;
   }
-  const bool want_zs = !use_slab && g->topo[2] == OCN_PERIODIC && fft_size_ok(g->dist ? g->Nzg : s->Nz) &&
+  const bool want_zs = !use_slab && g->topo[2] == OCN_PERIODIC && zsolve_size_ok(g->dist ? g->Nzg : s->Nz) &&
                        !(getenv("OCNHIP_NO_ZSOLVE") && atoi(getenv("OCNHIP_NO_ZSOLVE")) != 0);
   if (want_zs) {
     std::vector<double> lxh = eigenvalues_periodic(s->Nx, g->L[0]);

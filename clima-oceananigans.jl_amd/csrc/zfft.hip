@@ -314,6 +314,153 @@ __global__ void __launch_bounds__(256) k_zsolve(cd* __restrict__ a, long ncol, c
   }
 }
 
+
+// ---- fused z stage for Nz = 16 M with M = 20 or 24 (320 and 384 levels): mixed radix ----------------------------------------------
+// Same structure as k_zsolve: a workgroup owns 16 consecutive columns (256 contiguous bytes per level), M threads per column hold
+// 16 levels each (x[r + M n1]).  Stage 1: 16-point transform over n1 in registers, twiddle W_N^(r k1), transpose through LDS;
+// stage 2: the 16 transforms of length M of a column are taken by its first 16 threads (k1 = r < 16; 4 of 20 / 8 of 24 threads idle for
+// that stage), M points each in registers: 20 = 4 x 5 (five-point butterflies, twiddles, four-point butterflies), 24 = 8 x 3.  Eigenvalue
+// division on X[k1 + 16 k2], then the network backwards.  `tw`: exp(-2 pi i m / N), m = 0..N-1.
+template <int S> OCN_DEVFN void dft3(cd& a, cd& b, cd& c) {
+  const double H3 = 0.86602540378443864676;                      // sin(2 pi / 3)
+  const cd t1 = cadd(b, c), d = csub(b, c);
+  const cd t2 = cd{a.x - 0.5 * t1.x, a.y - 0.5 * t1.y};
+  const cd t3 = mul_mi<S>(cd{H3 * d.x, H3 * d.y});
+  a = cadd(a, t1);
+  b = cadd(t2, t3);
+  c = csub(t2, t3);
+}
+template <int S> OCN_DEVFN void dft5(cd& x0, cd& x1, cd& x2, cd& x3, cd& x4) {
+  const double C1 = 0.30901699437494742410, C2 = -0.80901699437494742410;     // cos(2 pi / 5), cos(4 pi / 5)
+  const double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917;      // sin(2 pi / 5), sin(4 pi / 5)
+  const cd t1 = cadd(x1, x4), t2 = cadd(x2, x3), t3 = csub(x1, x4), t4 = csub(x2, x3);
+  const cd a1 = cd{x0.x + C1 * t1.x + C2 * t2.x, x0.y + C1 * t1.y + C2 * t2.y};
+  const cd a2 = cd{x0.x + C2 * t1.x + C1 * t2.x, x0.y + C2 * t1.y + C1 * t2.y};
+  const cd b1 = mul_mi<S>(cd{S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y});
+  const cd b2 = mul_mi<S>(cd{S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y});
+  x0 = cadd(x0, cadd(t1, t2));
+  x1 = cadd(a1, b1);
+  x4 = csub(a1, b1);
+  x2 = cadd(a2, b2);
+  x3 = csub(a2, b2);
+}
+// W_M^m with the sign of the transform, from the table of N-th roots (N = 16 M)
+template <int M, int S> OCN_DEVFN cd rootM(const cd* tw, int m) {
+  cd w = tw[(16 * m) % (16 * M)];
+  if (S < 0) w.y = -w.y;
+  return w;
+}
+// in-place M-point DFT, natural order in and out
+template <int M, int S> OCN_DEVFN void dftM(cd* v, const cd* tw) {
+  if (M == 20) {
+    // n = a + 4 b, k = 5 c + d: five-point transforms over b, twiddles W20^(a d), four-point transforms over a
+#pragma unroll
+    for (int a = 0; a < 4; ++a) dft5<S>(v[a], v[a + 4], v[a + 8], v[a + 12], v[a + 16]);      // T[a][d] at v[a + 4 d]
+#pragma unroll
+    for (int a = 1; a < 4; ++a)
+#pragma unroll
+      for (int d = 1; d < 5; ++d) v[a + 4 * d] = cmul(v[a + 4 * d], rootM<M, S>(tw, a * d));
+#pragma unroll
+    for (int d = 0; d < 5; ++d) dft4<S>(v[4 * d], v[4 * d + 1], v[4 * d + 2], v[4 * d + 3]);  // X[5 c + d] at v[c + 4 d]
+    cd o[20];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int d = 0; d < 5; ++d) o[5 * c + d] = v[c + 4 * d];
+#pragma unroll
+    for (int q = 0; q < 20; ++q) v[q] = o[q];
+  } else {
+    // M = 24: n = a + 8 b, k = 3 c + d: three-point transforms over b, twiddles W24^(a d), eight-point transforms over a
+#pragma unroll
+    for (int a = 0; a < 8; ++a) dft3<S>(v[a], v[a + 8], v[a + 16]);                           // T[a][d] at v[a + 8 d]
+#pragma unroll
+    for (int a = 1; a < 8; ++a)
+#pragma unroll
+      for (int d = 1; d < 3; ++d) v[a + 8 * d] = cmul(v[a + 8 * d], rootM<M, S>(tw, a * d));
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dft8<S>(v + 8 * d);                                           // X[3 c + d] at v[c + 8 d]
+    cd o[24];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) o[3 * c + d] = v[c + 8 * d];
+#pragma unroll
+    for (int q = 0; q < 24; ++q) v[q] = o[q];
+  }
+}
+
+template <int M>
+__global__ void __launch_bounds__(16 * M) k_zsolve_mr(cd* __restrict__ a, long ncol, const double* __restrict__ lxy,
+                                                      const double* __restrict__ lz, const cd* __restrict__ tw, double norm, long zero_col) {
+  constexpr int N = 16 * M, K1S = 16 * M + 16;
+  OCN_SHARED double sm[16 * K1S];
+  const int c = threadIdx.x % 16, r = threadIdx.x / 16;            // r = n2 on the way in; the threads r < 16 take k1 = r in stage 2
+  const long gcol = (long)blockIdx.x * 16 + c;
+  const bool ok = gcol < ncol;
+  cd v[16];
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) v[n1] = ok ? a[gcol + ncol * (r + M * n1)] : cd{0, 0};
+  dft16<1>(v);
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], tw[(r * k1) % N]);
+  // transpose (k1, n2 = r) -> thread k1: image [k1][n2][c], one component at a time
+  cd z[M];
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) sm[k1 * K1S + r * 16 + c] = v[k1].x;
+  __syncthreads();
+  if (r < 16) {
+#pragma unroll
+    for (int n2 = 0; n2 < M; ++n2) z[n2].x = sm[r * K1S + n2 * 16 + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) sm[k1 * K1S + r * 16 + c] = v[k1].y;
+  __syncthreads();
+  if (r < 16) {
+#pragma unroll
+    for (int n2 = 0; n2 < M; ++n2) z[n2].y = sm[r * K1S + n2 * 16 + c];
+    dftM<M, 1>(z, tw);                                            // z[k2] = X[r + 16 k2]
+    // eigenvalue division (fft_based_poisson_solver.jl:106-111)
+    const double lc = ok ? lxy[gcol] : 1.0;
+#pragma unroll
+    for (int k2 = 0; k2 < M; ++k2) {
+      const int kz = r + 16 * k2;
+      double f = -norm / (lc + lz[kz]);
+      if (gcol == zero_col && kz == 0) f = 0.0;
+      z[k2].x *= f;
+      z[k2].y *= f;
+    }
+    dftM<M, -1>(z, tw);                                           // z[n2] = sum over k2 (k1 = r fixed)
+#pragma unroll
+    for (int n2 = 1; n2 < M; ++n2) {
+      cd w = tw[(r * n2) % N];
+      w.y = -w.y;
+      z[n2] = cmul(z[n2], w);
+    }
+  }
+  __syncthreads();
+  if (r < 16) {
+#pragma unroll
+    for (int n2 = 0; n2 < M; ++n2) sm[r * K1S + n2 * 16 + c] = z[n2].x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) v[k1].x = sm[k1 * K1S + r * 16 + c];
+  __syncthreads();
+  if (r < 16) {
+#pragma unroll
+    for (int n2 = 0; n2 < M; ++n2) sm[r * K1S + n2 * 16 + c] = z[n2].y;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) v[k1].y = sm[k1 * K1S + r * 16 + c];
+  dft16<-1>(v);                                                   // v[n1] = x[r + M n1], times N
+  if (ok) {
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) a[gcol + ncol * (r + M * n1)] = v[n1];
+  }
+}
+
 // ---- y-direction pass: in-place N-point FFT along ky of the half spectrum (Nxh, N, Nz) -------------------------------
 // Tiles of C columns.  Main tiles: C consecutive kx of one z-plane (contiguous in memory for every ky).  The
 // Nxh % C left-over kx columns are tiled over the flattened (kx_left, z) index.
@@ -445,12 +592,16 @@ __global__ void __launch_bounds__(256) k_xfft_rhs(GridDev g, const double* __res
 
 // host side ---------------------------------------------------------------------------------------------------
 struct ZSolve {
+  cd* twmr = nullptr;      // exp(-2 pi i m / N), N = 320 or 384: the mixed-radix z stage (created on first use)
+  int twmr_n = 0;
   cd* tw = nullptr;        // exp(-2 pi i m / 512), m = 0..511
   double* lxy = nullptr;
   long ncol = 0;
 };
 
 bool fft_size_ok(int n) { return n == 128 || n == 256 || n == 512; }
+// sizes the fused z stage serves: the three above and 16 x 20, 16 x 24 (mixed radix)
+bool zsolve_size_ok(int n) { return fft_size_ok(n) || n == 320 || n == 384; }
 
 void* zsolve_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std::vector<double>& ly_local) {
   // lxy[kx + Nxh * ky]
@@ -476,6 +627,7 @@ void* zsolve_create(ocn_ctx* ctx, const std::vector<double>& lx_half, const std:
 void zsolve_destroy(void* p) {
   ZSolve* z = (ZSolve*)p;
   if (!z) return;
+  hipFree(z->twmr);
   hipFree(z->tw);
   hipFree(z->lxy);
   delete z;
@@ -532,6 +684,29 @@ void xfft_rhs_run(ocn_model* m, void* p, void* spec, double dt, int extra_plane)
 // in place on the (ncol, Nz) spectrum; `zero_col` < 0 when this rank does not own the mean mode
 void zsolve_run(ocn_ctx* ctx, void* p, void* spec, int Nz, const double* lz, double norm, long zero_col) {
   ZSolve* z = (ZSolve*)p;
+  if (Nz == 320 || Nz == 384) {
+    if (z->twmr_n != Nz) {
+      std::vector<cd> t(Nz);
+      for (int m = 0; m < Nz; ++m) t[m] = {cos(2.0 * M_PI * m / Nz), -sin(2.0 * M_PI * m / Nz)};
+      hipStreamSynchronize(ctx->stream);
+      hipFree(z->twmr);
+      z->twmr = nullptr;
+      z->twmr_n = 0;
+      if (hipMalloc((void**)&z->twmr, sizeof(cd) * Nz) != hipSuccess) {
+        ocn_set_error(ctx, "zsolve: allocation failed");
+        return;
+      }
+      hipMemcpy(z->twmr, t.data(), sizeof(cd) * Nz, hipMemcpyHostToDevice);
+      z->twmr_n = Nz;
+    }
+    dim3 g((unsigned)((z->ncol + 15) / 16), 1, 1);
+    cd* a = (cd*)spec;
+    if (Nz == 320)
+      ocn_launch_sync(k_zsolve_mr<20>, g, dim3(320, 1, 1), ctx->stream, a, z->ncol, (const double*)z->lxy, lz, (const cd*)z->twmr, norm, zero_col);
+    else
+      ocn_launch_sync(k_zsolve_mr<24>, g, dim3(384, 1, 1), ctx->stream, a, z->ncol, (const double*)z->lxy, lz, (const cd*)z->twmr, norm, zero_col);
+    return;
+  }
   const int C = 256 / (Nz / 16);
   dim3 b(256, 1, 1), g((unsigned)((z->ncol + C - 1) / C), 1, 1);
   cd* a = (cd*)spec;
