@@ -55,7 +55,7 @@ class HydroDesc(C.Structure):
 
 class HGridDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("N", C.c_int32 * 3), ("H", C.c_int32 * 3), ("topology", C.c_int32 * 3),
-                ("x0", C.c_double * 3), ("L", C.c_double * 3), ("z_faces", C.POINTER(C.c_double)), ("radius", C.c_double), ("partition", C.c_int32)]
+                ("x0", C.c_double * 3), ("L", C.c_double * 3), ("z_faces", C.POINTER(C.c_double)), ("radius", C.c_double), ("partition", C.c_int32), ("band_overlap", C.c_int32)]
 
 
 NOTHING = 2

@@ -41,6 +41,9 @@ struct ocn_hgrid {
   // keeps the Bounded shape of its fields (Face-y fields hold N[1] + 1 rows: the last one is the upper neighbour's first, or the wall)
   bool slab = false;
   int gNy = 0, j0 = 0;
+  // an EXTENDED band (ocn_hgrid_desc.band_overlap = W): a stand-alone Bounded grid of the band's rows plus ext_lo / ext_hi rows of the
+  // neighbouring bands; rank / nranks remembered for the refresh of those rows (slab stays false: its fills are a plain grid's)
+  int ext_lo = 0, ext_hi = 0, own = 0, overlap = 0;
   bool wall_lo = true, wall_hi = true;      // the band touches the southern / northern wall (Bounded y) -- else a neighbour
   double *pack_s = nullptr, *pack_r = nullptr;
   size_t pack_n = 0;
@@ -688,9 +691,12 @@ __global__ void __launch_bounds__(256) k_hy_Guv(HyMetric g, HyPhys ph, const dou
   Gv[cv] = ((-Av - 0.0) - Cv) - py;
 }
 
+// NT tracers in one launch: the area-weighted velocities of the six faces are formed once and shared
+template <int NT>
 __global__ void __launch_bounds__(256) k_hy_Gc(HyMetric g, const double* __restrict__ u, const double* __restrict__ v,
-                                               const double* __restrict__ w, const double* __restrict__ c, double* __restrict__ Gc, int tadv,
-                                               long syu, long szu, long syv, long szv, long syc, long szc) {
+                                               const double* __restrict__ w, const double* __restrict__ c0, const double* __restrict__ c1,
+                                               double* __restrict__ G0, double* __restrict__ G1, int tadv, long syu, long szu, long syv, long szv,
+                                               long syc, long szc) {
   OCN_NO_CONTRACT
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
@@ -698,15 +704,25 @@ __global__ void __launch_bounds__(256) k_hy_Gc(HyMetric g, const double* __restr
   const long cu = (i + g.Hx) + (long)r * syu + (long)(k + g.Hz) * szu, cv = (i + g.Hx) + (long)r * syv + (long)(k + g.Hz) * szv;
   const long cc = (i + g.Hx) + (long)r * syc + (long)(k + g.Hz) * szc;
   if (!tadv) {
-    Gc[cc] = 0.0;
+    G0[cc] = 0.0;
+    if (NT > 1) G1[cc] = 0.0;
     return;
   }
   const double dz = g.dzc[k];
-  auto Fx = [&](int di) { return ((g.dyfc[r] * dz) * u[cu + di]) * (0.5 * (c[cc + di - 1] + c[cc + di])); };
-  auto Fy = [&](int dj) { return ((g.dxcf[r + dj] * dz) * v[cv + dj * syv]) * (0.5 * (c[cc + (dj - 1) * syc] + c[cc + dj * syc])); };
-  auto Fz = [&](int dk) { return (g.azcc[r] * w[cc + dk * szc]) * (0.5 * (c[cc + (dk - 1) * szc] + c[cc + dk * szc])); };
-  const double div = 1 / (g.azcc[r] * dz) * (((Fx(1) - Fx(0)) + (Fy(1) - Fy(0))) + (Fz(1) - Fz(0)));
-  Gc[cc] = -div;
+  const double ax0 = (g.dyfc[r] * dz) * u[cu], ax1 = (g.dyfc[r] * dz) * u[cu + 1];                  // Ax_q^fcc u at faces i, i + 1
+  const double ay0 = (g.dxcf[r] * dz) * v[cv], ay1 = (g.dxcf[r + 1] * dz) * v[cv + syv];            // Ay_q^cfc v at faces j, j + 1
+  const double az0 = g.azcc[r] * w[cc], az1 = g.azcc[r] * w[cc + szc];                              // Az_q^ccf w at faces k, k + 1
+  const double rv = 1 / (g.azcc[r] * dz);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const double* c = t ? c1 : c0;
+    const double cm = c[cc];
+    const double fx0 = ax0 * (0.5 * (c[cc - 1] + cm)), fx1 = ax1 * (0.5 * (cm + c[cc + 1]));
+    const double fy0 = ay0 * (0.5 * (c[cc - syc] + cm)), fy1 = ay1 * (0.5 * (cm + c[cc + syc]));
+    const double fz0 = az0 * (0.5 * (c[cc - szc] + cm)), fz1 = az1 * (0.5 * (cm + c[cc + szc]));
+    const double div = rv * (((fx1 - fx0) + (fy1 - fy0)) + (fz1 - fz0));
+    (t ? G1 : G0)[cc] = -div;
+  }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -878,10 +894,53 @@ static void hy_pressure_launch(ocn_hfield* p, const HyBuoy& q, const ocn_hfield*
 static bool is_loc(const ocn_hfield* f, const ocn_hgrid* g, int lx, int ly, int lz) {
   return f && f->g == g && f->loc[0] == lx && f->loc[1] == ly && f->loc[2] == lz;
 }
+
+// banded free surface: the overlap rows of the listed 2-D fields from the neighbouring bands' own rows -- whole parent rows are
+// contiguous, so the blocks travel straight out of and into the arrays; one grouped exchange (collective over the context's ranks)
+static int band_refresh(ocn_sefs* s, std::initializer_list<ocn_hfield*> fields) {
+  ocn_hgrid* g = s->g;
+  ocn_ctx* c = g->ctx;
+  const int W = g->overlap, Hy = g->H[1];
+  if (W <= 0) return OCN_OK;
+  std::vector<CommOp> sends, recvs;
+  int tag = 20;
+  for (ocn_hfield* f : fields) {
+    const size_t T0 = f->T[0];
+    const int extra = f->loc[1] == OCN_FACE ? 1 : 0;
+    auto at = [&](int row) { return f->d + (size_t)(Hy + row) * T0; };
+    if (g->ext_hi > 0) {    // upper neighbour: my top W own rows up, its bottom W (+1) own rows down into my upper overlap
+      sends.push_back({at(g->ext_lo + g->own - W), (size_t)W * T0 * sizeof(double), c->rank + 1, tag});
+      recvs.push_back({at(g->ext_lo + g->own), (size_t)(W + extra) * T0 * sizeof(double), c->rank + 1, tag + 1});
+    }
+    if (g->ext_lo > 0) {    // lower neighbour
+      sends.push_back({at(g->ext_lo), (size_t)(W + extra) * T0 * sizeof(double), c->rank - 1, tag + 1});
+      recvs.push_back({at(0), (size_t)W * T0 * sizeof(double), c->rank - 1, tag});
+    }
+    tag += 2;
+  }
+  return comm_exchange(c, sends, recvs);
+}
 // everything of ocn_sefs_step after the vertical integrals of the tendencies
 static int sefs_step_tail(ocn_sefs* s, double dt) {
   ocn_ctx* ctx = s->g->ctx;
   const double dtau = 2 * dt / s->substeps;                        // "we evolve for two times the dt" (:137)
+  if (s->g->overlap > 0) {
+    // banded: the overlap rows of the state and the forcing from the neighbours, then blocks of W substeps on the extended band (the
+    // artificial walls at its ends spoil one row per substep, from the outside in: after W substeps the band's own rows are still
+    // those of the whole-domain run) with a refresh of eta, U, V between blocks
+    const int W = s->g->overlap;
+    if (int rc = band_refresh(s, {s->eta, s->U, s->V, s->GU, s->GV})) return rc;
+    for (ocn_hfield* f : {s->U, s->V, s->GU, s->GV}) hfield_fill(f);
+    for (int first = 1; first <= s->substeps; first += W) {
+      const int count = s->substeps - first + 1 < W ? s->substeps - first + 1 : W;
+      if (int rc = ocn_sefs_substeps(s, dtau, first, count, 2)) return rc;
+      if (first + count <= s->substeps)
+        if (int rc = band_refresh(s, {s->eta, s->U, s->V})) return rc;
+    }
+    se_copy(ctx, s->eta->d, s->etabar->d, s->eta->n);
+    hfield_fill(s->eta);
+    return OCN_OK;
+  }
   hfield_fill(s->GU);
   hfield_fill(s->GV);
   if (int rc = ocn_sefs_substeps(s, dtau, 1, s->substeps, 2)) return rc;
@@ -906,7 +965,7 @@ static int hydro_allgather_rows(ocn_hydro* h) {
   ocn_sefs* s = h->fs;
   ocn_hgrid* lg = h->lg;
   ocn_ctx* c = lg->ctx;
-  if (!lg->slab) return OCN_OK;
+  if (!lg->slab || s->g->overlap > 0) return OCN_OK;
   const int R = c->nranks, nl = lg->N[1], Hy = lg->H[1];
   const bool per = lg->topo[1] == OCN_PERIODIC;
   ocn_hfield* fl[4] = {s->U, s->GU, s->V, s->GV};
@@ -951,10 +1010,17 @@ static void hydro_tendencies(ocn_hydro* h) {
   ocn_launch(k_hy_Guv, gr, b, g->ctx->stream, hy_metric(g), ph, (const double*)u->d, (const double*)v->d, (const double*)h->w->d, (const double*)p->d,
              h->gn[0]->d, h->gn[1]->d, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)p->T[0],
              (long)p->T[0] * p->T[1]);
-  for (size_t q = 0; q < h->c.size(); ++q)
-    ocn_launch(k_hy_Gc, gr, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d,
-               (const double*)h->c[q]->d, h->gn[2 + q]->d, h->phys.tadv, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0],
-               (long)v->T[0] * v->T[1], (long)p->T[0], (long)p->T[0] * p->T[1]);
+  for (size_t q = 0; q < h->c.size(); q += 2) {
+    const bool two = q + 1 < h->c.size();
+    const double *c0 = h->c[q]->d, *c1 = two ? h->c[q + 1]->d : nullptr;
+    double *G0 = h->gn[2 + q]->d, *G1 = two ? h->gn[3 + q]->d : nullptr;
+    if (two)
+      ocn_launch(k_hy_Gc<2>, gr, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d, c0, c1, G0, G1,
+                 h->phys.tadv, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)p->T[0], (long)p->T[0] * p->T[1]);
+    else
+      ocn_launch(k_hy_Gc<1>, gr, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d, c0, c1, G0, G1,
+                 h->phys.tadv, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)p->T[0], (long)p->T[0] * p->T[1]);
+  }
 }
 
 static bool same_shape(const ocn_hfield* a, const ocn_hfield* b) {
@@ -981,8 +1047,12 @@ int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* d, ocn_hgrid** out) {
     ocn_set_error(ctx, "ocn_hgrid_create: longitude must span at most 360 degrees, latitude must lie in [-90, 90] and be Bounded");
     return OCN_EINVAL;
   }
-  if (d->partition != 0 && d->partition != 1) return OCN_EINVAL;
+  if ((d->partition != 0 && d->partition != 1) || d->band_overlap < 0) return OCN_EINVAL;
   const bool slab = d->partition == 1 && ctx->nranks > 1;
+  if (slab && d->band_overlap > d->N[1] / ctx->nranks) {
+    ocn_set_error(ctx, "ocn_hgrid_create: an overlap of %d rows is wider than a band of %d", d->band_overlap, d->N[1] / ctx->nranks);
+    return OCN_EINVAL;
+  }
   if (slab && (d->N[1] % ctx->nranks != 0 || d->N[1] / ctx->nranks < d->H[1] + 1)) {
     ocn_set_error(ctx, "ocn_hgrid_create: %d rows do not split into %d bands of more than H = %d rows", d->N[1], ctx->nranks, d->H[1]);
     return OCN_EINVAL;
@@ -998,15 +1068,29 @@ int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* d, ocn_hgrid** out) {
   regular_axis(g->x0[1], g->L[1], g->N[1], g->H[1], g->topo[1], g->nodeF[1], g->nodeC[1], dy);
   if (slab) {
     // the band's rows of the GLOBAL node arrays (every metric below is then the global one of the same row, bit for bit)
-    const int nl = d->N[1] / ctx->nranks, j0 = nl * ctx->rank;
-    g->slab = true;
-    g->j0 = j0;
-    g->N[1] = nl;
+    int nl = d->N[1] / ctx->nranks, j0 = nl * ctx->rank;
     g->wall_lo = g->topo[1] != OCN_PERIODIC && ctx->rank == 0;
     g->wall_hi = g->topo[1] != OCN_PERIODIC && ctx->rank == ctx->nranks - 1;
+    g->own = nl;
+    if (d->band_overlap > 0) {
+      if (g->topo[1] == OCN_PERIODIC) {
+        delete g;
+        ocn_set_error(ctx, "ocn_hgrid_create: extended bands need a Bounded y (the global node arrays do not wrap)");
+        return OCN_EUNSUPPORTED;
+      }
+      g->overlap = d->band_overlap;
+      g->ext_lo = g->wall_lo ? 0 : d->band_overlap;
+      g->ext_hi = g->wall_hi ? 0 : d->band_overlap;
+      j0 -= g->ext_lo;
+      nl += g->ext_lo + g->ext_hi;
+    } else {
+      g->slab = true;
+    }
+    g->j0 = j0;
+    g->N[1] = nl;
     auto band = [&](std::vector<double>& v, int want) {
       std::vector<double> w(want);
-      for (int q = 0; q < want; ++q) w[q] = (j0 + q < (int)v.size()) ? v[j0 + q] : NAN;
+      for (int q = 0; q < want; ++q) w[q] = (j0 + q >= 0 && j0 + q < (int)v.size()) ? v[j0 + q] : NAN;
       v.swap(w);
     };
     band(g->nodeF[1], nl + 1 + 2 * g->H[1]);        // Bounded shape for every band
@@ -1285,8 +1369,12 @@ int ocn_sefs_substeps(ocn_sefs* s, double dtau, int first_index, int count, int 
   if (fuse && count >= 4 && !no_graph && !ctx->profiling) {
     uint64_t bits;
     memcpy(&bits, &dtau, 8);
+    // with uniform weights (the default) a recorded train serves any first index: the blocks of a banded sub-cycle share one graph
+    bool uniform = true;
+    for (size_t q = 1; q < s->wv.size(); ++q) uniform = uniform && s->wv[q] == s->wv[0] && s->wf[q] == s->wf[0];
+    const int kfirst = uniform ? 1 : first_index;
     for (auto& t : s->trains)
-      if (t.dtau_bits == bits && t.first == first_index && t.count == count && t.mode == (one ? 2 : 1) && t.exec) {
+      if (t.dtau_bits == bits && t.first == kfirst && t.count == count && t.mode == (one ? 2 : 1) && t.exec) {
         OCN_HIP_CHECK(ctx, hipGraphLaunch((hipGraphExec_t)t.exec, ctx->stream));
         s->graph_replays += 1;
         return api_done(ctx, OCN_OK);
@@ -1303,7 +1391,7 @@ int ocn_sefs_substeps(ocn_sefs* s, double dtau, int first_index, int count, int 
           hipGraphExecDestroy((hipGraphExec_t)s->trains.front().exec);
           s->trains.erase(s->trains.begin());
         }
-        s->trains.push_back({bits, first_index, count, one ? 2 : 1, (void*)exec});
+        s->trains.push_back({bits, kfirst, count, one ? 2 : 1, (void*)exec});
         OCN_HIP_CHECK(ctx, hipGraphLaunch(exec, ctx->stream));
         s->graph_replays += 1;
         return api_done(ctx, OCN_OK);
@@ -1429,9 +1517,12 @@ int ocn_hydro_create(const ocn_hydro_desc* d, ocn_hydro** out) {
   ocn_hgrid* g = d->u->g;                        // the grid of the 3-D fields
   ocn_ctx* ctx = fg->ctx;
   if (g != fg) {
-    bool ok = g->slab && !fg->slab && g->ctx == fg->ctx && g->kind == fg->kind && g->N[0] == fg->N[0] && g->gNy == fg->N[1] && g->N[2] == fg->N[2] &&
-              g->radius == fg->radius;
-    for (int q = 0; q < 3; ++q) ok = ok && g->H[q] == fg->H[q] && g->topo[q] == fg->topo[q] && g->x0[q] == fg->x0[q] && g->L[q] == fg->L[q];
+    // the free surface of a model on latitude bands: replicated on the whole grid, or banded on the extended band (band_overlap)
+    const bool banded = fg->overlap > 0;
+    bool ok = g->slab && !fg->slab && g->ctx == fg->ctx && g->kind == fg->kind && g->N[0] == fg->N[0] && g->N[2] == fg->N[2] && g->radius == fg->radius &&
+              g->gNy == (banded ? fg->gNy : fg->N[1]) && (!banded || (fg->own == g->N[1] && fg->j0 + fg->ext_lo == g->j0));
+    for (int q = 0; q < 3; ++q)
+      ok = ok && (g->H[q] == fg->H[q] || q == 1) && g->topo[q] == fg->topo[q] && g->x0[q] == fg->x0[q] && g->L[q] == fg->L[q];
     if (!ok) {
       ocn_set_error(ctx, "ocn_hydro_create: the 3-D fields must live on the free surface's grid or on a latitude band (partition = 1) of that very grid");
       return OCN_EINVAL;
@@ -1467,8 +1558,9 @@ int ocn_hydro_create(const ocn_hydro_desc* d, ocn_hydro** out) {
   ocn_hydro* h = new ocn_hydro;
   h->fs = d->free_surface;
   h->lg = g;
-  h->offU = (long)g->j0 * h->fs->U->T[0];
-  h->offV = (long)g->j0 * h->fs->V->T[0];
+  const long drow = (long)(g->j0 - fg->j0) + fg->H[1] - g->H[1];      // parent row of the free surface's arrays holding the model's parent row 0
+  h->offU = drow * h->fs->U->T[0];
+  h->offV = drow * h->fs->V->T[0];
   h->u = d->u; h->v = d->v; h->w = d->w; h->pHY = d->pHY;
   h->c.assign(d->tracers, d->tracers + d->ntracers);
   h->gn.assign(d->Gn, d->Gn + 2 + d->ntracers);

@@ -24,7 +24,7 @@ g_Earth = 9.80665
 
 
 class _HGrid:
-    def _create(self, ctx, kind, size, halo, topology, lo, ext, z, radius, partition=None):
+    def _create(self, ctx, kind, size, halo, topology, lo, ext, z, radius, partition=None, band_overlap=0):
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
         d = L.HGridDesc()
@@ -45,6 +45,8 @@ class _HGrid:
         if partition not in (None, "y"):
             raise ValueError("partition: None or 'y' (latitude bands over the context's ranks)")
         d.partition = 1 if partition == "y" else 0
+        d.band_overlap = int(band_overlap)
+        self.band_overlap = int(band_overlap)
         self.h = C.c_void_p()
         check(self.lib.ocn_hgrid_create(self.ctx.h, C.byref(d), C.byref(self.h)), self.ctx.h)
         j0, nl, ng = C.c_int32(), C.c_int32(), C.c_int32()
@@ -87,6 +89,12 @@ class _HGrid:
         cls, kw = self._ctor
         return cls(**kw)
 
+    def extended(self, overlap):
+        """the band extended by `overlap` rows towards each neighbouring band, as a stand-alone Bounded grid: what a banded free
+        surface sub-cycles on (ocn_hgrid_desc.band_overlap)"""
+        cls, kw = self._ctor
+        return cls(partition="y", band_overlap=int(overlap), **kw)
+
     def __del__(self):
         try:
             if self.h:
@@ -99,19 +107,20 @@ class _HGrid:
 class HRectilinearGrid(_HGrid):
     """RectilinearGrid(size, x, y, z, halo, topology) with regular x and y, for the hydrostatic pieces"""
 
-    def __init__(self, size, x, y, z, halo=(3, 3, 3), topology=(Periodic, Periodic, Bounded), arch=None, partition=None):
+    def __init__(self, size, x, y, z, halo=(3, 3, 3), topology=(Periodic, Periodic, Bounded), arch=None, partition=None, band_overlap=0):
         zr = z if len(z) == 2 else (z[0], z[-1])
         self._z0 = float(zr[0])
         self._ctor = (HRectilinearGrid, dict(size=size, x=x, y=y, z=z, halo=halo, topology=topology, arch=arch))
         self._create(arch, L.HGRID_RECTILINEAR, size, halo, topology, (x[0], y[0], zr[0]), (x[1] - x[0], y[1] - y[0], zr[1] - zr[0]), z, 0.0,
-                     partition)
+                     partition, band_overlap)
 
 
 class LatitudeLongitudeGrid(_HGrid):
     """LatitudeLongitudeGrid(size, longitude, latitude, z, halo, radius) -- Grids/latitude_longitude_grid.jl:174-213; regular
     longitude and latitude, metrics precomputed.  Topology as the reference chooses it: Periodic longitude iff it spans 360."""
 
-    def __init__(self, size, longitude, latitude, z, halo=(3, 3, 3), radius=R_Earth, topology=None, arch=None, partition=None):
+    def __init__(self, size, longitude, latitude, z, halo=(3, 3, 3), radius=R_Earth, topology=None, arch=None, partition=None,
+                 band_overlap=0):
         l1, l2 = longitude
         p1, p2 = latitude
         if not (l1 <= l2 and l2 - l1 <= 360 and -90 <= p1 <= p2 <= 90):
@@ -123,7 +132,8 @@ class LatitudeLongitudeGrid(_HGrid):
         self.radius = float(radius)
         self._ctor = (LatitudeLongitudeGrid, dict(size=size, longitude=longitude, latitude=latitude, z=z, halo=halo, radius=radius,
                                                   topology=topology, arch=arch))
-        self._create(arch, L.HGRID_LATLON, size, halo, topology, (l1, p1, zr[0]), (l2 - l1, p2 - p1, zr[1] - zr[0]), z, radius, partition)
+        self._create(arch, L.HGRID_LATLON, size, halo, topology, (l1, p1, zr[0]), (l2 - l1, p2 - p1, zr[1] - zr[0]), z, radius, partition,
+                     band_overlap)
 
 
 class HField:
@@ -306,7 +316,8 @@ class HydrostaticState:
     tracers, G^n and G^- of the prognostic fields, pHY' and the free surface (hydrostatic_free_surface_model.jl:92-211)"""
 
     def __init__(self, grid, tracers=("T", "S"), buoyancy=None, substeps=20, gravitational_acceleration=g_Earth, free_surface=None,
-                 momentum_advection="VectorInvariantEnstrophyConserving", coriolis=None, tracer_advection="CenteredSecondOrder"):
+                 momentum_advection="VectorInvariantEnstrophyConserving", coriolis=None, tracer_advection="CenteredSecondOrder",
+                 barotropic_overlap=0):
         self.grid, self.lib = grid, grid.lib
         self.chi = 0.1
         self.u, self.v, self.w = Field3(grid, Face, Center), Field3(grid, Center, Face), Field3(grid, Center, Center, Face)
@@ -317,8 +328,10 @@ class HydrostaticState:
         self.Gm = {n: Field3(grid, *loc.get(n, (Center, Center))) for n in names}
         self.pHY = Field3(grid, Center, Center)
         self.buoyancy = buoyancy
-        # on latitude bands the free surface is replicated: it lives on the whole grid, every rank sub-cycles all of it
-        self.free_surface = free_surface or SplitExplicitFreeSurface(grid.whole(), gravitational_acceleration, substeps)
+        # on latitude bands the free surface is replicated (it lives on the whole grid, every rank sub-cycles all of it) or, with
+        # barotropic_overlap = W > 0, banded: it lives on the band extended by W rows and refreshes them every W substeps
+        fsgrid = grid.whole() if not (grid.partition and barotropic_overlap) else grid.extended(barotropic_overlap)
+        self.free_surface = free_surface or SplitExplicitFreeSurface(fsgrid, gravitational_acceleration, substeps)
         d = L.HydroDesc()
         d.free_surface = self.free_surface.h
         d.u, d.v, d.w, d.pHY = self.u.h, self.v.h, self.w.h, self.pHY.h

@@ -268,6 +268,10 @@ typedef struct ocn_hgrid_desc {
                           * first): N, x0, L describe the GLOBAL grid, the handle is rank r's band of N[1] / nranks rows (the role
                           * of Partition(1, R) in the reference's DistributedArch, Distributed/multi_architectures.jl); its fields keep the
                           * Bounded shape, fill_halos exchanges rows with the neighbouring bands.  ocn_hgrid_band reports the rows. */
+  int32_t band_overlap;  /* with partition = 1: W > 0 makes the handle the band EXTENDED by W rows towards each neighbouring band (none
+                          * towards a wall), as a stand-alone Bounded grid -- what a banded SplitExplicitFreeSurface lives on: it sub-cycles
+                          * W substeps on the extended rows (the artificial walls spoil one row per substep from the outside in) and
+                          * refreshes the overlap rows from the neighbours.  0: the plain band. */
 } ocn_hgrid_desc;
 int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* desc, ocn_hgrid** out);
 /* rows of the global grid this handle holds: first row (0-based offset j0) and count; global count; whole grid: 0, Ny, Ny */

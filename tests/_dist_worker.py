@@ -149,8 +149,9 @@ def main():
         poisson_case(ocn, O, ctx, rank, world)
     elif case.startswith("hydro_bands"):   # HydrostaticFreeSurfaceModel on latitude bands, replicated free surface (config 5's layout)
         import test_hydrostatic_bands as hb
-        gridname = case.split(":")[1]
-        hb.band_check(hb.band_run(ocn, ctx, rank, world, gridname, 3, 150.0), hb.run_single_domain_oracle(gridname, 3, 150.0))
+        gridname = case.split(":")[1]                                      # "hydro_bands:<grid>[:<overlap rows of a banded free surface>]"
+        overlap = int(case.split(":")[2]) if case.count(":") > 1 else 0
+        hb.band_check(hb.band_run(ocn, ctx, rank, world, gridname, 3, 150.0, overlap=overlap), hb.run_single_domain_oracle(gridname, 3, 150.0))
     else:
         raise SystemExit(f"unknown case {case}")
     dist.barrier()

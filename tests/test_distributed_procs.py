@@ -53,7 +53,8 @@ CPU_CASES = [("zslab_ab2", 2, {}), ("zslab_ab2", 2, {"OCNHIP_DIST_SOLVER": "tran
              ("poisson", 2, {}), ("poisson", 2, {"OCNHIP_DIST_SOLVER": "transpose"}), ("yslab_amd", 2, {}),
              ("yslab_scalar", 3, {}),
              ("zslab_custom", 2, {"OCNHIP_OVERLAP": "1"}),     # 128 x 128 x 16 on two processes: the local w* term (two exchanges per step)
-             ("hydro_bands:sphere", 2, {}), ("hydro_bands:periodic_box", 4, {})]   # the hydrostatic model on latitude bands
+             ("hydro_bands:sphere", 2, {}), ("hydro_bands:periodic_box", 4, {}),   # the hydrostatic model on latitude bands, replicated free surface
+             ("hydro_bands:sphere:3", 4, {})]                                      # ... and the free surface banded with 3 overlap rows
 
 
 @pytest.mark.parametrize("case,world,env", CPU_CASES, ids=[f"{c}-{w}-{'-'.join(e.values()) or 'green'}" for c, w, e in CPU_CASES])
@@ -114,7 +115,8 @@ def test_bench_falls_back_to_shm_when_rccl_cannot_start():
 GPU_CASES = [("zslab_ab2", {"OCNHIP_OVERLAP": "1"}), ("zslab_rk3_tracer", {"OCNHIP_DIST_SOLVER": "transpose", "OCNHIP_OVERLAP": "1"}),
              ("zslab_wide", {}), ("zslab_custom", {"OCNHIP_OVERLAP": "1"}), ("zslab_custom", {"OCNHIP_WSTAR_EXCHANGE": "1"}),
              ("zslab_custom", {"OCNHIP_PHI_EXCHANGE": "1"}),
-             ("yslab_amd", {}), ("poisson", {}), ("hydro_bands:sphere", {}), ("hydro_bands:sector", {})]
+             ("yslab_amd", {}), ("poisson", {}), ("hydro_bands:sphere", {}), ("hydro_bands:sector", {}),
+             ("hydro_bands:sphere:4", {})]
 
 
 @pytest.mark.gpu
@@ -127,7 +129,8 @@ def test_library_two_ranks_one_gpu(case, env):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,env", [("zslab_custom", {"OCNHIP_OVERLAP": "1"}), ("zslab_rk3_tracer", {"OCNHIP_OVERLAP": "1"}),
-                                      ("hydro_bands:sphere", {})], ids=["zslab_custom", "zslab_rk3_tracer", "hydro_bands"])
+                                      ("hydro_bands:sphere", {}), ("hydro_bands:sphere:3", {})],
+                         ids=["zslab_custom", "zslab_rk3_tracer", "hydro_bands", "hydro_bands_banded"])
 def test_library_four_ranks_one_gpu(case, env):
     """four processes on the one MI355X (the box allows six): the carries of the slab Poisson solve run over three other ranks and
     the slab's own periodic image, the halo ring has four members -- closer to config 4's eight than the two-rank runs"""

@@ -54,4 +54,29 @@ ctx.sync()
 out["split_explicit_free_surface_step_ms"] = (time.perf_counter() - t0) / 5 * 1e3
 out["graph_replays"] = sefs.graph_replays
 out["finite"] = bool(np.isfinite(sefs.eta.parent()).all())
+# one band of an 8-rank run with a BANDED free surface: Ny / 8 own rows + 2 W overlap rows, 200 substeps in blocks of W (the refresh of
+# the overlap rows between blocks is the only thing missing here: one rank) -- the kernel side of DESIGN.md section 7's projection
+out["band_subcycle"] = {}
+for W in (10, 20, 25, 40):
+    rows = Ny // 8 + 2 * W
+    lat = 150.0 * rows / Ny
+    bg = H.LatitudeLongitudeGrid(size=(Nx, rows, Nz), longitude=(-180, 180), latitude=(-lat / 2, lat / 2), z=(-4000, 0), halo=(3, 3, 3))
+    bs = H.SplitExplicitFreeSurface(bg, substeps=substeps)
+    bs.eta.set(0.1 * rng.standard_normal((Nx, rows)))
+
+    def cycle():
+        first = 1
+        while first <= substeps:
+            n = min(W, substeps - first + 1)
+            bs.substeps_train(dtau, first, n, fused=2)
+            first += n
+    for _ in range(3):
+        cycle()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        cycle()
+    ctx.sync()
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    out["band_subcycle"][f"W={W}"] = {"rows": rows, "blocks": -(-substeps // W), "ms_per_200_substeps": ms, "graph_replays": bs.graph_replays}
 print(json.dumps(out))
