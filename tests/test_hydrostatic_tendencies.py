@@ -163,3 +163,65 @@ def test_physics_arguments_are_checked(kind, ocn, backend):
         st.set_physics("VectorInvariantEnstrophyConserving", SPHERICAL + ("EnergyConserving",), "CenteredSecondOrder")   # no latitude on a box
     with pytest.raises(KeyError):
         st.set_physics("WENO5", None, "CenteredSecondOrder")
+
+
+# ---- BASELINE config 5 at its own size, through size-independent properties ---------------------------------------------------------
+@pytest.mark.gpu
+def test_config5_full_size_properties(ocn):
+    _config5_properties(ocn, (1024, 512, 128), 200)
+
+
+def test_config5_miniature_properties_hostemu(ocn, backend):
+    if backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    _config5_properties(ocn, (32, 24, 8), 12)
+
+
+def _config5_properties(ocn, size, substeps):
+    """1024 x 512 x 128 LatitudeLongitudeGrid, T and S with a linear equation of state, spherical Coriolis, 200 substeps, four whole
+    time steps of a zonally symmetric jet with a temperature front:
+      * a zonally symmetric state stays zonally symmetric BIT FOR BIT (every column of a latitude circle runs the same arithmetic);
+      * (u, v, w) satisfy the discrete continuity equation below the surface cell;
+      * the volume integrals of T and S are conserved to round-off (flux form, no flux through walls, bottom or the zeroed top face);
+      * the area mean of eta is conserved by the sub-cycle (test_split_explicit_free_surface_solver.jl:244-251 asserts the same of one
+        substep train) and nothing blows up."""
+    H = ocn.hydrostatic
+    Nx, Ny, Nz = size
+    grid = H.LatitudeLongitudeGrid(size=(Nx, Ny, Nz), longitude=(-180, 180), latitude=(-75, 75), z=(-4000, 0), halo=(3, 3, 3))
+    st = H.HydrostaticState(grid, tracers=("T", "S"), buoyancy=TS, substeps=substeps, coriolis=SPHERICAL + ("EnstrophyConserving",))
+    st.u.set(lambda x, y, z: 15 * np.cos(np.pi * y / 180) ** 2 * np.exp(z / 1500) + 0 * x)
+    st.tracers["T"].set(lambda x, y, z: 20 * np.cos(np.pi * y / 180) + 5e-3 * z + 0 * x)
+    st.tracers["S"].set(lambda x, y, z: 35 + 0.5 * np.sin(np.pi * y / 90) + 0 * x + 0 * z)
+    H.update_state(st)
+    og = OS.LatitudeLongitudeGrid(size=(8, Ny, Nz), longitude=(-180, 180), latitude=(-75, 75), z=(-4000, 0), halo=(3, 3, 3))
+    vol = (og.Az_cc[3:3 + Ny].reshape(1, -1, 1) * og.dz_centers().reshape(1, 1, -1))
+    area = og.Az_cc[3:3 + Ny].reshape(1, -1)
+
+    def integrals():
+        return [float((st.tracers[n].interior() * vol).sum()) for n in ("T", "S")] + [float((st.free_surface.eta.interior().reshape(Nx, Ny) * area).sum())]
+    before = integrals()
+    for q in range(4):
+        H.time_step(st, 60.0, euler=(q == 0))
+    after = integrals()
+    scale = [float((np.abs(st.tracers[n].interior()) * vol).sum()) for n in ("T", "S")]
+    for b, a, s in zip(before[:2], after[:2], scale):
+        assert abs(a - b) <= 1e-12 * s, (b, a)
+    eta = st.free_surface.eta.interior().reshape(Nx, Ny)
+    assert abs(after[2] - before[2]) <= 1e-10 * float((np.abs(eta) * area).sum() + area.sum() * 1e-6)
+    u, v, w = st.u.parent(), st.v.parent(), st.w.parent()
+    for a in (u, v, w, eta.reshape(Nx, Ny, 1), st.tracers["T"].interior()):
+        assert np.isfinite(a).all()
+        core = a[3:3 + Nx] if a.shape[0] > Nx else a
+        assert np.array_equal(core, np.broadcast_to(core[:1], core.shape)), "zonal symmetry lost"
+    assert np.abs(v).max() > 0 and np.abs(w).max() > 0          # the jet is not balanced: it does evolve
+    I, J = slice(3, 3 + Nx), slice(3, 3 + Ny)
+    row = lambda m: m[3:3 + Ny].reshape(1, -1)            # noqa: E731
+    rowp = lambda m: m[4:4 + Ny].reshape(1, -1)           # noqa: E731
+    dz = og.dz_centers()
+    worst = 0.0
+    for k in range(1, Nz):
+        div = 1 / row(og.Az_cc) * ((row(og.dy_fc) * u[4:4 + Nx, J, 3 + k - 1] - row(og.dy_fc) * u[I, J, 3 + k - 1])
+                                   + (rowp(og.dx_cf) * v[I, 4:4 + Ny, 3 + k - 1] - row(og.dx_cf) * v[I, J, 3 + k - 1]))
+        res = div + (w[I, J, 3 + k] - w[I, J, 3 + k - 1]) / dz[k - 1]
+        worst = max(worst, float(np.abs(res).max() / max(np.abs(div).max(), 1e-300)))
+    assert worst < 1e-12
