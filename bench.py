@@ -213,6 +213,112 @@ def spawn_ranks(args):
     raise SystemExit(rc)
 
 
+
+# ---- BASELINE config 5: HydrostaticFreeSurfaceModel on a LatitudeLongitudeGrid, SplitExplicitFreeSurface --------------------------
+B_ALG_C5_3D = 41 * 8.0      # field sweeps of one time step per 3-D cell: tendencies 13 (u, v, w, pHY' read + G_u, G_v written; u, v, w + T, S read +
+                            # G_T, G_S written), the merged passes after them 28
+B_ALG_C5_2D = 128.0         # per 2-D cell and barotropic substep (eta, U, V, the three averages read and written, G^U, G^V, H^fc, H^cf read)
+
+
+def run_config5(args, ocn, ctx, dist, rank, world, transport, real_stdout):
+    """1024 x 512 x 128, T and S with a linear equation of state, HydrostaticSphericalCoriolis, VectorInvariant momentum advection,
+    CenteredSecondOrder tracer advection, 200 barotropic substeps; one GPU, or latitude bands with a banded free surface (N ranks)"""
+    import numpy as np
+    H = ocn.hydrostatic
+    Nx, Ny, Nz = tuple(args.size) if args.size else ((32, 8 * world, 4) if args.rehearse_hostemu else (1024, 512, 128))
+    substeps = 12 if args.rehearse_hostemu else 200
+    kw = dict(size=(Nx, Ny, Nz), longitude=(-180, 180), latitude=(-75, 75), z=(-4000, 0), halo=(3, 3, 3), arch=ctx)
+    overlap = min(20, Ny // world) if world > 1 else 0
+    grid = H.LatitudeLongitudeGrid(partition="y" if world > 1 else None, **kw)
+    st = H.HydrostaticState(grid, tracers=("T", "S"), buoyancy=("TS", 9.80665, 1.67e-4, 7.8e-4, "T", "S"), substeps=substeps,
+                            coriolis=("HydrostaticSphericalCoriolis", 7.292115e-5, "EnstrophyConserving"), barotropic_overlap=overlap)
+    # solid-body rotation in balance with the free surface (Williamson et al. 1992, case 2): stays bounded however many steps are timed
+    R, Om, U0, g = 6371.0e3, 7.292115e-5, 10.0, 9.80665
+    st.u.set(lambda x, y, z: U0 * np.cos(np.pi * y / 180) + 0 * x + 0 * z)
+    st.free_surface.eta.set(lambda x, y: -(R * Om * U0 + U0 ** 2 / 2) * np.sin(np.pi * y / 180) ** 2 / g + 0 * x)
+    st.tracers["T"].set(lambda x, y, z: 20 * np.cos(np.pi * y / 180) + 5e-3 * z + 0 * x)
+    st.tracers["S"].set(35.0)
+    H.update_state(st)
+    dt = 60.0
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+    H.time_step(st, dt, euler=True)
+    for _ in range(max(args.warmup - 1, 0)):
+        H.time_step(st, dt)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        H.time_step(st, dt)
+    ctx.sync()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t[0])
+    ms = el / args.steps * 1e3
+    cells = Nx * Ny * Nz
+    value = cells / (ms * 1e-3)
+    vmax = float(np.abs(st.v.interior()).max())
+    finite = bool(np.isfinite(st.u.interior()).all())
+    if rank != 0:
+        return
+    b_alg = B_ALG_C5_3D + B_ALG_C5_2D * substeps / Nz
+    out = {"metric": "cell-updates/sec per time_step!, 1024x512x128 HydrostaticFreeSurfaceModel (BASELINE config 5)", "value": value,
+           "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+           "data": ("rehearsal on the host emulation of the kernels: plumbing check, NOT a measurement" if args.rehearse_hostemu else
+                    "synthetic; REHEARSAL: ranks share GPUs and exchange through host shared memory -- not a scaling measurement"
+                    if world > 1 and transport and transport.startswith("shm") else "synthetic"),
+           "config": {"workload": f"{Nx}x{Ny}x{Nz} LatitudeLongitudeGrid, HydrostaticFreeSurfaceModel, SplitExplicitFreeSurface ({substeps} substeps), "
+                                  "VectorInvariant momentum advection, CenteredSecondOrder tracers T + S, linear equation of state, "
+                                  "HydrostaticSphericalCoriolis, AB2 (BASELINE config 5 without closures)",
+                      "decomposition": f"latitude bands x{world}" + (f", banded free surface with {overlap} overlap rows" if world > 1 else ""),
+                      "dt": dt, "init": "solid-body rotation in balance with the free surface", "transport": transport},
+           # the whole step against the HBM roofline (no single kernel dominates: sub-cycle 29 %, k_hy_Guv 16 %, k_hy_tracers 13 %);
+           # duration = the timed region itself (host clock between stream synchronisations)
+           "roofline": {"bound": "hbm", "kernel": "time_step! (all launches)", "achieved": value / world * b_alg / 1e9, "peak": (HBM_PEAK / 1e9),
+                        "unit": "GB/s", "frac": value / world * b_alg / 1e9 / (HBM_PEAK / 1e9), "traffic": None,
+                        "alg_bytes_per_cell_update": b_alg},
+           "max_abs_v": vmax, "finite": finite, "cpu_baseline": None}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_config5()
+    line = json.dumps(out)
+    if real_stdout is not None:
+        sys.stdout.flush()
+        os.write(real_stdout, (line + "\n").encode())
+    else:
+        print(line)
+
+
+def cpu_baseline_config5():
+    """the NumPy oracle (oracle/hydrostatic.py: the checker, timed here as the CPU baseline) on a bounded sample of config 5:
+    128 x 64 x 16 cells, 20 substeps, two time steps on one core"""
+    import numpy as np
+    from oracle import hydrostatic as OH
+    from oracle import split_explicit as OS
+    N = (128, 64, 16)
+    g = OS.LatitudeLongitudeGrid(size=N, longitude=(-180, 180), latitude=(-75, 75), z=(-4000, 0), halo=(3, 3, 3))
+    st = OH.HydrostaticState(g, tracers=("T", "S"), buoyancy=("TS", 9.80665, 1.67e-4, 7.8e-4, "T", "S"), substeps=20,
+                             coriolis=("HydrostaticSphericalCoriolis", 7.292115e-5, "EnstrophyConserving"))
+    st.u.set(lambda x, y, z: 10 * np.cos(np.pi * y / 180) + 0 * x + 0 * z)
+    st.tracers["T"].set(lambda x, y, z: 20 + 5e-3 * z + 0 * x + 0 * y)
+    st.tracers["S"].set(35.0)
+    OH.update_state(st)
+    OH.time_step(st, 60.0, euler=True)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 10.0:
+        OH.time_step(st, 60.0)
+        n += 1
+    el = time.perf_counter() - t0
+    return {"value": N[0] * N[1] * N[2] * n / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{N[0]}x{N[1]}x{N[2]} cells, 20 substeps, {n} NumPy-oracle time steps in {el:.1f} s (single thread)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,7 +332,7 @@ def main():
     ap.add_argument("--tracers", type=int, default=0, help="passive tracers (config 2b: 1)")
     ap.add_argument("--nu", type=float, default=0.0, help="config 2 with ScalarDiffusivity(nu = kappa = NU) (DNS-style; 0: inviscid headline)")
     ap.add_argument("--topology", default="PPP", help="config 2 with other x/y/z topologies, e.g. PBB (debug / widening rows)")
-    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (headline, default), 1 (2-D turbulence) or 3 (ocean LES)")
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (headline, default), 1 (2-D turbulence), 3 (ocean LES) or 5 (hydrostatic model on the sphere)")
     ap.add_argument("--lib", default=None, help="another build of libocnhip.so (kernel experiments; never the host emulation)")
     ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
                     help="N > 1: strong = 256^3 on 2 / 4 GPUs and config 4 (512x512x256) on 8; weak = 256x256x256N")
@@ -293,6 +399,11 @@ def main():
     else:
         Nglobal = (256, 256, 256)
     extent = tuple(float(x) / Nglobal[0] for x in Nglobal)    # cubic cells, x extent 1
+    if args.config == 5:
+        run_config5(args, ocn, ctx, dist, rank, world, transport, real_stdout)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.config == 3:
         model, dt3, Nglobal, n = build_config3(ocn, ctx, args)
     elif args.config == 1:

@@ -82,6 +82,22 @@ def test_bench_spawns_its_ranks_hostemu(backend):
     assert rec["max_abs_divergence"] < 1e-10
 
 
+def test_bench_config5_on_two_ranks_hostemu(backend):
+    """`python bench.py --config 5 --gpus 2`: the hydrostatic model on two latitude bands with a banded free surface, ranks spawned by
+    the bench itself (plumbing rehearsal on the host emulation)"""
+    if backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OCNHIP_LIB"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--gpus", "2", "--rehearse-hostemu", "--steps", "2",
+                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and "latitude bands x2, banded free surface" in rec["config"]["decomposition"]
+    assert rec["finite"] and rec["max_abs_v"] < 1e-3 and "NOT a measurement" in rec["data"]
+
+
 def test_bench_refuses_missing_gpus():
     """--gpus N on a node with fewer GPUs exits non-zero instead of silently measuring one GPU"""
     env = dict(os.environ)
