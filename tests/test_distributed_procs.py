@@ -128,6 +128,21 @@ def test_bench_falls_back_to_shm_when_rccl_cannot_start():
     assert "REHEARSAL" in rec["data"] and rec["max_abs_divergence"] < 1e-10
 
 
+@pytest.mark.gpu
+def test_bench_config5_two_ranks_one_gpu():
+    """`python bench.py --config 5 --gpus 2` with both ranks on the one GPU of the box (RCCL refuses the duplicate device, the ranks
+    agree on the shared-memory transport): latitude bands, banded free surface, libocnhip.so"""
+    env = dict(os.environ, OCNHIP_BENCH_NDEV="1", OCNHIP_COMM_TIMEOUT_S="60")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OCNHIP_LIB", "OCNHIP_TRANSPORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--gpus", "2", "--steps", "3", "--warmup", "1", "--size",
+                          "128", "64", "16", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["transport"].startswith("shm") and "banded free surface" in rec["config"]["decomposition"]
+    assert rec["finite"] and "REHEARSAL" in rec["data"]
+
+
 GPU_CASES = [("zslab_ab2", {"OCNHIP_OVERLAP": "1"}), ("zslab_rk3_tracer", {"OCNHIP_DIST_SOLVER": "transpose", "OCNHIP_OVERLAP": "1"}),
              ("zslab_wide", {}), ("zslab_custom", {"OCNHIP_OVERLAP": "1"}), ("zslab_custom", {"OCNHIP_WSTAR_EXCHANGE": "1"}),
              ("zslab_custom", {"OCNHIP_PHI_EXCHANGE": "1"}),
