@@ -237,7 +237,8 @@ class SplitExplicitFreeSurface:
         check(self.lib.ocn_sefs_substep(self.h, float(dtau), int(substep_index)), self.grid.ctx.h)
 
     def substeps_train(self, dtau, first, count, fused=True):
-        """fused: False / 0 the reference's five launches per substep, True / 1 two launches, 2 one launch (hipGraph trains)"""
+        """fused: False / 0 the reference's five launches per substep, True / 1 two launches, 2 one launch, 3 four substeps per
+        launch (hipGraph trains)"""
         check(self.lib.ocn_sefs_substeps(self.h, float(dtau), int(first), int(count), int(fused)), self.grid.ctx.h)
 
     @property

@@ -302,8 +302,10 @@ int ocn_sefs_set_weights(ocn_sefs* s, int n, const double* velocity_weights, con
 /* split_explicit_free_surface_substep!(η, state, auxiliary, settings, arch, grid, g, Δτ, substep_index)  (kernels.jl:31-58) */
 int ocn_sefs_substep(ocn_sefs* s, double dtau, int substep_index);
 /* `for substep in first:first+count-1 substep!(...) end` (kernels.jl:154-156).  fused = 1: two launches per substep instead
- * of five; fused = 2: one (eta, U, V double buffered inside the object); either way the whole train is replayed from a hipGraph
- * and leaves the same bits in every parent array, halos included.  0: the reference's five launches. */
+ * of five; fused = 2: one (eta, U, V double buffered inside the object); fused = 3: four substeps per launch on tiles with a ring
+ * of four ghost cells (grids of 64 x 16 cells and more; smaller ones run as 2), the last substep of the train by the one-launch
+ * kernel; whichever, the whole train is replayed from a hipGraph and leaves the same bits in every parent array, halos included.
+ * 0: the reference's five launches. */
 int ocn_sefs_substeps(ocn_sefs* s, double dtau, int first_index, int count, int fused);
 int ocn_sefs_graph_replays(const ocn_sefs* s, int64_t* replays);
 /* barotropic_mode!(U, V, grid, u, v) (:76-81): into_forcing == 0 -> state.U, state.V; != 0 -> auxiliary.Gᵁ, Gⱽ */

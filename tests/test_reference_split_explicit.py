@@ -319,21 +319,23 @@ def test_step_on_the_sphere_matches_oracle(kind, ocn, backend):
         assert np.abs(x - y).max() <= 1e-12 * np.abs(x).max()
 
 
+@pytest.mark.parametrize("size", [(40, 24), (72, 20), pytest.param((200, 90), marks=pytest.mark.gpu)], ids=["40x24", "72x20", "200x90"])
 @pytest.mark.parametrize("topo_y", [P, B])
 @pytest.mark.parametrize("kind", ["hostemu", pytest.param("gpu", marks=pytest.mark.gpu)])
-def test_fused_train_is_bitwise_the_plain_substeps(kind, topo_y, ocn, backend):
-    """ocn_sefs_substeps(fused = 1) -- two launches per substep, replayed from a hipGraph on the GPU -- leaves exactly the bits
+def test_fused_train_is_bitwise_the_plain_substeps(kind, topo_y, size, ocn, backend):
+    """ocn_sefs_substeps(fused = 1, 2, 3) -- two launches per substep, one launch per substep, four substeps per launch (tiles with
+    ghost rings; from 64 x 16 cells up: 72 x 20 and 200 x 90 have ragged last tiles), replayed from hipGraphs on the GPU -- leave exactly the bits
     of the reference's five-launch substeps in every parent array, halos included (periodic and wall-bounded y)"""
     be = _backend(kind, ocn, backend)
     out = []
-    for fused in (0, 1, 2):
+    for fused in (0, 1, 2, 3):
         if topo_y == P:
-            grid = be.HRectilinearGrid(size=(40, 24, 4), x=(0, 3.0), y=(0, 2.0), z=(-100, 0), halo=(3, 3, 3), topology=(P, P, B))
+            grid = be.HRectilinearGrid(size=size + (4,), x=(0, 3.0), y=(0, 2.0), z=(-100, 0), halo=(3, 3, 3), topology=(P, P, B))
         else:
-            grid = be.LatitudeLongitudeGrid(size=(40, 24, 4), longitude=(-180, 180), latitude=(-70, 70), z=(-100, 0), halo=(3, 3, 3))
+            grid = be.LatitudeLongitudeGrid(size=size + (4,), longitude=(-180, 180), latitude=(-70, 70), z=(-100, 0), halo=(3, 3, 3))
         sefs = be.SplitExplicitFreeSurface(grid, substeps=10)
         rng = np.random.default_rng(8)
-        sefs.eta.set(rng.standard_normal((40, 24)))
+        sefs.eta.set(rng.standard_normal(size))
         sefs.GU.set(1e-3 * rng.standard_normal(sefs.GU.interior().shape))
         sefs.GV.set(1e-3 * rng.standard_normal(sefs.GV.interior().shape))
         sefs.GU.fill_halo_regions()
@@ -344,10 +346,12 @@ def test_fused_train_is_bitwise_the_plain_substeps(kind, topo_y, ocn, backend):
         for rep in range(3):                              # the second and third call replay the recorded train
             sefs.substeps_train(dtau, 1, 10, fused=fused)
         sefs.substeps_train(dtau, 1, 7, fused=fused)      # an odd train: the one-launch form ends in its second set and copies home
+        sefs.substeps_train(dtau, 3, 2, fused=fused)      # 1 + 1 substeps
+        sefs.substeps_train(dtau, 2, 6, fused=fused)      # 4 + 1 + 1: a short multi-substep launch in the middle
         out.append(sefs)
         if fused and kind == "gpu":
             assert sefs.graph_replays >= 3
-    for other in out[1:]:                                   # two launches per substep, one launch per substep
+    for other in out[1:]:                                   # two launches per substep, one launch per substep, four substeps per launch
         for name in ("eta", "U", "V", "etabar", "Ubar", "Vbar"):
             x, y = getattr(out[0], name).parent(), getattr(other, name).parent()
             assert np.isfinite(x).all() and np.array_equal(x, y), name
