@@ -31,7 +31,7 @@ ctx = grid.ctx
 dt = 60.0
 dtau = 2 * dt / substeps
 out = {"workload": f"{Nx}x{Ny}x{Nz} LatitudeLongitudeGrid, SplitExplicitFreeSurface, {substeps} substeps (BASELINE config 5, free-surface part)"}
-for name, fused in (("reference_launch_train", 0), ("fused_graph_train", 1), ("one_launch_graph_train", 2)):
+for name, fused in (("reference_launch_train", 0), ("fused_graph_train", 1), ("one_launch_graph_train", 2), ("four_substeps_per_launch_graph_train", 3)):
     for _ in range(3):
         sefs.substeps_train(dtau, 1, substeps, fused=fused)
     ctx.sync()
@@ -43,7 +43,8 @@ for name, fused in (("reference_launch_train", 0), ("fused_graph_train", 1), ("o
     ms = (time.perf_counter() - t0) / reps * 1e3
     out[name] = {"ms_per_200_substeps": ms, "us_per_substep": ms * 1e3 / substeps,
                  "GB_per_s_at_152B": 152.0 * Nx * Ny * substeps / (ms * 1e-3) / 1e9,
-                 "GB_per_s_at_128B": 128.0 * Nx * Ny * substeps / (ms * 1e-3) / 1e9}
+                 "GB_per_s_at_128B": 128.0 * Nx * Ny * substeps / (ms * 1e-3) / 1e9,
+                 "GB_per_s_at_50B": 50.0 * Nx * Ny * substeps / (ms * 1e-3) / 1e9}
 for _ in range(2):
     sefs.step(Gn[0], Gn[1], Gm[0], Gm[1], dt, 0.1)
 ctx.sync()
@@ -68,7 +69,7 @@ for W in (10, 20, 25, 40):
         first = 1
         while first <= substeps:
             n = min(W, substeps - first + 1)
-            bs.substeps_train(dtau, first, n, fused=2)
+            bs.substeps_train(dtau, first, n, fused=3)
             first += n
     for _ in range(3):
         cycle()
