@@ -19,6 +19,7 @@
 // thread writing its value and its halo images; k_se_eta) and replays the whole train from a hipGraph; it leaves exactly
 // the bits the launch-by-launch path leaves, halos included (tests/test_reference_split_explicit.py).
 #include "internal.h"
+#include "stencils.h"
 
 // kernels whose launch-by-launch and fused forms (and the NumPy oracle) must round identically: no contraction into FMAs
 #if defined(__clang__)
@@ -679,7 +680,7 @@ __global__ void k_hy_ab2_store(double* f, const double* gn, double* gm, double d
 struct HyPhys {
   int madv;          // 0 none, 1 VectorInvariant enstrophy-conserving, 2 energy-conserving
   int cor;           // 0 none, 1 HydrostaticSphericalCoriolis enstrophy-conserving, 2 energy-conserving, 3 FPlane
-  int tadv;          // 0 none, 1 CenteredSecondOrder
+  int tadv;          // 0 none, 1 CenteredSecondOrder, 2 CenteredFourthOrder, 3 UpwindBiasedFifthOrder, 4 WENO5 (Z weights)
   double f0;
   const double* frow;   // f at the rows of (Face, Face) points
 };
@@ -789,6 +790,40 @@ __global__ void __launch_bounds__(256) k_hy_Gc(HyMetric g, const double* __restr
     const double fz0 = az0 * (0.5 * (c[cc - szc] + cm)), fz1 = az1 * (0.5 * (cm + c[cc + szc]));
     const double div = rv * (((fx1 - fx0) + (fy1 - fy0)) + (fz1 - fz0));
     (t ? G1 : G0)[cc] = -div;
+  }
+}
+
+
+// higher-order flux-form tracer advection on these grids (CenteredFourthOrder, UpwindBiasedFifthOrder, WENO5 with Z weights): the
+// reconstructions of stencils.h (the Nonhydrostatic kernels' own, fast reciprocal and contraction included: parity with the oracle to
+// round-off, not to the bit) times the area-weighted face velocities; upwind_biased_product(Ax u, c^L, c^R) = (Ax u) c^upwind;
+// inside the boundary buffer of a Bounded direction the second-order fallback (topologically_conditional_interpolation.jl:19-83).
+// On a latitude band the buffer test uses the GLOBAL row (jrow0 + j) and row count.  One thread per cell: every face flux is
+// formed twice (by the two cells it separates) -- the general kernel, not a tiled one.
+template <int ADV, int NT>
+__global__ void __launch_bounds__(256) k_hy_Gc_hi(HyMetric g, const double* __restrict__ u, const double* __restrict__ v,
+                                                  const double* __restrict__ w, const double* __restrict__ c0, const double* __restrict__ c1,
+                                                  double* __restrict__ G0, double* __restrict__ G1, int xb, int yb, int jrow0, int gNy, long syu,
+                                                  long szu, long syv, long szv, long syc, long szc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
+  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  constexpr int NB = ADV == ADV_C4 ? 1 : 2;                       // boundary_buffer of the scheme
+  const int r = j + g.Hy;
+  const long cu = (i + g.Hx) + (long)r * syu + (long)(k + g.Hz) * szu, cv = (i + g.Hx) + (long)r * syv + (long)(k + g.Hz) * szv;
+  const long cc = (i + g.Hx) + (long)r * syc + (long)(k + g.Hz) * szc;
+  const double dz = g.dzc[k];
+  const double ax0 = (g.dyfc[r] * dz) * u[cu], ax1 = (g.dyfc[r] * dz) * u[cu + 1];
+  const double ay0 = (g.dxcf[r] * dz) * v[cv], ay1 = (g.dxcf[r + 1] * dz) * v[cv + syv];
+  const double az0 = g.azcc[r] * w[cc], az1 = g.azcc[r] * w[cc + szc];
+  const double rv = 1 / (g.azcc[r] * dz);
+  const int jg = jrow0 + j;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const double* c = (t ? c1 : c0) + cc;
+    const double fx0 = adv_flux_b<ADV>(c, 1, ax0, xb != 0, i + 1, g.Nx, NB), fx1 = adv_flux_b<ADV>(c + 1, 1, ax1, xb != 0, i + 2, g.Nx, NB);
+    const double fy0 = adv_flux_b<ADV>(c, syc, ay0, yb != 0, jg + 1, gNy, NB), fy1 = adv_flux_b<ADV>(c + syc, syc, ay1, yb != 0, jg + 2, gNy, NB);
+    const double fz0 = adv_flux_b<ADV>(c, szc, az0, true, k + 1, g.Nz, NB), fz1 = adv_flux_b<ADV>(c + szc, szc, az1, true, k + 2, g.Nz, NB);
+    (t ? G1 : G0)[cc] = -(rv * (((fx1 - fx0) + (fy1 - fy0)) + (fz1 - fz0)));
   }
 }
 
@@ -1003,6 +1038,13 @@ static int band_refresh(ocn_sefs* s, std::initializer_list<ocn_hfield*> fields) 
   }
   return comm_exchange(c, sends, recvs);
 }
+// train form of the time step: four substeps per launch; the host emulation (one OS thread per GPU thread, 1024 per workgroup here)
+// keeps the one-launch form for speed -- the four-substep kernel is compared with the launch-by-launch substeps in its own test
+#ifndef OCN_HOST_EMU
+#define SE_STEP_MODE 3
+#else
+#define SE_STEP_MODE 2
+#endif
 // everything of ocn_sefs_step after the vertical integrals of the tendencies
 static int sefs_step_tail(ocn_sefs* s, double dt) {
   ocn_ctx* ctx = s->g->ctx;
@@ -1016,7 +1058,7 @@ static int sefs_step_tail(ocn_sefs* s, double dt) {
     for (ocn_hfield* f : {s->U, s->V, s->GU, s->GV}) hfield_fill(f);
     for (int first = 1; first <= s->substeps; first += W) {
       const int count = s->substeps - first + 1 < W ? s->substeps - first + 1 : W;
-      if (int rc = ocn_sefs_substeps(s, dtau, first, count, 3)) return rc;
+      if (int rc = ocn_sefs_substeps(s, dtau, first, count, SE_STEP_MODE)) return rc;
       if (first + count <= s->substeps)
         if (int rc = band_refresh(s, {s->eta, s->U, s->V})) return rc;
     }
@@ -1026,7 +1068,7 @@ static int sefs_step_tail(ocn_sefs* s, double dt) {
   }
   hfield_fill(s->GU);
   hfield_fill(s->GV);
-  if (int rc = ocn_sefs_substeps(s, dtau, 1, s->substeps, 3)) return rc;
+  if (int rc = ocn_sefs_substeps(s, dtau, 1, s->substeps, SE_STEP_MODE)) return rc;
   // set!(eta, etabar) copies the parent array (Fields/set!.jl:41-44); then fill_halo_regions!(eta)
   se_copy(ctx, s->eta->d, s->etabar->d, s->eta->n);
   hfield_fill(s->eta);
@@ -1097,6 +1139,23 @@ static void hydro_tendencies(ocn_hydro* h) {
     const bool two = q + 1 < h->c.size();
     const double *c0 = h->c[q]->d, *c1 = two ? h->c[q + 1]->d : nullptr;
     double *G0 = h->gn[2 + q]->d, *G1 = two ? h->gn[3 + q]->d : nullptr;
+    const int tadv = h->phys.tadv;
+    if (tadv >= 2) {
+      // CenteredFourthOrder / UpwindBiasedFifthOrder / WENO5
+      const int xb = g->topo[0] != OCN_PERIODIC, yb = g->topo[1] != OCN_PERIODIC;
+#define HY_GC_HI(ADVV)                                                                                                                     \
+  if (two)                                                                                                                                 \
+    ocn_launch(k_hy_Gc_hi<ADVV, 2>, gr, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d,  \
+               c0, c1, G0, G1, xb, yb, g->j0, g->gNy, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1],        \
+               (long)p->T[0], (long)p->T[0] * p->T[1]);                                                                                    \
+  else                                                                                                                                     \
+    ocn_launch(k_hy_Gc_hi<ADVV, 1>, gr, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d,  \
+               c0, c1, G0, G1, xb, yb, g->j0, g->gNy, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1],        \
+               (long)p->T[0], (long)p->T[0] * p->T[1]);
+      if (tadv == 2) { HY_GC_HI(ADV_C4) } else if (tadv == 3) { HY_GC_HI(ADV_U5) } else { HY_GC_HI(ADV_WENO_Z) }
+#undef HY_GC_HI
+      continue;
+    }
     if (two)
       ocn_launch(k_hy_Gc<2>, gr, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d, c0, c1, G0, G1,
                  h->phys.tadv, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)p->T[0], (long)p->T[0] * p->T[1]);
@@ -1775,17 +1834,20 @@ int ocn_hydro_set_physics(ocn_hydro* h, int momentum_advection, int coriolis, do
   if (!h) return OCN_EINVAL;
   ocn_hgrid* g = h->lg;
   ocn_ctx* ctx = g->ctx;
-  if (momentum_advection < 0 || momentum_advection > 2 || coriolis < 0 || coriolis > 3 || tracer_advection < 0 || tracer_advection > 1) {
-    ocn_set_error(ctx, "ocn_hydro_set_physics: momentum_advection 0..2, coriolis 0..3, tracer_advection 0..1");
+  if (momentum_advection < 0 || momentum_advection > 2 || coriolis < 0 || coriolis > 3 || tracer_advection < 0 || tracer_advection > 4) {
+    ocn_set_error(ctx, "ocn_hydro_set_physics: momentum_advection 0..2, coriolis 0..3, tracer_advection 0..4");
     return OCN_EINVAL;
   }
   if ((coriolis == 1 || coriolis == 2) && g->kind != HG_LATLON) {
     ocn_set_error(ctx, "ocn_hydro_set_physics: HydrostaticSphericalCoriolis needs a LatitudeLongitudeGrid");
     return OCN_EINVAL;
   }
-  if (g->H[0] < 1 || g->H[1] < 1 || g->H[2] < 1) {
-    ocn_set_error(ctx, "ocn_hydro_set_physics: the second-order stencils read one halo cell in every direction");
-    return OCN_EINVAL;
+  {
+    const int need = tracer_advection >= 3 ? 3 : tracer_advection == 2 ? 2 : 1;      // halo the tracer scheme reads
+    if (g->H[0] < need || g->H[1] < need || g->H[2] < need || (g->topo[0] == OCN_PERIODIC && g->N[0] < need)) {
+      ocn_set_error(ctx, "ocn_hydro_set_physics: the stencils of this configuration read %d halo cell(s) in every direction", need);
+      return OCN_EINVAL;
+    }
   }
   OCN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   hipFree(h->frow);

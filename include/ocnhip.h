@@ -365,7 +365,10 @@ int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fus
  *   (Advection/vector_invariant_advection.jl:25-80);
  * coriolis: 0 nothing, 1 / 2 HydrostaticSphericalCoriolis(rotation_rate = coriolis_parameter) with the Enstrophy- / Energy-
  *   ConservingScheme (Coriolis/hydrostatic_spherical_coriolis.jl:29-66; LatitudeLongitudeGrid only), 3 FPlane(f = coriolis_parameter);
- * tracer_advection: 0 nothing, 1 CenteredSecondOrder() (tracer_advection_operators.jl:33-37).
+ * tracer_advection: 0 nothing, 1 CenteredSecondOrder() -- the default; bit-exact against the oracle --, 2 CenteredFourthOrder(),
+ *   3 UpwindBiasedFifthOrder(), 4 WENO5() (Z weights, uniform coefficients): flux form with this grid's areas
+ *   (tracer_advection_operators.jl:33-37, upwind_biased_advective_fluxes.jl:103-128), second-order inside the boundary buffer of a
+ *   Bounded direction (topologically_conditional_interpolation.jl:19-83); halos of 2 / 3 / 3 cells.
  * Defaults of a new handle: 1, 0, 1 -- the reference model's. */
 int ocn_hydro_set_physics(ocn_hydro* h, int momentum_advection, int coriolis, double coriolis_parameter, int tracer_advection);
 /* calculate_tendencies!(model) (calculate_hydrostatic_free_surface_tendencies.jl:15-160): G^n of u, v and every tracer over the

@@ -262,8 +262,62 @@ def momentum_tendencies(st, momentum_advection="VectorInvariantEnstrophyConservi
     S(st.Gn["v"].data)[...] = ((-Av - 0) - Cv) - py
 
 
+class _SphereOps:
+    """what oracle/advection.py's Advection needs of a grid, for the grids of split_explicit.py: offset functions over the compute
+    region, areas and volumes with the per-row metrics (Ax^fcc = dy^fc dz, Ay^cfc = dx^cf[j] dz, Az^ccf = Az^cc[j], V^ccc = Az^cc[j] dz;
+    spacings_and_areas_and_volumes.jl:203-232)"""
+
+    def __init__(self, grid):
+        from .operators import Ops
+        self.st = _Stencil(grid)
+
+        class G:                                    # the attributes Advection._cond / Ops.index read
+            topo = grid.topo
+            N = (grid.Nx, grid.Ny, grid.Nz)
+        self.g = G
+        self.flat = (False, False, False)
+        self._ops = Ops
+        self.grid = grid
+
+    def dC(self, d, f):
+        return self._ops.dC(self, d, f)
+
+    def dF(self, d, f):
+        return self._ops.dF(self, d, f)
+
+    def iC(self, d, f):
+        return self._ops.iC(self, d, f)
+
+    def iF(self, d, f):
+        return self._ops.iF(self, d, f)
+
+    def index(self, d, o):
+        return self._ops.index(self, d, o)
+
+    def Ax(self, lz, o):
+        return self.st.R(self.grid.dy_fc, o[1]) * self.st.Zc(o[2])
+
+    def Ay(self, lz, o):
+        return self.st.R(self.grid.dx_cf, o[1]) * self.st.Zc(o[2])
+
+    def Az(self):
+        return self.st.R(self.grid.Az_cc)
+
+    def V(self, lz, o):
+        return self.st.R(self.grid.Az_cc, o[1]) * self.st.Zc(o[2])
+
+    def field(self, f):
+        return lambda o: self.st.S(f.data, *o)
+
+
+TRACER_SCHEMES = ("CenteredSecondOrder", "CenteredFourthOrder", "UpwindBiasedFifthOrder", "WENO5")
+
+
 def tracer_tendency(st, name, tracer_advection="CenteredSecondOrder"):
-    """G^n.c = -div_Uc over the grid's cells (tracer_advection: None | "CenteredSecondOrder")"""
+    """G^n.c = -div_Uc over the grid's cells.  tracer_advection: None | "CenteredSecondOrder" (the model's default; written out below)
+    | "CenteredFourthOrder" | "UpwindBiasedFifthOrder" | "WENO5" (Z weights, uniform coefficients) -- the flux-form operators of
+    oracle/advection.py (tracer_advection_operators.jl:31-35, upwind_biased_advective_fluxes.jl:103-128,
+    topologically_conditional_interpolation.jl:19-83) with this grid's areas and volumes"""
     g = st.grid
     o = _Stencil(g)
     S, R = o.S, o.R
@@ -271,7 +325,13 @@ def tracer_tendency(st, name, tracer_advection="CenteredSecondOrder"):
         S(st.Gn[name].data)[...] = 0.0
         return
     if tracer_advection != "CenteredSecondOrder":
-        raise ValueError(tracer_advection)
+        from . import advection as A
+        scheme = {"CenteredFourthOrder": A.CenteredFourthOrder, "UpwindBiasedFifthOrder": A.UpwindBiasedFifthOrder, "WENO5": A.WENO5}[tracer_advection]()
+        ops = _SphereOps(g)
+        adv = A.Advection(ops, scheme)
+        div = adv.div_Uc(ops.field(st.u), ops.field(st.v), ops.field(st.w), ops.field(st.tracers[name]))((0, 0, 0))
+        S(st.Gn[name].data)[...] = -div
+        return
     u, v, w, c = st.u.data, st.v.data, st.w.data, st.tracers[name].data
     Fx = lambda di: ((R(g.dy_fc) * o.Zc()) * S(u, di)) * (0.5 * (S(c, di - 1) + S(c, di)))                    # noqa: E731
     Fy = lambda dj: ((R(g.dx_cf, dj) * o.Zc()) * S(v, 0, dj)) * (0.5 * (S(c, 0, dj - 1) + S(c, 0, dj)))       # noqa: E731

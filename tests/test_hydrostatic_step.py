@@ -54,6 +54,7 @@ GRIDS = {
     "sphere": ("LatitudeLongitudeGrid", dict(size=(48, 24, 8), longitude=(-180, 180), latitude=(-75, 75),
                                              z=[-4000, -2500, -1500, -900, -500, -250, -100, -30, 0], halo=(3, 3, 3))),
     "sector": ("LatitudeLongitudeGrid", dict(size=(20, 18, 5), longitude=(0, 60), latitude=(15, 75), z=(-1000, 0), halo=(2, 2, 2))),
+    "sector3": ("LatitudeLongitudeGrid", dict(size=(20, 18, 6), longitude=(0, 60), latitude=(15, 75), z=(-1000, 0), halo=(3, 3, 3))),
     "box": ("HRectilinearGrid", dict(size=(16, 12, 6), x=(0, 1e5), y=(0, 8e4), z=(-600, 0), halo=(1, 1, 1), topology=(P, P, B))),
     "channel": ("HRectilinearGrid", dict(size=(24, 10, 4), x=(0, 2e5), y=(-5e4, 5e4), z=[-500, -300, -120, -40, 0], halo=(3, 3, 3),
                                          topology=(P, B, B))),

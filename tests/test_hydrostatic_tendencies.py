@@ -163,6 +163,8 @@ def test_physics_arguments_are_checked(kind, ocn, backend):
         st.set_physics("VectorInvariantEnstrophyConserving", SPHERICAL + ("EnergyConserving",), "CenteredSecondOrder")   # no latitude on a box
     with pytest.raises(KeyError):
         st.set_physics("WENO5", None, "CenteredSecondOrder")
+    with pytest.raises(ocn.OcnError):                                   # the box has one halo cell: WENO5 reads three
+        st.set_physics("VectorInvariantEnstrophyConserving", None, "WENO5")
 
 
 # ---- BASELINE config 5 at its own size, through size-independent properties ---------------------------------------------------------
@@ -225,3 +227,79 @@ def _config5_properties(ocn, size, substeps):
         res = div + (w[I, J, 3 + k] - w[I, J, 3 + k - 1]) / dz[k - 1]
         worst = max(worst, float(np.abs(res).max() / max(np.abs(div).max(), 1e-300)))
     assert worst < 1e-12
+
+
+# ---- higher-order tracer advection on the sphere -----------------------------------------------------------------------------------
+SCHEME_ORDER = {"CenteredSecondOrder": (2, 0.1), "CenteredFourthOrder": (4, 0.2), "UpwindBiasedFifthOrder": (5, 0.3), "WENO5": (5, 0.6)}
+
+
+@pytest.mark.parametrize("scheme", list(SCHEME_ORDER))
+@pytest.mark.parametrize("kind", KINDS)
+def test_tracer_advection_order_on_the_sphere(kind, scheme, ocn, backend):
+    """ANALYTIC: solid-body rotation u = U0 cos(phi) carries a tracer c(lambda) with G_c = -U0 / R dc/dlambda at every latitude;
+    the error of G_c falls with the scheme's order when the longitudes are refined (the property the reference asserts of its schemes
+    on a line, validation/convergence_tests/one_dimensional_advection_schemes.jl:89-120) -- here through the flux form with the
+    sphere's areas and volumes, where the y and z fluxes cancel to round-off"""
+    be = _backend(kind, ocn, backend)
+    U0, R = 10.0, 6371.0e3
+    errs = []
+    for Nx in (48, 96):
+        grid = be.LatitudeLongitudeGrid(size=(Nx, 12, 4), longitude=(-180, 180), latitude=(-60, 60), z=(-1000, 0), halo=(3, 3, 3))
+        st = be.H.HydrostaticState(grid, tracers=("c",), buoyancy=None, substeps=4, tracer_advection=scheme)
+        st.u.set(lambda x, y, z: U0 * np.cos(np.pi * y / 180) + 0 * x + 0 * z)
+        st.tracers["c"].set(lambda x, y, z: np.exp(np.cos(np.pi * x / 180)) + 0 * y + 0 * z)
+        be.H.update_state(st)
+        be.H.calculate_tendencies(st)
+        lam = np.deg2rad(-180 + (np.arange(Nx) + 0.5) * 360.0 / Nx).reshape(-1, 1, 1)
+        # the sphere's cell area is exact in latitude (R^2 dlambda (sin phi_n - sin phi_s)) while dx dy is not: the flux form carries
+        # the ratio dx^fc dy^fc / Az^cc of its row, a function of the latitude spacing only
+        og = OS.LatitudeLongitudeGrid(size=(Nx, 12, 4), longitude=(-180, 180), latitude=(-60, 60), z=(-1000, 0), halo=(3, 3, 3))
+        ratio = (og.dx_fc * og.dy_fc / og.Az_cc)[3:15].reshape(1, -1, 1)
+        exact = -U0 / R * (-np.sin(lam) * np.exp(np.cos(lam))) * ratio
+        G = st.Gn["c"].interior()
+        errs.append(np.abs(G - exact).max() / np.abs(exact).max())
+    order, slack = SCHEME_ORDER[scheme]
+    assert abs(np.log2(errs[0] / errs[1]) - order) < slack, (scheme, errs, np.log2(errs[0] / errs[1]))
+
+
+TRACER_SCHEMES = ["CenteredFourthOrder", "UpwindBiasedFifthOrder", "WENO5"]
+
+
+def _compare_tracer_schemes(be, gridname, scheme):
+    """G^n of the tracers and the state after two whole steps against the oracle: these kernels share the Nonhydrostatic ones'
+    reconstructions (fast reciprocal, contraction), so the bar is theirs -- 2e-11 of the field's range -- not bit equality"""
+    states = []
+    for b in (be, OracleBackend):
+        _, st, _ = make_state(b, gridname, buoyancy=TS, tracers=("T", "S", "e"), amplitude=0.05)
+        if b is OracleBackend:
+            st.tracer_advection = scheme
+        else:
+            st.set_physics("VectorInvariantEnstrophyConserving", None, scheme)
+        b.H.update_state(st)
+        b.H.calculate_tendencies(st)
+        states.append(st)
+    st, so = states
+    for n in ("T", "S", "e"):
+        got, want = st.Gn[n].interior(), so.Gn[n].interior()
+        assert np.abs(got - want).max() <= 2e-11 * np.abs(want).max(), (n, np.abs(got - want).max() / np.abs(want).max())
+    for q in range(2):
+        be.H.time_step(st, 100.0, euler=(q == 0))
+        OH.time_step(so, 100.0, euler=(q == 0))
+    for n in ("T", "S", "e"):
+        got, want = st.tracers[n].interior(), so.tracers[n].interior()
+        assert np.abs(got - want).max() <= 2e-11 * np.abs(want).max(), n
+
+
+@pytest.mark.parametrize("scheme", TRACER_SCHEMES)
+@pytest.mark.parametrize("gridname", ["sphere", "sector3", "channel"])
+def test_tracer_schemes_match_oracle_hostemu(gridname, scheme, ocn, backend):
+    if backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    _compare_tracer_schemes(LibBackend(ocn), gridname, scheme)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scheme", TRACER_SCHEMES)
+@pytest.mark.parametrize("gridname", ["sphere", "sector3", "channel"])
+def test_tracer_schemes_match_oracle_gpu(gridname, scheme, ocn):
+    _compare_tracer_schemes(LibBackend(ocn), gridname, scheme)
