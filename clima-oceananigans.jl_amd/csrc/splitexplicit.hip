@@ -55,6 +55,8 @@ struct ocn_hgrid {
   std::vector<double> h_azff, h_phif;                                  // Az^ff per row; latitude of the rows of faces [degrees] (lat-lon only)
   std::vector<double> h_dzf;                                           // dz^f[k] = zC[k] - zC[k-1], k = 1..Nz+1 (entry [k - 1]); needs Hz >= 1
   double *dxfc = nullptr, *dxcf = nullptr, *dyfc = nullptr, *dycf = nullptr, *azcc = nullptr, *dzc = nullptr, *dzf = nullptr, *azff = nullptr;   // device copies
+  // correctly rounded reciprocals of the divisors of the tendency kernel (hy_div below)
+  double *r_dxfc = nullptr, *r_dycf = nullptr, *r_azcc = nullptr, *r_azff = nullptr, *r_dzf = nullptr;
 };
 
 struct ocn_hfield {
@@ -495,17 +497,21 @@ __global__ void k_se_vsum(double* out, const double* a, const double* b, double 
   out[(i + Hx) + (long)(j + Hy) * sy2] = acc;
 }
 
-// barotropic_split_explicit_corrector_kernel! (:89-95) over i = 1..Nx, j = 1..Ny, k = 1..Nz
+// barotropic_split_explicit_corrector_kernel! (:89-95) over i = 1..Nx, j = 1..Ny, k = 1..Nz: u += (-U + U-bar) / H^fc, v likewise.
+// One thread per column: the two quotients are those of every level of the column, formed once (the same operands give the same bits).
 __global__ void k_se_correct(double* u, double* v, const double* U, const double* V, const double* Ub, const double* Vb, const double* Hfc,
                              const double* Hcf, int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, long su3, long szu, long sv3, long szv,
                              long su2, long sv2) {
   OCN_NO_CONTRACT
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
-  if (i >= Nx || j >= Ny || k >= Nz) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= Nx || j >= Ny) return;
   const long cu2 = (i + Hx) + (long)(j + Hy) * su2, cv2 = (i + Hx) + (long)(j + Hy) * sv2;
-  const long cu3 = (i + Hx) + (long)(j + Hy) * su3 + (long)(k + Hz) * szu, cv3 = (i + Hx) + (long)(j + Hy) * sv3 + (long)(k + Hz) * szv;
-  u[cu3] = u[cu3] + (-U[cu2] + Ub[cu2]) / Hfc[cu2];
-  v[cv3] = v[cv3] + (-V[cv2] + Vb[cv2]) / Hcf[cv2];
+  long cu3 = (i + Hx) + (long)(j + Hy) * su3 + (long)Hz * szu, cv3 = (i + Hx) + (long)(j + Hy) * sv3 + (long)Hz * szv;
+  const double du = (-U[cu2] + Ub[cu2]) / Hfc[cu2], dv = (-V[cv2] + Vb[cv2]) / Hcf[cv2];
+  for (int k = 0; k < Nz; ++k, cu3 += szu, cv3 += szv) {
+    u[cu3] = u[cu3] + du;
+    v[cv3] = v[cv3] + dv;
+  }
 }
 
 __global__ void k_se_copy(double* dst, const double* src, size_t n) {
@@ -686,8 +692,17 @@ struct HyPhys {
 };
 struct HyMetric {
   const double *dxfc, *dxcf, *dyfc, *dycf, *azcc, *azff, *dzc, *dzf;
+  const double *r_dxfc, *r_dycf, *r_azcc, *r_azff, *r_dzf;      // correctly rounded reciprocals (host: 1.0 / x)
   int Nx, Ny, Nz, Hx, Hy, Hz;
 };
+// x / d, correctly rounded, from the correctly rounded reciprocal r = RN(1 / d) of a divisor that is a per-row or per-level constant:
+// q = RN(x r) is a faithful quotient, the remainder x - q d is exact in one fused multiply-add, and RN(q + rem r) is then the
+// correctly rounded quotient (Markstein's theorem) -- the bits of the IEEE division the oracle performs, at three instructions
+// instead of the ~15 of a double-precision division (k_hy_Guv holds 17 of them per cell).
+__device__ inline double hy_div(double x, double d, double r) {
+  const double q = x * r;
+  return fma(fma(-q, d, x), r, q);
+}
 
 __global__ void __launch_bounds__(256) k_hy_Guv(HyMetric g, HyPhys ph, const double* __restrict__ u, const double* __restrict__ v,
                                                 const double* __restrict__ w, const double* __restrict__ p, double* __restrict__ Gu,
@@ -705,7 +720,7 @@ __global__ void __launch_bounds__(256) k_hy_Guv(HyMetric g, HyPhys ph, const dou
   auto zeta = [&](int di, int dj) {
     const double circ = (g.dycf[r + dj] * V(di, dj, 0) - g.dycf[r + dj] * V(di - 1, dj, 0)) -
                         (g.dxfc[r + dj] * U(di, dj, 0) - g.dxfc[r + dj - 1] * U(di, dj - 1, 0));
-    return circ / g.azff[r + dj];
+    return hy_div(circ, g.azff[r + dj], g.r_azff[r + dj]);
   };
   auto sq = [](double x) { return x * x; };
   auto Kh = [&](int di, int dj) {
@@ -715,29 +730,29 @@ __global__ void __launch_bounds__(256) k_hy_Guv(HyMetric g, HyPhys ph, const dou
   auto Ix_dyu = [&](int dj) { return 0.5 * (g.dyfc[r + dj] * U(0, dj, 0) + g.dyfc[r + dj] * U(1, dj, 0)); };
   auto Ix_dxv = [&](int dj) { return 0.5 * (g.dxcf[r + dj] * V(-1, dj, 0) + g.dxcf[r + dj] * V(0, dj, 0)); };
   auto Iy_dyu = [&](int di) { return 0.5 * (g.dyfc[r - 1] * U(di, -1, 0) + g.dyfc[r] * U(di, 0, 0)); };
-  const double dxfc = g.dxfc[r], dycf = g.dycf[r];
+  const double dxfc = g.dxfc[r], dycf = g.dycf[r], rdxfc = g.r_dxfc[r], rdycf = g.r_dycf[r];
   double Au = 0.0, Av = 0.0;
   if (ph.madv) {
     double vvU, vvV;
     if (ph.madv == 1) {
       const double z00 = zeta(0, 0);
-      vvU = -(0.5 * (z00 + zeta(0, 1))) * (0.5 * (Iy_dxv(-1) + Iy_dxv(0))) / dxfc;
-      vvV = +(0.5 * (z00 + zeta(1, 0))) * (0.5 * (Ix_dyu(-1) + Ix_dyu(0))) / dycf;
+      vvU = hy_div(-(0.5 * (z00 + zeta(0, 1))) * (0.5 * (Iy_dxv(-1) + Iy_dxv(0))), dxfc, rdxfc);
+      vvV = hy_div(+(0.5 * (z00 + zeta(1, 0))) * (0.5 * (Ix_dyu(-1) + Ix_dyu(0))), dycf, rdycf);
     } else {
       const double z00 = zeta(0, 0);
-      vvU = -(0.5 * (z00 * Ix_dxv(0) + zeta(0, 1) * Ix_dxv(1))) / dxfc;
-      vvV = +(0.5 * (z00 * Iy_dyu(0) + zeta(1, 0) * Iy_dyu(1))) / dycf;
+      vvU = hy_div(-(0.5 * (z00 * Ix_dxv(0) + zeta(0, 1) * Ix_dxv(1))), dxfc, rdxfc);
+      vvV = hy_div(+(0.5 * (z00 * Iy_dyu(0) + zeta(1, 0) * Iy_dyu(1))), dycf, rdycf);
     }
     auto z2w = [&](int dk) {
-      return (0.5 * (g.azcc[r] * W(-1, 0, dk) + g.azcc[r] * W(0, 0, dk))) * ((U(0, 0, dk) - U(0, 0, dk - 1)) / g.dzf[k + dk]);
+      return (0.5 * (g.azcc[r] * W(-1, 0, dk) + g.azcc[r] * W(0, 0, dk))) * hy_div(U(0, 0, dk) - U(0, 0, dk - 1), g.dzf[k + dk], g.r_dzf[k + dk]);
     };
     auto z1w = [&](int dk) {
-      return (0.5 * (g.azcc[r - 1] * W(0, -1, dk) + g.azcc[r] * W(0, 0, dk))) * ((V(0, 0, dk) - V(0, 0, dk - 1)) / g.dzf[k + dk]);
+      return (0.5 * (g.azcc[r - 1] * W(0, -1, dk) + g.azcc[r] * W(0, 0, dk))) * hy_div(V(0, 0, dk) - V(0, 0, dk - 1), g.dzf[k + dk], g.r_dzf[k + dk]);
     };
-    const double vaU = 0.5 * (z2w(0) + z2w(1)) / g.azcc[r];          // Az^fcc = Az^cc (regular x)
-    const double vaV = 0.5 * (z1w(0) + z1w(1)) / g.azff[r];          // Az^cfc = Az^ff
+    const double vaU = hy_div(0.5 * (z2w(0) + z2w(1)), g.azcc[r], g.r_azcc[r]);          // Az^fcc = Az^cc (regular x)
+    const double vaV = hy_div(0.5 * (z1w(0) + z1w(1)), g.azff[r], g.r_azff[r]);          // Az^cfc = Az^ff
     const double k00 = Kh(0, 0);
-    const double bhU = (k00 - Kh(-1, 0)) / dxfc, bhV = (k00 - Kh(0, -1)) / dycf;
+    const double bhU = hy_div(k00 - Kh(-1, 0), dxfc, rdxfc), bhV = hy_div(k00 - Kh(0, -1), dycf, rdycf);
     Au = (vvU + vaU) + bhU;
     Av = (vvV + vaV) + bhV;
   }
@@ -747,14 +762,14 @@ __global__ void __launch_bounds__(256) k_hy_Guv(HyMetric g, HyPhys ph, const dou
     Cv = ph.f0 * (0.5 * (0.5 * (U(0, -1, 0) + U(1, -1, 0)) + 0.5 * (U(0, 0, 0) + U(1, 0, 0))));
   } else if (ph.cor == 1) {
     const double f0 = ph.frow[r], f1 = ph.frow[r + 1];
-    Cu = -(0.5 * (f0 + f1)) * (0.5 * (Iy_dxv(-1) + Iy_dxv(0))) / dxfc;
-    Cv = +(0.5 * (f0 + f0)) * (0.5 * (Ix_dyu(-1) + Ix_dyu(0))) / dycf;
+    Cu = hy_div(-(0.5 * (f0 + f1)) * (0.5 * (Iy_dxv(-1) + Iy_dxv(0))), dxfc, rdxfc);
+    Cv = hy_div(+(0.5 * (f0 + f0)) * (0.5 * (Ix_dyu(-1) + Ix_dyu(0))), dycf, rdycf);
   } else if (ph.cor == 2) {
     const double f0 = ph.frow[r], f1 = ph.frow[r + 1];
-    Cu = -(0.5 * (f0 * Ix_dxv(0) + f1 * Ix_dxv(1))) / dxfc;
-    Cv = +(0.5 * (f0 * Iy_dyu(0) + f0 * Iy_dyu(1))) / dycf;
+    Cu = hy_div(-(0.5 * (f0 * Ix_dxv(0) + f1 * Ix_dxv(1))), dxfc, rdxfc);
+    Cv = hy_div(+(0.5 * (f0 * Iy_dyu(0) + f0 * Iy_dyu(1))), dycf, rdycf);
   }
-  const double px = (p[cc] - p[cc - 1]) / dxfc, py = (p[cc] - p[cc - syc]) / dycf;
+  const double px = hy_div(p[cc] - p[cc - 1], dxfc, rdxfc), py = hy_div(p[cc] - p[cc - syc], dycf, rdycf);
   Gu[cu] = ((-Au - 0.0) - Cu) - px;
   Gv[cv] = ((-Av - 0.0) - Cv) - py;
 }
@@ -1077,7 +1092,7 @@ static int sefs_step_tail(ocn_sefs* s, double dt) {
 // offU / offV: first element of the rows of u's grid inside the free surface's 2-D arrays (a latitude band; 0 otherwise)
 static void sefs_correct_launch(ocn_sefs* s, ocn_hfield* u, ocn_hfield* v, long offU = 0, long offV = 0) {
   const ocn_hgrid* g = u->g;
-  dim3 blk(64, 4, 1), gr((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, g->N[2]);
+  dim3 blk(64, 4, 1), gr((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, 1);
   ocn_launch(k_se_correct, gr, blk, g->ctx->stream, u->d, v->d, (const double*)s->U->d + offU, (const double*)s->V->d + offV,
              (const double*)s->Ubar->d + offU, (const double*)s->Vbar->d + offV, (const double*)s->Hfc->d + offU, (const double*)s->Hcf->d + offV, g->N[0],
              g->N[1], g->N[2], g->H[0], g->H[1], g->H[2], (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1],
@@ -1123,6 +1138,7 @@ static void hydro_update_state(ocn_hydro* h, bool pressure_done) {
 static HyMetric hy_metric(const ocn_hgrid* g) {
   HyMetric q;
   q.dxfc = g->dxfc; q.dxcf = g->dxcf; q.dyfc = g->dyfc; q.dycf = g->dycf; q.azcc = g->azcc; q.azff = g->azff; q.dzc = g->dzc; q.dzf = g->dzf;
+  q.r_dxfc = g->r_dxfc; q.r_dycf = g->r_dycf; q.r_azcc = g->r_azcc; q.r_azff = g->r_azff; q.r_dzf = g->r_dzf;
   q.Nx = g->N[0]; q.Ny = g->N[1]; q.Nz = g->N[2]; q.Hx = g->H[0]; q.Hy = g->H[1]; q.Hz = g->H[2];
   return q;
 }
@@ -1293,6 +1309,18 @@ int ocn_hgrid_create(ocn_ctx* ctx, const ocn_hgrid_desc* d, ocn_hgrid** out) {
   if (!rc) rc = upload(ctx, g->h_dzc, &g->dzc);
   if (!rc) rc = upload(ctx, g->h_dzf, &g->dzf);
   if (!rc) rc = upload(ctx, g->h_azff, &g->azff);
+  {
+    auto recip = [](const std::vector<double>& v) {
+      std::vector<double> r(v.size());
+      for (size_t q = 0; q < v.size(); ++q) r[q] = 1.0 / v[q];
+      return r;
+    };
+    if (!rc) rc = upload(ctx, recip(g->h_dxfc), &g->r_dxfc);
+    if (!rc) rc = upload(ctx, recip(g->h_dycf), &g->r_dycf);
+    if (!rc) rc = upload(ctx, recip(g->h_azcc), &g->r_azcc);
+    if (!rc) rc = upload(ctx, recip(g->h_azff), &g->r_azff);
+    if (!rc) rc = upload(ctx, recip(g->h_dzf), &g->r_dzf);
+  }
   if (rc) { ocn_hgrid_destroy(g); return rc; }
   *out = g;
   return OCN_OK;
@@ -1305,6 +1333,7 @@ static void hgrid_release(ocn_hgrid* g) {
   hipFree(g->pack_s);
   hipFree(g->pack_r);
   hipFree(g->dxfc); hipFree(g->dxcf); hipFree(g->dyfc); hipFree(g->dycf); hipFree(g->azcc); hipFree(g->dzc); hipFree(g->dzf); hipFree(g->azff);
+  hipFree(g->r_dxfc); hipFree(g->r_dycf); hipFree(g->r_azcc); hipFree(g->r_azff); hipFree(g->r_dzf);
   delete g;
 }
 
