@@ -22,6 +22,9 @@
 #include "stencils.h"
 
 // kernels whose launch-by-launch and fused forms (and the NumPy oracle) must round identically: no contraction into FMAs
+// OCN_UNIFORM (compat.h): a value every lane of the wave holds alike -- a row index with 64-wide rows of threads (blockDim.x == 64).
+// Told to the compiler, the per-row metric loads become scalar loads (one per wave through the scalar cache) instead of 64-lane
+// vector loads.
 #if defined(__clang__)
 #define OCN_NO_CONTRACT _Pragma("clang fp contract(off)")
 #else
@@ -298,7 +301,7 @@ __global__ void k_se_eta(SeArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= a.Nx || j >= a.Ny) return;
   const long ce = (i + a.Hx) + (long)(j + a.Hy) * a.se, cu = (i + a.Hx) + (long)(j + a.Hy) * a.su, cv = (i + a.Hx) + (long)(j + a.Hy) * a.sv;
-  const int r = j + a.Hy;
+  const int r = OCN_UNIFORM(j + a.Hy);
   const double u0 = a.U[cu], v0 = a.V[cv];
   const double div = 1.0 / a.azcc[r] * ((a.dyfc[r] * a.U[cu + 1] - a.dyfc[r] * u0) + (a.dxcf[r + 1] * a.V[cv + a.sv] - a.dxcf[r] * v0));
   const double e1 = a.eta[ce] - a.dtau * div;
@@ -374,7 +377,7 @@ __global__ void k_se_substep1(SeArgs1 b) {
   const int js = j > 0 ? j - 1 : (a.yper ? Ny - 1 : 0);
   const bool north_wall = !a.yper && j == Ny - 1;
   const int jn = j + 1 < Ny ? j + 1 : (a.yper ? 0 : j);          // unused at a north wall
-  const int r = j + Hy, rn = jn + Hy;
+  const int r = OCN_UNIFORM(j + Hy), rn = OCN_UNIFORM(jn + Hy);
   auto E = [&](int ii, int jj) { return b.etaI[(ii + Hx) + (long)(jj + Hy) * a.se]; };
   const long cu = (i + Hx) + (long)r * a.su, cv = (i + Hx) + (long)r * a.sv, ce = (i + Hx) + (long)r * a.se;
   const long cue = (ie + Hx) + (long)r * a.su, cvn = (i + Hx) + (long)rn * a.sv;
@@ -441,7 +444,7 @@ __global__ void __launch_bounds__(1024) k_se_multi(SeArgsM m) {
   else rowok = j >= 0 && j < Ny;
   if (!rowok) gj = j < 0 ? 0 : Ny - 1;                              // any valid row: the loads below stay in bounds, the values are dropped
   const bool own = tx >= G && tx < G + TX && ty >= G && ty < G + TY && i < Nx && j < Ny;
-  const int r = gj + Hy;
+  const int r = OCN_UNIFORM(gj + Hy);
   const long cu = (gi + Hx) + (long)r * a.su, cv = (gi + Hx) + (long)r * a.sv, ce = (gi + Hx) + (long)r * a.se;
   double e = m.b.etaI[ce], u = m.b.UI[cu], v = m.b.VI[cv];
   const double hfc = a.Hfc[cu], hcf = a.Hcf[cv], gu = a.GU[cu], gv = a.GV[cv];
@@ -564,7 +567,7 @@ __global__ void k_hy_w(HyGrid g, const double* u, const double* v, double* w, lo
   OCN_NO_CONTRACT
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= g.Nx || j >= g.Ny) return;
-  const int r = j + g.Hy;
+  const int r = OCN_UNIFORM(j + g.Hy);       // blockDim.x == 64: one row per wave
   const double dy = g.dyfc[r], dxs = g.dxcf[r], dxn = g.dxcf[r + 1], ra = 1 / g.azcc[r];
   long cu = (i + g.Hx) + (long)r * syu + (long)g.Hz * szu, cv = (i + g.Hx) + (long)r * syv + (long)g.Hz * szv;
   long cw = (i + g.Hx) + (long)r * syw + (long)g.Hz * szw;
@@ -710,7 +713,7 @@ __global__ void __launch_bounds__(256) k_hy_Guv(HyMetric g, HyPhys ph, const dou
   OCN_NO_CONTRACT
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
-  const int r = j + g.Hy;
+  const int r = OCN_UNIFORM(j + g.Hy);       // blockDim.x == 64: one row per wave
   const long cu = (i + g.Hx) + (long)r * syu + (long)(k + g.Hz) * szu, cv = (i + g.Hx) + (long)r * syv + (long)(k + g.Hz) * szv;
   const long cc = (i + g.Hx) + (long)r * syc + (long)(k + g.Hz) * szc;       // w and pHY' share the (Center, Center) row pitch
   const long szw = szc;
@@ -783,7 +786,7 @@ __global__ void __launch_bounds__(256) k_hy_Gc(HyMetric g, const double* __restr
   OCN_NO_CONTRACT
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
-  const int r = j + g.Hy;
+  const int r = OCN_UNIFORM(j + g.Hy);       // blockDim.x == 64: one row per wave
   const long cu = (i + g.Hx) + (long)r * syu + (long)(k + g.Hz) * szu, cv = (i + g.Hx) + (long)r * syv + (long)(k + g.Hz) * szv;
   const long cc = (i + g.Hx) + (long)r * syc + (long)(k + g.Hz) * szc;
   if (!tadv) {
@@ -823,7 +826,7 @@ __global__ void __launch_bounds__(256) k_hy_Gc_hi(HyMetric g, const double* __re
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
   if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
   constexpr int NB = ADV == ADV_C4 ? 1 : 2;                       // boundary_buffer of the scheme
-  const int r = j + g.Hy;
+  const int r = OCN_UNIFORM(j + g.Hy);       // blockDim.x == 64: one row per wave
   const long cu = (i + g.Hx) + (long)r * syu + (long)(k + g.Hz) * szu, cv = (i + g.Hx) + (long)r * syv + (long)(k + g.Hz) * szv;
   const long cc = (i + g.Hx) + (long)r * syc + (long)(k + g.Hz) * szc;
   const double dz = g.dzc[k];
