@@ -31,6 +31,15 @@
 #define OCN_NO_CONTRACT
 #endif
 
+// x / d, correctly rounded, from the correctly rounded reciprocal r = RN(1 / d) of a divisor that is a per-row or per-level constant:
+// q = RN(x r) is a faithful quotient, the remainder x - q d is exact in one fused multiply-add, and RN(q + rem r) is then the
+// correctly rounded quotient (Markstein's theorem) -- the bits of the IEEE division the oracle performs, at three instructions
+// instead of the ~15 of a double-precision division (k_hy_Guv holds 17 of them per cell).
+__device__ inline double hy_div(double x, double d, double r) {
+  const double q = x * r;
+  return fma(fma(-q, d, x), r, q);
+}
+
 enum { HG_RECT = 0, HG_LATLON = 1 };
 
 struct ocn_hgrid {
@@ -276,6 +285,7 @@ struct SeArgs {
   double *eta, *U, *V, *etabar, *Ubar, *Vbar;
   const double *GU, *GV, *Hfc, *Hcf;
   const double *dxfc, *dycf, *dyfc, *dxcf, *azcc;   // per row, entry [j + Hy] for the 0-based row j
+  const double *r_dxfc, *r_dycf;                    // correctly rounded reciprocals of dxfc, dycf (hy_div)
   int Nx, Ny, Hx, Hy;
   long se, su, sv;                                   // row pitch of the Center-Center, Face-Center and Center-Face parents
   double g, dtau, wv, wf;
@@ -382,14 +392,14 @@ __global__ void k_se_substep1(SeArgs1 b) {
   const long cu = (i + Hx) + (long)r * a.su, cv = (i + Hx) + (long)r * a.sv, ce = (i + Hx) + (long)r * a.se;
   const long cue = (ie + Hx) + (long)r * a.su, cvn = (i + Hx) + (long)rn * a.sv;
   const double e0 = E(i, j), ew = E(iw, j), es = E(i, js), ee = E(ie, j);
-  const double u0 = b.UI[cu] + a.dtau * (-a.g * a.Hfc[cu] * ((e0 - ew) / a.dxfc[r]) + a.GU[cu]);
-  const double u1 = b.UI[cue] + a.dtau * (-a.g * a.Hfc[cue] * ((ee - e0) / a.dxfc[r]) + a.GU[cue]);
-  double v0 = b.VI[cv] + a.dtau * (-a.g * a.Hcf[cv] * ((e0 - es) / a.dycf[r]) + a.GV[cv]);
+  const double u0 = b.UI[cu] + a.dtau * (-a.g * a.Hfc[cu] * hy_div(e0 - ew, a.dxfc[r], a.r_dxfc[r]) + a.GU[cu]);
+  const double u1 = b.UI[cue] + a.dtau * (-a.g * a.Hfc[cue] * hy_div(ee - e0, a.dxfc[r], a.r_dxfc[r]) + a.GU[cue]);
+  double v0 = b.VI[cv] + a.dtau * (-a.g * a.Hcf[cv] * hy_div(e0 - es, a.dycf[r], a.r_dycf[r]) + a.GV[cv]);
   if (!a.yper && j == 0) v0 = 0.0;                               // impenetrable south face
   double v1 = 0.0;                                               // impenetrable north face
   if (!north_wall) {
     const double en = E(i, jn);
-    v1 = b.VI[cvn] + a.dtau * (-a.g * a.Hcf[cvn] * ((en - e0) / a.dycf[rn]) + a.GV[cvn]);
+    v1 = b.VI[cvn] + a.dtau * (-a.g * a.Hcf[cvn] * hy_div(en - e0, a.dycf[rn], a.r_dycf[rn]) + a.GV[cvn]);
   }
   const double div = 1.0 / a.azcc[r] * ((a.dyfc[r] * u1 - a.dyfc[r] * u0) + (a.dxcf[r + 1] * v1 - a.dxcf[r] * v0));
   const double e1 = e0 - a.dtau * div;
@@ -449,6 +459,7 @@ __global__ void __launch_bounds__(1024) k_se_multi(SeArgsM m) {
   double e = m.b.etaI[ce], u = m.b.UI[cu], v = m.b.VI[cv];
   const double hfc = a.Hfc[cu], hcf = a.Hcf[cv], gu = a.GU[cu], gv = a.GV[cv];
   const double dxfc = a.dxfc[r], dycf = a.dycf[r], dyfc = a.dyfc[r], dxcf0 = a.dxcf[r], dxcf1 = a.dxcf[r + 1], azcc = a.azcc[r];
+  const double rdxfc = a.r_dxfc[r], rdycf = a.r_dycf[r];
   double ub = 0, vb = 0, eb = 0;
   if (own) { ub = a.Ubar[cu]; vb = a.Vbar[cv]; eb = a.etabar[ce]; }
   if (!rowok) { e = 0.0; u = 0.0; v = 0.0; }
@@ -460,8 +471,8 @@ __global__ void __launch_bounds__(1024) k_se_multi(SeArgsM m) {
     sE[me] = e;
     __syncthreads();
     const double ew = sE[west], es = sE[south];
-    u = u + a.dtau * (-a.g * hfc * ((e - ew) / dxfc) + gu);
-    v = v + a.dtau * (-a.g * hcf * ((e - es) / dycf) + gv);
+    u = u + a.dtau * (-a.g * hfc * hy_div(e - ew, dxfc, rdxfc) + gu);
+    v = v + a.dtau * (-a.g * hcf * hy_div(e - es, dycf, rdycf) + gv);
     if (south_face || !rowok) v = 0.0;                              // rows beyond a wall hold V = 0: the wall's north / south face
     sU[me] = u;
     sV[me] = v;
@@ -698,14 +709,6 @@ struct HyMetric {
   const double *r_dxfc, *r_dycf, *r_azcc, *r_azff, *r_dzf;      // correctly rounded reciprocals (host: 1.0 / x)
   int Nx, Ny, Nz, Hx, Hy, Hz;
 };
-// x / d, correctly rounded, from the correctly rounded reciprocal r = RN(1 / d) of a divisor that is a per-row or per-level constant:
-// q = RN(x r) is a faithful quotient, the remainder x - q d is exact in one fused multiply-add, and RN(q + rem r) is then the
-// correctly rounded quotient (Markstein's theorem) -- the bits of the IEEE division the oracle performs, at three instructions
-// instead of the ~15 of a double-precision division (k_hy_Guv holds 17 of them per cell).
-__device__ inline double hy_div(double x, double d, double r) {
-  const double q = x * r;
-  return fma(fma(-q, d, x), r, q);
-}
 
 __global__ void __launch_bounds__(256) k_hy_Guv(HyMetric g, HyPhys ph, const double* __restrict__ u, const double* __restrict__ v,
                                                 const double* __restrict__ w, const double* __restrict__ p, double* __restrict__ Gu,
@@ -869,6 +872,7 @@ static SeArgs se_args(const ocn_sefs* s, double dtau, int index) {
   a.eta = s->eta->d; a.U = s->U->d; a.V = s->V->d; a.etabar = s->etabar->d; a.Ubar = s->Ubar->d; a.Vbar = s->Vbar->d;
   a.GU = s->GU->d; a.GV = s->GV->d; a.Hfc = s->Hfc->d; a.Hcf = s->Hcf->d;
   a.dxfc = g->dxfc; a.dycf = g->dycf; a.dyfc = g->dyfc; a.dxcf = g->dxcf; a.azcc = g->azcc;
+  a.r_dxfc = g->r_dxfc; a.r_dycf = g->r_dycf;
   a.Nx = g->N[0]; a.Ny = g->N[1]; a.Hx = g->H[0]; a.Hy = g->H[1];
   a.se = s->eta->T[0]; a.su = s->U->T[0]; a.sv = s->V->T[0];
   a.g = s->grav; a.dtau = dtau;
