@@ -698,7 +698,8 @@ __global__ void k_hy_ab2_store(double* f, const double* gn, double* gm, double d
 //   Advection/tracer_advection_operators.jl:33-37, centered_advective_fluxes.jl:31-33   flux-form CenteredSecondOrder
 // One thread per cell; every operator keeps the reference's operand order, without contraction (see OCN_NO_CONTRACT).
 struct HyPhys {
-  int madv;          // 0 none, 1 VectorInvariant enstrophy-conserving, 2 energy-conserving
+  int madv;          // 0 none, 1 VectorInvariant enstrophy-conserving, 2 energy-conserving, 3 WENO5(vector_invariant = VorticityStencil())
+  int xb, yb, jrow0, gNy;   // madv 3: Bounded x / y (boundary buffer), global row of the band's first row and global row count
   int cor;           // 0 none, 1 HydrostaticSphericalCoriolis enstrophy-conserving, 2 energy-conserving, 3 FPlane
   int tadv;          // 0 none, 1 CenteredSecondOrder, 2 CenteredFourthOrder, 3 UpwindBiasedFifthOrder, 4 WENO5 (Z weights)
   double f0;
@@ -744,10 +745,32 @@ __global__ void __launch_bounds__(256) k_hy_Guv(HyMetric g, HyPhys ph, const dou
       const double z00 = zeta(0, 0);
       vvU = hy_div(-(0.5 * (z00 + zeta(0, 1))) * (0.5 * (Iy_dxv(-1) + Iy_dxv(0))), dxfc, rdxfc);
       vvV = hy_div(+(0.5 * (z00 + zeta(1, 0))) * (0.5 * (Ix_dyu(-1) + Ix_dyu(0))), dycf, rdycf);
-    } else {
+    } else if (ph.madv == 2) {
       const double z00 = zeta(0, 0);
       vvU = hy_div(-(0.5 * (z00 * Ix_dxv(0) + zeta(0, 1) * Ix_dxv(1))), dxfc, rdxfc);
       vvV = hy_div(+(0.5 * (z00 * Iy_dyu(0) + zeta(1, 0) * Iy_dyu(1))), dycf, rdycf);
+    } else {
+      // WENO5(vector_invariant = VorticityStencil()) (vector_invariant_advection.jl:54-66): transporting velocity times the upwind-biased
+      // WENO5 interpolation of zeta to the velocity point (stencils.h recon5: parity with the oracle to round-off, like the WENO tracer
+      // kernel), second order inside the boundary buffer of a Bounded direction (topologically_conditional_interpolation.jl:49-62)
+      const double vhat = hy_div(0.5 * (Iy_dxv(-1) + Iy_dxv(0)), dxfc, rdxfc), uhat = hy_div(0.5 * (Ix_dyu(-1) + Ix_dyu(0)), dycf, rdycf);
+      const int jg = ph.jrow0 + j + 1, ig = i + 1;                  // 1-based global indices of the buffer test
+      {
+        const bool pos = vhat > 0.0;
+        double zi;
+        if (ph.yb && !(pos ? outside_left(jg, ph.gNy, 2) : outside_right(jg, ph.gNy, 2))) zi = 0.5 * (zeta(0, 0) + zeta(0, 1));
+        else zi = pos ? recon5<ADV_WENO_Z>(zeta(0, -2), zeta(0, -1), zeta(0, 0), zeta(0, 1), zeta(0, 2), true)
+                      : recon5<ADV_WENO_Z>(zeta(0, 3), zeta(0, 2), zeta(0, 1), zeta(0, 0), zeta(0, -1), false);
+        vvU = -(vhat * zi);
+      }
+      {
+        const bool pos = uhat > 0.0;
+        double zi;
+        if (ph.xb && !(pos ? outside_left(ig, g.Nx, 2) : outside_right(ig, g.Nx, 2))) zi = 0.5 * (zeta(0, 0) + zeta(1, 0));
+        else zi = pos ? recon5<ADV_WENO_Z>(zeta(-2, 0), zeta(-1, 0), zeta(0, 0), zeta(1, 0), zeta(2, 0), true)
+                      : recon5<ADV_WENO_Z>(zeta(3, 0), zeta(2, 0), zeta(1, 0), zeta(0, 0), zeta(-1, 0), false);
+        vvV = +(uhat * zi);
+      }
     }
     auto z2w = [&](int dk) {
       return (0.5 * (g.azcc[r] * W(-1, 0, dk) + g.azcc[r] * W(0, 0, dk))) * hy_div(U(0, 0, dk) - U(0, 0, dk - 1), g.dzf[k + dk], g.r_dzf[k + dk]);
@@ -986,7 +1009,7 @@ struct ocn_hydro {
   HyBuoy buoy;
   int bT, bS;                                // indices (into c) of the tracers the buoyancy reads, -1: none
   double *Un = nullptr, *Vn = nullptr;       // barotropic mode of the stepped velocities, kept for the corrector
-  HyPhys phys{1, 0, 1, 0.0, nullptr};        // the model's defaults: VectorInvariant(), no Coriolis, CenteredSecondOrder tracers
+  HyPhys phys{1, 0, 0, 0, 0, 0, 1, 0.0, nullptr};        // the model's defaults: VectorInvariant(), no Coriolis, CenteredSecondOrder tracers
   double* frow = nullptr;
   double chi = 0.1;                          // QuasiAdamsBashforth2TimeStepper's default
 };
@@ -1155,6 +1178,10 @@ static void hydro_tendencies(ocn_hydro* h) {
   const ocn_hfield *u = h->u, *v = h->v, *p = h->pHY;
   HyPhys ph = h->phys;
   ph.frow = h->frow;
+  ph.xb = g->topo[0] != OCN_PERIODIC;
+  ph.yb = g->topo[1] != OCN_PERIODIC;
+  ph.jrow0 = g->j0;
+  ph.gNy = g->gNy;
   ocn_launch(k_hy_Guv, gr, b, g->ctx->stream, hy_metric(g), ph, (const double*)u->d, (const double*)v->d, (const double*)h->w->d, (const double*)p->d,
              h->gn[0]->d, h->gn[1]->d, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)p->T[0],
              (long)p->T[0] * p->T[1]);
@@ -1870,8 +1897,8 @@ int ocn_hydro_set_physics(ocn_hydro* h, int momentum_advection, int coriolis, do
   if (!h) return OCN_EINVAL;
   ocn_hgrid* g = h->lg;
   ocn_ctx* ctx = g->ctx;
-  if (momentum_advection < 0 || momentum_advection > 2 || coriolis < 0 || coriolis > 3 || tracer_advection < 0 || tracer_advection > 4) {
-    ocn_set_error(ctx, "ocn_hydro_set_physics: momentum_advection 0..2, coriolis 0..3, tracer_advection 0..4");
+  if (momentum_advection < 0 || momentum_advection > 3 || coriolis < 0 || coriolis > 3 || tracer_advection < 0 || tracer_advection > 4) {
+    ocn_set_error(ctx, "ocn_hydro_set_physics: momentum_advection 0..3, coriolis 0..3, tracer_advection 0..4");
     return OCN_EINVAL;
   }
   if ((coriolis == 1 || coriolis == 2) && g->kind != HG_LATLON) {
@@ -1879,7 +1906,7 @@ int ocn_hydro_set_physics(ocn_hydro* h, int momentum_advection, int coriolis, do
     return OCN_EINVAL;
   }
   {
-    const int need = tracer_advection >= 3 ? 3 : tracer_advection == 2 ? 2 : 1;      // halo the tracer scheme reads
+    const int need = (tracer_advection >= 3 || momentum_advection == 3) ? 3 : tracer_advection == 2 ? 2 : 1;      // halo the schemes read
     if (g->H[0] < need || g->H[1] < need || g->H[2] < need || (g->topo[0] == OCN_PERIODIC && g->N[0] < need)) {
       ocn_set_error(ctx, "ocn_hydro_set_physics: the stencils of this configuration read %d halo cell(s) in every direction", need);
       return OCN_EINVAL;

@@ -351,10 +351,12 @@ class HydrostaticState:
         self.set_physics(momentum_advection, coriolis, tracer_advection)
 
     def set_physics(self, momentum_advection, coriolis, tracer_advection):
-        """momentum_advection: None | "VectorInvariantEnstrophyConserving" | "VectorInvariantEnergyConserving";
+        """momentum_advection: None | "VectorInvariantEnstrophyConserving" | "VectorInvariantEnergyConserving" |
+        "WENOVectorInvariantVorticityStencil" (WENO5(vector_invariant = VorticityStencil()));
         coriolis: None | ("HydrostaticSphericalCoriolis", rotation_rate, "EnstrophyConserving" | "EnergyConserving") | ("FPlane", f);
         tracer_advection: None | "CenteredSecondOrder" | "CenteredFourthOrder" | "UpwindBiasedFifthOrder" | "WENO5" """
-        ma = {None: 0, "VectorInvariantEnstrophyConserving": 1, "VectorInvariantEnergyConserving": 2}[momentum_advection]
+        ma = {None: 0, "VectorInvariantEnstrophyConserving": 1, "VectorInvariantEnergyConserving": 2,
+              "WENOVectorInvariantVorticityStencil": 3}[momentum_advection]
         ta = {None: 0, "CenteredSecondOrder": 1, "CenteredFourthOrder": 2, "UpwindBiasedFifthOrder": 3, "WENO5": 4}[tracer_advection]
         if coriolis is None:
             ck, cp = 0, 0.0

@@ -362,7 +362,8 @@ int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fus
 
 /* ---- third slice: calculate_tendencies! (no closure, forcing or immersed boundary) and the whole time_step! ---------------
  * momentum_advection: 0 nothing, 1 VectorInvariant(scheme = EnstrophyConservingScheme()) -- the default --, 2 EnergyConservingScheme
- *   (Advection/vector_invariant_advection.jl:25-80);
+ *   (Advection/vector_invariant_advection.jl:25-80), 3 WENO5(vector_invariant = VorticityStencil()): the vertical-vorticity term as
+ *   transporting velocity times the upwind-biased WENO5 interpolation of zeta (vector_invariant_advection.jl:54-66), halo 3;
  * coriolis: 0 nothing, 1 / 2 HydrostaticSphericalCoriolis(rotation_rate = coriolis_parameter) with the Enstrophy- / Energy-
  *   ConservingScheme (Coriolis/hydrostatic_spherical_coriolis.jl:29-66; LatitudeLongitudeGrid only), 3 FPlane(f = coriolis_parameter);
  * tracer_advection: 0 nothing, 1 CenteredSecondOrder() -- the default; bit-exact against the oracle --, 2 CenteredFourthOrder(),

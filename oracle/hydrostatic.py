@@ -187,7 +187,8 @@ def coriolis_parameter_rows(grid, coriolis):
 
 
 def momentum_tendencies(st, momentum_advection="VectorInvariantEnstrophyConserving", coriolis=None):
-    """G^n.u, G^n.v over the grid's cells.  momentum_advection: None | "VectorInvariantEnstrophyConserving" | "VectorInvariantEnergyConserving";
+    """G^n.u, G^n.v over the grid's cells.  momentum_advection: None | "VectorInvariantEnstrophyConserving" | "VectorInvariantEnergyConserving"
+    | "WENOVectorInvariantVorticityStencil";
     coriolis: None | ("HydrostaticSphericalCoriolis", rotation_rate, "EnergyConserving" | "EnstrophyConserving") | ("FPlane", f)"""
     g = st.grid
     o = _Stencil(g)
@@ -226,6 +227,20 @@ def momentum_tendencies(st, momentum_advection="VectorInvariantEnstrophyConservi
         elif momentum_advection == "VectorInvariantEnergyConserving":
             vvU = -(0.5 * (zeta(0, 0) * Ix_dxv(0) + zeta(0, 1) * Ix_dxv(1))) / R(dxfc)
             vvV = +(0.5 * (zeta(0, 0) * Iy_dyu(0) + zeta(1, 0) * Iy_dyu(1))) / R(dycf)
+        elif momentum_advection == "WENOVectorInvariantVorticityStencil":
+            # WENO5(vector_invariant = VorticityStencil()) (vector_invariant_advection.jl:54-66): the transporting velocity times the
+            # upwind-biased WENO5 interpolation of zeta_3^ffc to the velocity point, smoothness measured on the vorticity itself
+            # (weno_fifth_order.jl:380-403 through pass_stencil :475-476), second order inside the boundary buffer
+            # (topologically_conditional_interpolation.jl:49-62); vertical advection and Bernoulli head as for VectorInvariant
+            from . import advection as A
+            adv = A.Advection(_SphereOps(g), A.WENO5())
+            zf = lambda o: zeta(o[0], o[1])                                                    # noqa: E731   (o[2] = 0 throughout)
+            up = lambda q, L, Rr: ((q + np.abs(q)) * L + (q - np.abs(q)) * Rr) / 2               # noqa: E731   upwind_biased_product
+            vhat = (0.5 * (Iy_dxv(-1) + Iy_dxv(0))) / R(dxfc)
+            uhat = (0.5 * (Ix_dyu(-1) + Ix_dyu(0))) / R(dycf)
+            with np.errstate(all="ignore"):            # rows beyond the walls hold no metric: their stencils are the ones the buffer test discards
+                vvU = -up(vhat, adv.leftC(1, zf)((0, 0, 0)), adv.rightC(1, zf)((0, 0, 0)))
+                vvV = +up(uhat, adv.leftC(0, zf)((0, 0, 0)), adv.rightC(0, zf)((0, 0, 0)))
         else:
             raise ValueError(momentum_advection)
 

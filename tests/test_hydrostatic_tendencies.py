@@ -303,3 +303,62 @@ def test_tracer_schemes_match_oracle_hostemu(gridname, scheme, ocn, backend):
 @pytest.mark.parametrize("gridname", ["sphere", "sector3", "channel"])
 def test_tracer_schemes_match_oracle_gpu(gridname, scheme, ocn):
     _compare_tracer_schemes(LibBackend(ocn), gridname, scheme)
+
+
+# ---- WENO5(vector_invariant = VorticityStencil()) momentum advection -------------------------------------------------------------------
+def _compare_weno_vector_invariant(be, gridname):
+    latlon = GRIDS[gridname][0] == "LatitudeLongitudeGrid"
+    coriolis = SPHERICAL + ("EnstrophyConserving",) if latlon else ("FPlane", 1e-4)
+    states = []
+    for b in (be, OracleBackend):
+        _, st, _ = make_state(b, gridname, buoyancy=TS, tracers=("T", "S"), amplitude=0.05)
+        if b is OracleBackend:
+            st.momentum_advection, st.coriolis = "WENOVectorInvariantVorticityStencil", coriolis
+        else:
+            st.set_physics("WENOVectorInvariantVorticityStencil", coriolis, "CenteredSecondOrder")
+        b.H.update_state(st)
+        b.H.calculate_tendencies(st)
+        states.append(st)
+    st, so = states
+    for n in ("u", "v"):
+        got, want = st.Gn[n].interior(), so.Gn[n].interior()
+        assert np.abs(got - want).max() <= 2e-11 * np.abs(want).max(), (n, np.abs(got - want).max() / np.abs(want).max())
+    for q in range(2):
+        be.H.time_step(st, 100.0, euler=(q == 0))
+        OH.time_step(so, 100.0, euler=(q == 0))
+    for a, b in ((st.u, so.u), (st.v, so.v), (st.w, so.w), (st.free_surface.eta, so.free_surface.eta)):
+        got, want = a.interior(), b.interior()
+        assert np.abs(got - want.reshape(got.shape)).max() <= 2e-11 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("gridname", ["sphere", "sector3", "channel"])
+def test_weno_vector_invariant_matches_oracle_hostemu(gridname, ocn, backend):
+    if backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    _compare_weno_vector_invariant(LibBackend(ocn), gridname)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gridname", ["sphere", "sector3", "channel"])
+def test_weno_vector_invariant_matches_oracle_gpu(gridname, ocn):
+    _compare_weno_vector_invariant(LibBackend(ocn), gridname)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_weno_vector_invariant_solid_body_rotation(kind, ocn, backend):
+    """solid-body rotation under the WENO vector-invariant scheme: G_u = 0, G_v converges to -(f u + u^2 tan(phi) / R) (second order:
+    the Bernoulli head and the Coriolis term are), away from the boundary buffer"""
+    be = _backend(kind, ocn, backend)
+    U0, R = 20.0, 6371.0e3
+    errs = []
+    for Ny in (16, 32):
+        grid, st = williamson2(be, Ny, advection="WENOVectorInvariantVorticityStencil")
+        be.H.calculate_tendencies(st)
+        assert np.abs(st.Gn["u"].interior()).max() <= 1e-17
+        phi = np.deg2rad(OS.LatitudeLongitudeGrid(size=(2 * Ny, Ny, 4), longitude=(-180, 180), latitude=(-80, 80), z=(-1000, 0),
+                                                  halo=(3, 3, 3)).nodes("Face", 1))
+        exact = -(2 * OMEGA * np.sin(phi) * U0 * np.cos(phi) + U0 ** 2 * np.cos(phi) * np.sin(phi) / R)
+        num = st.Gn["v"].interior()[0, :, 1]
+        n = min(num.size, exact.size)
+        errs.append(np.abs(num[3:n - 3] - exact[3:n - 3]).max() / np.abs(exact).max())
+    assert errs[0] < 2e-2 and 3.3 < errs[0] / errs[1] < 4.7, errs
