@@ -1,23 +1,34 @@
-// splitexplicit.hip -- SplitExplicitFreeSurface of the HydrostaticFreeSurfaceModel (BASELINE config 5, first slice):
-// the barotropic sub-cycling, the vertical integrals and the corrector, on a RectilinearGrid or a LatitudeLongitudeGrid.
+// splitexplicit.hip -- the HydrostaticFreeSurfaceModel with a SplitExplicitFreeSurface (BASELINE config 5): grids and fields, the
+// free surface's barotropic sub-cycle, and the model's whole AB2 time step, on one GPU or on latitude bands.
 //
 //   reference (paths relative to /root/reference/src)                                         here
-//   Models/HydrostaticFreeSurfaceModels/split_explicit_free_surface_kernels.jl:14-19  kernel 1    k_se_uv
-//                                                                     :21-29          kernel 2    k_se_eta
-//                                                                     :31-58  substep!            sefs_substep_plain
-//                                                                     :63-81  barotropic_mode!    k_se_vsum (+ fills)
-//                                                                     :83-87  set_average_to_zero!
-//                                                                     :89-113 corrector           k_se_correct
-//                                                                     :124-171 split_explicit_free_surface_step!  ocn_sefs_step
-//   split_explicit_free_surface.jl:78-117 (state, auxiliary), :137-154 (settings)                 ocn_sefs_create
-//   Grids/latitude_longitude_grid.jl:174-213,418-445 (regular longitude / latitude, precomputed metrics)   ocn_hgrid_create
-//   BoundaryConditions/fill_halo_regions*.jl for Field{LX, LY, Nothing} / 3-D fields in x and y  k_h_fill_*
+//   Grids/latitude_longitude_grid.jl:174-213,418-445 (regular longitude / latitude, precomputed metrics)   ocn_hgrid_create (+ bands)
+//   BoundaryConditions/fill_halo_regions*.jl, default conditions, z / x / y                      hfield_fill, k_h_fill_*, hfield_exchange_y
+//   Models/HydrostaticFreeSurfaceModels/split_explicit_free_surface.jl:78-117,137-154            ocn_sefs_create
+//   .../split_explicit_free_surface_kernels.jl:14-19  kernel 1                                    k_se_uv
+//                                              :21-29  kernel 2                                   k_se_eta
+//                                              :31-58  substep!                                   sefs_substep_plain / k_se_uv_fused /
+//                                                                                                 k_se_substep1 / k_se_multi
+//                                              :63-81  barotropic_mode!                           k_se_vsum (+ fills)
+//                                              :83-87  set_average_to_zero!
+//                                              :89-113 corrector                                  k_se_correct
+//                                              :124-171 split_explicit_free_surface_step!         ocn_sefs_step, sefs_step_tail
+//   .../calculate_hydrostatic_free_surface_tendencies.jl, hydrostatic_free_surface_tendency_kernel_functions.jl,
+//   Advection/vector_invariant_advection.jl, Coriolis/hydrostatic_spherical_coriolis.jl, Advection/tracer_advection_operators.jl
+//                                                                                                 k_hy_Guv, k_hy_Gc, k_hy_Gc_hi
+//   .../hydrostatic_free_surface_ab2_step.jl:15-48, TimeSteppers/quasi_adams_bashforth_2.jl:70-166  ocn_hydro_ab2_step, k_hy_ab2, k_hy_momentum,
+//                                                                                                 k_hy_tracers, ocn_hydro_time_step
+//   .../compute_w_from_continuity.jl:31-36, NonhydrostaticModels/update_hydrostatic_pressure.jl:10-18,
+//   .../update_hydrostatic_free_surface_model_state.jl:21-48                                     k_hy_w, k_hy_pressure, hydro_update_state
+//   Distributed/ (Partition by latitude)                                                          bands: hfield_exchange_y, hydro_allgather_rows,
+//                                                                                                 band_refresh
 //
-// The loop over the substeps is the hot part: 200 substeps of five tiny launches each (fill eta, kernel 1, fill U, fill V,
-// kernel 2) in the reference -- 1000 launches of a few microseconds per time step, all latency.  ocn_sefs_substeps runs the
-// same arithmetic as TWO launches per substep (k_se_uv_fused: the eta fill, kernel 1 and the U / V fills in one pass, every
-// thread writing its value and its halo images; k_se_eta) and replays the whole train from a hipGraph; it leaves exactly
-// the bits the launch-by-launch path leaves, halos included (tests/test_reference_split_explicit.py).
+// The loop over the substeps is the hot part of the free surface: 200 substeps of five tiny launches each (fill eta, kernel 1, fill U,
+// fill V, kernel 2) in the reference -- 1000 launches of a few microseconds per time step, all latency.  ocn_sefs_substeps runs the same
+// arithmetic as two launches per substep, as one (eta, U, V double buffered), or as four substeps per launch on tiles with ghost rings
+// (k_se_multi), and replays the whole train from a hipGraph; every form leaves exactly the bits the launch-by-launch path leaves, halos
+// included (tests/test_reference_split_explicit.py).  The kernels of this file are compiled without contraction into FMAs and divide
+// through correctly rounded reciprocals (hy_div), so they also agree with the NumPy oracle bit for bit.
 #include "internal.h"
 #include "stencils.h"
 
