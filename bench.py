@@ -232,7 +232,8 @@ def run_config5(args, ocn, ctx, dist, rank, world, transport, real_stdout):
     grid = H.LatitudeLongitudeGrid(partition="y" if world > 1 else None, **kw)
     st = H.HydrostaticState(grid, tracers=("T", "S"), buoyancy=("TS", 9.80665, 1.67e-4, 7.8e-4, "T", "S"), substeps=substeps,
                             coriolis=("HydrostaticSphericalCoriolis", 7.292115e-5, "EnstrophyConserving"), barotropic_overlap=overlap,
-                            tracer_advection=args.tracer_advection, momentum_advection=args.momentum_advection)
+                            tracer_advection=args.tracer_advection, momentum_advection=args.momentum_advection,
+                            closure=(1e-2, 1e-4) if args.implicit_diffusion else None)
     # solid-body rotation in balance with the free surface (Williamson et al. 1992, case 2): stays bounded however many steps are timed
     R, Om, U0, g = 6371.0e3, 7.292115e-5, 10.0, 9.80665
     st.u.set(lambda x, y, z: U0 * np.cos(np.pi * y / 180) + 0 * x + 0 * z)
@@ -276,7 +277,8 @@ def run_config5(args, ocn, ctx, dist, rank, world, transport, real_stdout):
                     if world > 1 and transport and transport.startswith("shm") else "synthetic"),
            "config": {"workload": f"{Nx}x{Ny}x{Nz} LatitudeLongitudeGrid, HydrostaticFreeSurfaceModel, SplitExplicitFreeSurface ({substeps} substeps), "
                                   f"{args.momentum_advection} momentum advection, {args.tracer_advection} tracers T + S, linear equation of state, "
-                                  "HydrostaticSphericalCoriolis, AB2 (BASELINE config 5 without closures)",
+                                  "HydrostaticSphericalCoriolis, AB2 (BASELINE config 5"
+                                  + (", implicit vertical diffusion)" if args.implicit_diffusion else " without closures)"),
                       "decomposition": f"latitude bands x{world}" + (f", banded free surface with {overlap} overlap rows" if world > 1 else ""),
                       "dt": dt, "init": "solid-body rotation in balance with the free surface", "transport": transport},
            # the whole step against the HBM roofline (no single kernel dominates: sub-cycle 29 %, k_hy_Guv 16 %, k_hy_tracers 13 %);
@@ -335,6 +337,8 @@ def main():
     ap.add_argument("--topology", default="PPP", help="config 2 with other x/y/z topologies, e.g. PBB (debug / widening rows)")
     ap.add_argument("--tracer-advection", default="CenteredSecondOrder",
                     help="config 5: CenteredSecondOrder (the model's default), CenteredFourthOrder, UpwindBiasedFifthOrder or WENO5")
+    ap.add_argument("--implicit-diffusion", action="store_true",
+                    help="config 5: closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(); nu = 1e-2, kappa = 1e-4)")
     ap.add_argument("--momentum-advection", default="VectorInvariantEnstrophyConserving",
                     help="config 5: VectorInvariantEnstrophyConserving (default), VectorInvariantEnergyConserving or WENOVectorInvariantVorticityStencil")
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config: 2 (headline, default), 1 (2-D turbulence), 3 (ocean LES) or 5 (hydrostatic model on the sphere)")

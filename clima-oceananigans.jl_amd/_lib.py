@@ -165,6 +165,7 @@ def load():
         "ocn_hydro_ab2_step": (I, [P, D, D]),
         "ocn_hydro_step_after_tendencies": (I, [P, D, D, I]),
         "ocn_hydro_set_physics": (I, [P, I, I, D, I]),
+        "ocn_hydro_set_closure": (I, [P, D, I, PD]),
         "ocn_hydro_calculate_tendencies": (I, [P]),
         "ocn_hydro_time_step": (I, [P, D, I]),
         "ocn_profile_enable": (I, [P, I]),

@@ -882,6 +882,32 @@ __global__ void __launch_bounds__(256) k_hy_Gc_hi(HyMetric g, const double* __re
   }
 }
 
+
+// implicit_step! for VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(); nu, kappa) with constant coefficients
+// (vertically_implicit_diffusion_solver.jl:46-100, Solvers/batched_tridiagonal_solver.jl:89-121): the tridiagonal coefficients depend on
+// the level only, so the pivots beta_k and the multipliers t_k of the modified Thomas algorithm are tabulated once per (kappa, dt) on
+// the host -- the very numbers every column of the reference's solver computes -- and a thread only substitutes: up the column
+// phi_k = (f_k - a_{k-1} phi_{k-1}) / beta_k (the division through beta's correctly rounded reciprocal), down phi_k -= t_{k+1} phi_{k+1}.
+struct HyImp {
+  const double *a, *beta, *rbeta, *t;      // a[k]: lower diagonal below level k + 1 (0-based k = 0..Nz-2); beta[k], t[k]: level k
+};
+__global__ void k_hy_implicit(double* f, HyImp c, int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, long sy, long sz) {
+  OCN_NO_CONTRACT
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= Nx || j >= Ny) return;
+  double* p = f + (i + Hx) + (long)(j + Hy) * sy + (long)Hz * sz;
+  double phi = hy_div(p[0], c.beta[0], c.rbeta[0]);
+  p[0] = phi;
+  for (int k = 1; k < Nz; ++k) {
+    phi = hy_div(p[k * sz] - c.a[k - 1] * phi, c.beta[k], c.rbeta[k]);
+    p[k * sz] = phi;
+  }
+  for (int k = Nz - 2; k >= 0; --k) {
+    phi = p[k * sz] - c.t[k + 1] * phi;
+    p[k * sz] = phi;
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static int api_done(ocn_ctx* ctx, int rc) {
   if (ctx->sticky_rc) {
@@ -1023,6 +1049,10 @@ struct ocn_hydro {
   HyPhys phys{1, 0, 0, 0, 0, 0, 1, 0.0, nullptr};        // the model's defaults: VectorInvariant(), no Coriolis, CenteredSecondOrder tracers
   double* frow = nullptr;
   double chi = 0.1;                          // QuasiAdamsBashforth2TimeStepper's default
+  // VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(); nu, kappa): entry 0 the viscosity, 1 + q the diffusivity of tracer q
+  std::vector<double> kap;
+  struct ImpTab { double kappa, dt; double* d = nullptr; };      // device table of 4 Nz doubles: a, beta, 1 / beta, t
+  std::vector<ImpTab> imptab;
 };
 
 static HyGrid hy_grid(const ocn_hgrid* g) {
@@ -1224,6 +1254,66 @@ static void hydro_tendencies(ocn_hydro* h) {
       ocn_launch(k_hy_Gc<1>, gr, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d, c0, c1, G0, G1,
                  h->phys.tadv, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)p->T[0], (long)p->T[0] * p->T[1]);
   }
+}
+
+// the per-level tables of the implicit solve for (kappa, dt); cached on the handle
+static int hydro_imp_table(ocn_hydro* h, double kappa, double dt, HyImp* out) {
+  const ocn_hgrid* g = h->lg;
+  const int Nz = g->N[2];
+  for (auto& e : h->imptab)
+    if (e.kappa == kappa && e.dt == dt) {
+      *out = HyImp{e.d, e.d + Nz, e.d + 2 * Nz, e.d + 3 * Nz};
+      return OCN_OK;
+    }
+  auto dzc = [&](int k) { return g->h_dzc[k - 1]; };          // 1-based level
+  auto dzf = [&](int k) { return g->h_dzf[k - 1]; };          // 1-based face
+  auto upper = [&](int k) { return k > Nz - 1 ? 0.0 : -dt * (kappa / dzc(k) / dzf(k + 1)); };
+  auto lower = [&](int k) { return k < 1 ? 0.0 : -dt * (kappa / dzc(k + 1) / dzf(k + 1)); };
+  auto diag = [&](int k) { return (1.0 - dt * 0.0 - upper(k)) - lower(k - 1); };
+  std::vector<double> tab(4 * (size_t)Nz, 0.0);
+  double* a = tab.data();
+  double *beta = a + Nz, *rbeta = a + 2 * Nz, *t = a + 3 * Nz;
+  double b = diag(1);
+  beta[0] = b;
+  for (int k = 2; k <= Nz; ++k) {
+    t[k - 1] = upper(k - 1) / b;
+    b = diag(k) - lower(k - 1) * t[k - 1];
+    if (!(fabs(b) > 10 * 2.220446049250313e-16)) {
+      ocn_set_error(g->ctx, "implicit vertical diffusion: the tridiagonal system is not diagonally dominant at level %d", k);
+      return OCN_EINVAL;
+    }
+    beta[k - 1] = b;
+    a[k - 2] = lower(k - 1);
+  }
+  for (int k = 0; k < Nz; ++k) rbeta[k] = 1.0 / beta[k];
+  if (h->imptab.size() >= 16) {
+    hipStreamSynchronize(g->ctx->stream);
+    for (auto& e : h->imptab) hipFree(e.d);
+    h->imptab.clear();
+  }
+  ocn_hydro::ImpTab e;
+  e.kappa = kappa;
+  e.dt = dt;
+  if (int rc = upload(g->ctx, tab, &e.d)) return rc;
+  h->imptab.push_back(e);
+  *out = HyImp{e.d, e.d + Nz, e.d + 2 * Nz, e.d + 3 * Nz};
+  return OCN_OK;
+}
+// implicit_step!(field, ...) for entry q of h->kap (0: u and v, 1 + n: tracer n); nothing when that diffusivity is zero
+static int hydro_implicit(ocn_hydro* h, ocn_hfield* f, int q, double dt) {
+  if ((size_t)q >= h->kap.size() || h->kap[q] == 0.0) return OCN_OK;
+  HyImp c;
+  if (int rc = hydro_imp_table(h, h->kap[q], dt, &c)) return rc;
+  const ocn_hgrid* g = h->lg;
+  dim3 b, gr;
+  hy_cols(g, b, gr);
+  ocn_launch(k_hy_implicit, gr, b, g->ctx->stream, f->d, c, g->N[0], g->N[1], g->N[2], g->H[0], g->H[1], g->H[2], (long)f->T[0], (long)f->T[0] * f->T[1]);
+  return OCN_OK;
+}
+static bool hydro_has_implicit(const ocn_hydro* h) {
+  for (double k : h->kap)
+    if (k != 0.0) return true;
+  return false;
 }
 
 static bool same_shape(const ocn_hfield* a, const ocn_hfield* b) {
@@ -1819,6 +1909,7 @@ void ocn_hydro_destroy(ocn_hydro* h) {
   hipFree(h->Un);
   hipFree(h->Vn);
   hipFree(h->frow);
+  for (auto& e : h->imptab) hipFree(e.d);
   delete h;
   hgrid_release(g);
 }
@@ -1841,7 +1932,10 @@ int ocn_hydro_ab2_step(ocn_hydro* h, double dt, double chi) {
   if (rc) return rc;
   hy_ab2_launch(h->u, h->gn[0], h->gm[0], dt, chi, false);
   hy_ab2_launch(h->v, h->gn[1], h->gm[1], dt, chi, false);
+  if ((rc = hydro_implicit(h, h->u, 0, dt)) || (rc = hydro_implicit(h, h->v, 0, dt))) return rc;
   for (size_t q = 0; q < h->c.size(); ++q) hy_ab2_launch(h->c[q], h->gn[2 + q], h->gm[2 + q], dt, chi, false);
+  for (size_t q = 0; q < h->c.size(); ++q)
+    if ((rc = hydro_implicit(h, h->c[q], 1 + (int)q, dt))) return rc;
   return ocn_sefs_step(h->fs, h->gn[0], h->gn[1], h->gm[0], h->gm[1], dt, chi);
 }
 
@@ -1871,13 +1965,26 @@ int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fus
                GU->d + off, (q ? h->Vn : h->Un) + off, dt, cn, cm, (const double*)g->dzc, f->S[0], f->S[1], g->N[0], g->N[1], g->N[2], g->H[0], g->H[1],
                g->H[2], (long)f->T[0], (long)f->T[0] * f->T[1], (long)U->T[0]);
   }
+  const bool implicit = hydro_has_implicit(h);
+  if (implicit && h->kap[0] != 0.0) {
+    // the implicit vertical-viscosity solves follow the explicit steps; the barotropic mode of the stepped velocities (for the corrector)
+    // is then summed again from the solved columns
+    if ((rc = hydro_implicit(h, h->u, 0, dt)) || (rc = hydro_implicit(h, h->v, 0, dt))) return api_done(ctx, rc);
+    for (int q = 0; q < 2; ++q) {
+      ocn_hfield* f = q ? h->v : h->u;
+      ocn_hfield* U = q ? s->V : s->U;
+      dim3 vb(64, 4, 1), vg((f->S[0] + 63) / 64, (f->S[1] + 3) / 4, 1);
+      ocn_launch(k_se_vsum, vg, vb, ctx->stream, (q ? h->Vn : h->Un) + (q ? h->offV : h->offU), (const double*)f->d, (const double*)nullptr, 0.0, 0.0,
+                 (const double*)g->dzc, f->S[0], f->S[1], g->N[2], g->H[0], g->H[1], g->H[2], (long)f->T[0], (long)f->T[0] * f->T[1], (long)U->T[0]);
+    }
+  }
   if ((rc = hydro_allgather_rows(h))) return api_done(ctx, rc);
   hfield_fill(s->U);
   hfield_fill(s->V);
   bool pressure_done = false;
   for (size_t q = 0; q < h->c.size(); ++q) {
-    if ((int)q == h->bS && h->bT >= 0) continue;                   // stepped together with T
-    if ((int)q == h->bT) {
+    if ((int)q == h->bS && h->bT >= 0 && !implicit) continue;      // stepped together with T
+    if ((int)q == h->bT && !implicit) {
       dim3 b, gr;
       hy_cols(g, b, gr);
       ocn_hfield *T = h->c[q], *S = h->bS >= 0 ? h->c[h->bS] : nullptr;
@@ -1889,6 +1996,9 @@ int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fus
       hy_ab2_launch(h->c[q], h->gn[2 + q], h->gm[2 + q], dt, chi, true);
     }
   }
+  if (implicit)          // the tracers' implicit solves; the hydrostatic pressure then comes from update_state!'s own kernel
+    for (size_t q = 0; q < h->c.size(); ++q)
+      if ((rc = hydro_implicit(h, h->c[q], 1 + (int)q, dt))) return api_done(ctx, rc);
   // the free surface: G^U, G^V are in place
   for (ocn_hfield* f : {s->etabar, s->Ubar, s->Vbar}) OCN_ASYNC(hipMemsetAsync(f->d, 0, f->n * sizeof(double), ctx->stream));
   if ((rc = sefs_step_tail(s, dt))) return api_done(ctx, rc);
@@ -1902,6 +2012,20 @@ int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fus
   return api_done(ctx, OCN_OK);
 }
 
+
+
+/* closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(); nu, kappa = (kappa_1, ...)) with constant coefficients:
+ * implicit_step! of u, v and every tracer inside ab2_step! (hydrostatic_free_surface_ab2_step.jl:72-85,115-128); zeros switch it off */
+int ocn_hydro_set_closure(ocn_hydro* h, double nu, int ntracers, const double* kappa) {
+  if (!h || ntracers != (int)h->c.size() || (ntracers > 0 && !kappa) || !(nu >= 0)) return OCN_EINVAL;
+  for (int q = 0; q < ntracers; ++q)
+    if (!(kappa[q] >= 0)) return OCN_EINVAL;
+  if (h->lg->H[2] < 1 && (nu > 0)) return OCN_EINVAL;
+  h->kap.assign(1 + (size_t)ntracers, 0.0);
+  h->kap[0] = nu;
+  for (int q = 0; q < ntracers; ++q) h->kap[1 + q] = kappa[q];
+  return OCN_OK;
+}
 
 /* ---- third slice: calculate_tendencies! and the whole time step ---------------------------------------------------------------- */
 int ocn_hydro_set_physics(ocn_hydro* h, int momentum_advection, int coriolis, double coriolis_parameter, int tracer_advection) {

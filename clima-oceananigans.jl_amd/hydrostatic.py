@@ -318,7 +318,7 @@ class HydrostaticState:
 
     def __init__(self, grid, tracers=("T", "S"), buoyancy=None, substeps=20, gravitational_acceleration=g_Earth, free_surface=None,
                  momentum_advection="VectorInvariantEnstrophyConserving", coriolis=None, tracer_advection="CenteredSecondOrder",
-                 barotropic_overlap=0):
+                 barotropic_overlap=0, closure=None):
         self.grid, self.lib = grid, grid.lib
         self.chi = 0.1
         self.u, self.v, self.w = Field3(grid, Face, Center), Field3(grid, Center, Face), Field3(grid, Center, Center, Face)
@@ -349,6 +349,15 @@ class HydrostaticState:
         self.h = C.c_void_p()
         check(self.lib.ocn_hydro_create(C.byref(d), C.byref(self.h)), grid.ctx.h)
         self.set_physics(momentum_advection, coriolis, tracer_advection)
+        self.set_closure(closure)
+
+    def set_closure(self, closure):
+        """None | (nu, kappa | {tracer: kappa}): VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(); nu, kappa), constants"""
+        self.closure = closure
+        nu, kap = closure or (0.0, 0.0)
+        names = list(self.tracers)
+        k = np.array([float(kap.get(n, 0.0)) if isinstance(kap, dict) else float(kap) for n in names] or [0.0])
+        check(self.lib.ocn_hydro_set_closure(self.h, float(nu), len(names), k.ctypes.data_as(C.POINTER(C.c_double))), self.grid.ctx.h)
 
     def set_physics(self, momentum_advection, coriolis, tracer_advection):
         """momentum_advection: None | "VectorInvariantEnstrophyConserving" | "VectorInvariantEnergyConserving" |

@@ -372,6 +372,11 @@ int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fus
  *   Bounded direction (topologically_conditional_interpolation.jl:19-83); halos of 2 / 3 / 3 cells.
  * Defaults of a new handle: 1, 0, 1 -- the reference model's. */
 int ocn_hydro_set_physics(ocn_hydro* h, int momentum_advection, int coriolis, double coriolis_parameter, int tracer_advection);
+/* closure = VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(); nu, kappa = (kappa per tracer)) with constant
+ * coefficients: implicit_step! of u, v and every tracer inside ab2_step! (hydrostatic_free_surface_ab2_step.jl:72-85,115-128;
+ * TurbulenceClosures/vertically_implicit_diffusion_solver.jl:46-100, Solvers/batched_tridiagonal_solver.jl:89-121); no flux through top
+ * and bottom; ntracers must be the handle's; all zeros (the default) switch it off.  Other closures stay on the reference's path. */
+int ocn_hydro_set_closure(ocn_hydro* h, double nu, int32_t ntracers, const double* kappa);
 /* calculate_tendencies!(model) (calculate_hydrostatic_free_surface_tendencies.jl:15-160): G^n of u, v and every tracer over the
  * grid's cells, from the state update_state! left (filled halos, w, pHY') */
 int ocn_hydro_calculate_tendencies(ocn_hydro* h);

@@ -86,8 +86,9 @@ class HydrostaticState:
 
     def __init__(self, grid, tracers=("T", "S"), buoyancy=None, substeps=20, gravitational_acceleration=SE.G_EARTH, F3=Field3,
                  free_surface=None, momentum_advection="VectorInvariantEnstrophyConserving", coriolis=None,
-                 tracer_advection="CenteredSecondOrder"):
+                 tracer_advection="CenteredSecondOrder", closure=None):
         self.grid = grid
+        self.closure = closure        # None | (nu, kappa | {tracer: kappa}): VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(); nu, kappa)
         self.momentum_advection, self.coriolis, self.tracer_advection = momentum_advection, coriolis, tracer_advection
         self.u, self.v, self.w = F3(grid, Face, Center, Center), F3(grid, Center, Face, Center), F3(grid, Center, Center, Face)
         self.tracers = {n: F3(grid, Center, Center, Center) for n in tracers}
@@ -111,14 +112,50 @@ def update_state(st):
     fill_halo_regions(st.pHY)
 
 
+def implicit_step(f, kappa, dt):
+    """implicit_step!(field, solver, closure::VerticalScalarDiffusivity{VerticallyImplicitTimeDiscretization}, ...) with a constant
+    diffusivity: (1 - dt d_z kappa d_z) c^{n+1} = c* per column, coefficients of vertically_implicit_diffusion_solver.jl:46-100
+    (kappa / dz^c / dz^f; no flux through top and bottom), solved in place by the modified Thomas algorithm of
+    Solvers/batched_tridiagonal_solver.jl:89-121 (its |beta| <= 10 eps early exit cannot trigger: beta >= 1 here)"""
+    if not kappa:
+        return
+    g = f.grid
+    Nz, Hz = g.Nz, g.Hz
+    az = g.ax[2]
+    dzc = lambda k: az.dc if az.regular else float(az.d_center(k))      # noqa: E731  1-based level
+    dzf = lambda k: az.df if az.regular else float(az.d_face(k))        # noqa: E731  1-based face
+    upper = lambda k: 0.0 if k > Nz - 1 else -dt * (kappa / dzc(k) / dzf(k + 1))          # noqa: E731  ivd_upper_diagonal(k)
+    lower = lambda k: 0.0 if k < 1 else -dt * (kappa / dzc(k + 1) / dzf(k + 1))           # noqa: E731  ivd_lower_diagonal(k), k' = k + 1
+    diag = lambda k: (1.0 - dt * 0.0 - upper(k)) - lower(k - 1)                           # noqa: E731  ivd_diagonal(k)
+    I, J = slice(g.Hx, g.Hx + g.Nx), slice(g.Hy, g.Hy + g.Ny)
+    P = f.data
+    lev = lambda k: (I, J, Hz + k - 1)                                                    # noqa: E731
+    beta = diag(1)
+    P[lev(1)] = P[lev(1)] / beta
+    t = [0.0] * (Nz + 2)
+    for k in range(2, Nz + 1):
+        t[k] = upper(k - 1) / beta
+        beta = diag(k) - lower(k - 1) * t[k]
+        assert abs(beta) > 10 * np.finfo(float).eps
+        P[lev(k)] = (P[lev(k)] - lower(k - 1) * P[lev(k - 1)]) / beta
+    for k in range(Nz - 1, 0, -1):
+        P[lev(k)] = P[lev(k)] - t[k + 1] * P[lev(k + 1)]
+
+
 def ab2_step(st, dt, chi):
-    """ab2_step!(model::HydrostaticFreeSurfaceModel, dt, chi) (hydrostatic_free_surface_ab2_step.jl:15-48)"""
+    """ab2_step!(model::HydrostaticFreeSurfaceModel, dt, chi) (hydrostatic_free_surface_ab2_step.jl:15-48, :60-130): barotropic mode,
+    explicit steps of the velocities then their implicit vertical-diffusion solves, the same for the tracers, the free surface"""
     fs = st.free_surface
+    nu, kap = getattr(st, "closure", None) or (0.0, {})
     fs.barotropic_mode(fs.U, fs.V, st.u, st.v)             # local_ab2_step!: the barotropic mode of the velocities before the step
     for n in ("u", "v"):
         ab2_step_field(getattr(st, n), st.Gn[n], st.Gm[n], dt, chi)
+    for n in ("u", "v"):
+        implicit_step(getattr(st, n), nu, dt)
     for n, c in st.tracers.items():
         ab2_step_field(c, st.Gn[n], st.Gm[n], dt, chi)
+    for n, c in st.tracers.items():
+        implicit_step(c, kap.get(n, 0.0) if isinstance(kap, dict) else kap, dt)
     fs.step(st.Gn["u"], st.Gn["v"], st.Gm["u"], st.Gm["v"], dt, chi)
 
 

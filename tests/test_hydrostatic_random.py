@@ -51,8 +51,9 @@ def draw(seed):
     if R > 1 and ybounded and rng.random() < 0.5:
         overlap = int(rng.integers(1, nl + 1))
     substeps = int(rng.integers(3, 12))
+    closure = None if rng.random() < 0.5 else (float(rng.choice([0.0, 1e-2, 1.0])), {"T": float(rng.choice([0.0, 1e-3, 0.5])), "S": float(rng.choice([0.0, 2e-3]))})
     return dict(ctor=ctor, kw=kw, R=R, coriolis=coriolis, buoyancy=buoyancy, madv=madv, scheme=scheme, overlap=overlap, substeps=substeps,
-                ybounded=ybounded, seed=seed)
+                ybounded=ybounded, seed=seed, closure=closure)
 
 
 def fields_of(cfg):
@@ -72,7 +73,7 @@ def fields_of(cfg):
 def run_oracle(cfg, steps, dt):
     g = getattr(OS, cfg["ctor"])(**cfg["kw"])
     st = OH.HydrostaticState(g, tracers=("T", "S"), buoyancy=cfg["buoyancy"], substeps=cfg["substeps"], momentum_advection=cfg["madv"],
-                             coriolis=cfg["coriolis"], tracer_advection=cfg["scheme"])
+                             coriolis=cfg["coriolis"], tracer_advection=cfg["scheme"], closure=cfg["closure"])
     init = fields_of(cfg)
     st.u.set(init["u"]); st.v.set(init["v"]); st.free_surface.eta.set(init["eta"]); st.tracers["T"].set(init["T"]); st.tracers["S"].set(init["S"])
     OH.update_state(st)
@@ -86,7 +87,7 @@ def run_rank(ocn, ctx, r, cfg, steps, dt):
     R = cfg["R"]
     grid = getattr(H, cfg["ctor"])(arch=ctx, partition="y" if R > 1 else None, **cfg["kw"])
     st = H.HydrostaticState(grid, tracers=("T", "S"), buoyancy=cfg["buoyancy"], substeps=cfg["substeps"], momentum_advection=cfg["madv"],
-                            coriolis=cfg["coriolis"], tracer_advection=cfg["scheme"], barotropic_overlap=cfg["overlap"])
+                            coriolis=cfg["coriolis"], tracer_advection=cfg["scheme"], barotropic_overlap=cfg["overlap"], closure=cfg["closure"])
     init = fields_of(cfg)
     j0, nl = grid.j0, grid.Ny
     fg = st.free_surface.grid

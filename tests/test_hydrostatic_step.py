@@ -285,3 +285,69 @@ def test_entry_points_refuse_mismatched_fields(kind, ocn, backend):
     with pytest.raises(ocn.OcnError):                                  # pressures on another grid than the free surface's
         other = be.HRectilinearGrid(size=(8, 8, 4), x=(0, 1), y=(0, 1), z=(-1, 0), halo=(1, 1, 1), topology=(P, P, B))
         H.HydrostaticState(grid, tracers=(), free_surface=H.SplitExplicitFreeSurface(other, substeps=4))
+
+
+# ---- VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization()) ---------------------------------------------------------------
+@pytest.mark.parametrize("kind", KINDS)
+def test_implicit_vertical_diffusion_decays_a_cosine_mode_exactly(kind, ocn, backend):
+    """ANALYTIC: cos(pi z / L) is an eigenvector of the discrete no-flux operator d_z kappa d_z on a regular z grid, eigenvalue
+    -kappa (2 - 2 cos(pi dz / L)) / dz^2: one implicit step multiplies it by 1 / (1 + dt kappa lambda) in every column, and the column
+    integral of any profile is conserved (no flux through top and bottom); zero tendencies, no flow"""
+    be = _backend(kind, ocn, backend)
+    grid = be.LatitudeLongitudeGrid(size=(12, 8, 40), longitude=(-180, 180), latitude=(-60, 60), z=(-1000, 0), halo=(3, 3, 3))
+    st = be.H.HydrostaticState(grid, tracers=("T", "S"), buoyancy=None, substeps=4, closure=(1e-2, {"T": 1e-1, "S": 0.0}))
+    rng = np.random.default_rng(3)
+    st.tracers["T"].set(lambda x, y, z: np.cos(np.pi * z / 1000) + 0 * x + 0 * y)
+    st.tracers["S"].set(rng.standard_normal(st.tracers["S"].interior().shape))
+    st.u.set(lambda x, y, z: 0.1 * np.cos(np.pi * z / 1000) * np.cos(np.pi * y / 180) + 0 * x)
+    T0, S0, u0 = st.tracers["T"].interior().copy(), st.tracers["S"].interior().copy(), st.u.interior().copy()
+    be.H.update_state(st)
+    dt, dz = 1000.0, 25.0
+    lam = (2 - 2 * np.cos(np.pi * dz / 1000)) / dz ** 2
+    be.H.time_step_after_tendencies(st, dt, -0.5)                  # G^n = G^- = 0: only the implicit solves (and the free surface) act
+    T1, S1 = st.tracers["T"].interior(), st.tracers["S"].interior()
+    assert np.abs(T1 / T0 - 1 / (1 + dt * 1e-1 * lam)).max() < 1e-13
+    assert np.array_equal(S1, S0)                                   # kappa_S = 0: untouched
+    assert np.abs(T1.sum(axis=2) - T0.sum(axis=2)).max() < 1e-12
+    # u: the same mode with nu, then the barotropic correction adds a depth-independent velocity: compare the baroclinic parts
+    u1 = st.u.interior()
+    bc = lambda a: a - a.mean(axis=2, keepdims=True)                # noqa: E731
+    assert np.abs(bc(u1) - bc(u0) / (1 + dt * 1e-2 * lam)).max() < 1e-13 * np.abs(u0).max()
+
+
+CLOSURE_CASES = [("sphere", TS, ("T", "S"), (5e-3, {"T": 2e-3, "S": 1e-3})), ("channel", TS, ("S", "e", "T"), (1e-2, 3e-3)),
+                 ("sector", ("b", "b"), ("b",), (0.0, {"b": 4e-3}))]
+
+
+def _compare_closure(be, gridname, buoyancy, tracers, closure, fused):
+    states = []
+    for b in (be, OracleBackend):
+        _, st, _ = make_state(b, gridname, buoyancy=buoyancy, tracers=tracers)
+        if b is OracleBackend:
+            st.closure = closure
+        else:
+            st.set_closure(closure)
+        b.H.update_state(st)
+        for q in range(2):
+            b.H.time_step_after_tendencies(st, 400.0, -0.5 if q == 0 else 0.1, fused=fused)
+        states.append(st)
+    st, so = states
+    got, want = all_fields(st), all_fields(so)
+    exact = metrics_identical(st, gridname)
+    for k in want:
+        close(got[k], want[k], exact, f"{k} on {gridname} with implicit vertical diffusion")
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["sequence", "fused"])
+@pytest.mark.parametrize("gridname,buoyancy,tracers,closure", CLOSURE_CASES, ids=[c[0] for c in CLOSURE_CASES])
+def test_implicit_vertical_diffusion_matches_oracle_hostemu(gridname, buoyancy, tracers, closure, fused, ocn, backend):
+    if backend != "hostemu":
+        pytest.skip("host-emulation run only")
+    _compare_closure(LibBackend(ocn), gridname, buoyancy, tracers, closure, fused)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True], ids=["sequence", "fused"])
+@pytest.mark.parametrize("gridname,buoyancy,tracers,closure", CLOSURE_CASES, ids=[c[0] for c in CLOSURE_CASES])
+def test_implicit_vertical_diffusion_matches_oracle_gpu(gridname, buoyancy, tracers, closure, fused, ocn):
+    _compare_closure(LibBackend(ocn), gridname, buoyancy, tracers, closure, fused)
