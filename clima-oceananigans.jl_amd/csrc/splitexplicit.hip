@@ -726,12 +726,16 @@ __global__ void __launch_bounds__(256) k_hy_Guv(HyMetric g, HyPhys ph, const dou
                                                 const double* __restrict__ w, const double* __restrict__ p, double* __restrict__ Gu,
                                                 double* __restrict__ Gv, long syu, long szu, long syv, long szv, long syc, long szc) {
   OCN_NO_CONTRACT
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
-  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  // one thread per column marching upwards: the vertical-advection products of a level's upper face are kept for the next level (the
+  // upper face of level k IS the lower face of level k + 1: same operands, same bits), so along z every 3-D value comes from HBM once
+  // -- the one-thread-per-cell form pulled 2.2 times its algorithmic bytes through L2 (profiles/r03_pmc_config5.json)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
   const int r = OCN_UNIFORM(j + g.Hy);       // blockDim.x == 64: one row per wave
-  const long cu = (i + g.Hx) + (long)r * syu + (long)(k + g.Hz) * szu, cv = (i + g.Hx) + (long)r * syv + (long)(k + g.Hz) * szv;
-  const long cc = (i + g.Hx) + (long)r * syc + (long)(k + g.Hz) * szc;       // w and pHY' share the (Center, Center) row pitch
+  long cu = (i + g.Hx) + (long)r * syu + (long)g.Hz * szu, cv = (i + g.Hx) + (long)r * syv + (long)g.Hz * szv;
+  long cc = (i + g.Hx) + (long)r * syc + (long)g.Hz * szc;       // w and pHY' share the (Center, Center) row pitch
   const long szw = szc;
+  int k = 0;
   auto U = [&](int di, int dj, int dk) { return u[cu + di + dj * syu + dk * szu]; };
   auto V = [&](int di, int dj, int dk) { return v[cv + di + dj * syv + dk * szv]; };
   auto W = [&](int di, int dj, int dk) { return w[cc + di + dj * syc + dk * szw]; };
@@ -749,6 +753,18 @@ __global__ void __launch_bounds__(256) k_hy_Guv(HyMetric g, HyPhys ph, const dou
   auto Ix_dxv = [&](int dj) { return 0.5 * (g.dxcf[r + dj] * V(-1, dj, 0) + g.dxcf[r + dj] * V(0, dj, 0)); };
   auto Iy_dyu = [&](int di) { return 0.5 * (g.dyfc[r - 1] * U(di, -1, 0) + g.dyfc[r] * U(di, 0, 0)); };
   const double dxfc = g.dxfc[r], dycf = g.dycf[r], rdxfc = g.r_dxfc[r], rdycf = g.r_dycf[r];
+  auto z2w = [&](int dk) {
+    return (0.5 * (g.azcc[r] * W(-1, 0, dk) + g.azcc[r] * W(0, 0, dk))) * hy_div(U(0, 0, dk) - U(0, 0, dk - 1), g.dzf[k + dk], g.r_dzf[k + dk]);
+  };
+  auto z1w = [&](int dk) {
+    return (0.5 * (g.azcc[r - 1] * W(0, -1, dk) + g.azcc[r] * W(0, 0, dk))) * hy_div(V(0, 0, dk) - V(0, 0, dk - 1), g.dzf[k + dk], g.r_dzf[k + dk]);
+  };
+  double z2w_lo = 0.0, z1w_lo = 0.0;         // zeta_2 w and zeta_1 w at the lower face of the current level
+  if (ph.madv) {
+    z2w_lo = z2w(0);
+    z1w_lo = z1w(0);
+  }
+  for (; k < g.Nz; ++k, cu += szu, cv += szv, cc += szc) {
   double Au = 0.0, Av = 0.0;
   if (ph.madv) {
     double vvU, vvV;
@@ -783,14 +799,11 @@ __global__ void __launch_bounds__(256) k_hy_Guv(HyMetric g, HyPhys ph, const dou
         vvV = +(uhat * zi);
       }
     }
-    auto z2w = [&](int dk) {
-      return (0.5 * (g.azcc[r] * W(-1, 0, dk) + g.azcc[r] * W(0, 0, dk))) * hy_div(U(0, 0, dk) - U(0, 0, dk - 1), g.dzf[k + dk], g.r_dzf[k + dk]);
-    };
-    auto z1w = [&](int dk) {
-      return (0.5 * (g.azcc[r - 1] * W(0, -1, dk) + g.azcc[r] * W(0, 0, dk))) * hy_div(V(0, 0, dk) - V(0, 0, dk - 1), g.dzf[k + dk], g.r_dzf[k + dk]);
-    };
-    const double vaU = hy_div(0.5 * (z2w(0) + z2w(1)), g.azcc[r], g.r_azcc[r]);          // Az^fcc = Az^cc (regular x)
-    const double vaV = hy_div(0.5 * (z1w(0) + z1w(1)), g.azff[r], g.r_azff[r]);          // Az^cfc = Az^ff
+    const double z2w_hi = z2w(1), z1w_hi = z1w(1);
+    const double vaU = hy_div(0.5 * (z2w_lo + z2w_hi), g.azcc[r], g.r_azcc[r]);          // Az^fcc = Az^cc (regular x)
+    const double vaV = hy_div(0.5 * (z1w_lo + z1w_hi), g.azff[r], g.r_azff[r]);          // Az^cfc = Az^ff
+    z2w_lo = z2w_hi;
+    z1w_lo = z1w_hi;
     const double k00 = Kh(0, 0);
     const double bhU = hy_div(k00 - Kh(-1, 0), dxfc, rdxfc), bhV = hy_div(k00 - Kh(0, -1), dycf, rdycf);
     Au = (vvU + vaU) + bhU;
@@ -812,42 +825,62 @@ __global__ void __launch_bounds__(256) k_hy_Guv(HyMetric g, HyPhys ph, const dou
   const double px = hy_div(p[cc] - p[cc - 1], dxfc, rdxfc), py = hy_div(p[cc] - p[cc - syc], dycf, rdycf);
   Gu[cu] = ((-Au - 0.0) - Cu) - px;
   Gv[cv] = ((-Av - 0.0) - Cv) - py;
+  }
 }
 
-// NT tracers in one launch: the area-weighted velocities of the six faces are formed once and shared
+// NT tracers in one launch, one thread per column marching upwards: the area-weighted velocities of the faces are formed once and
+// shared by the tracers, a level's own values and its top flux stay in registers for the next level (the top flux of level k IS the
+// bottom flux of level k + 1: same operands, same bits), so every 3-D value is fetched once along z -- the one-thread-per-cell form
+// of this kernel pulled 2.1 times its algorithmic bytes through L2 (profiles/r03_pmc_config5.json), the levels above and below a
+// level being fetched again by other workgroups long after.
 template <int NT>
 __global__ void __launch_bounds__(256) k_hy_Gc(HyMetric g, const double* __restrict__ u, const double* __restrict__ v,
                                                const double* __restrict__ w, const double* __restrict__ c0, const double* __restrict__ c1,
                                                double* __restrict__ G0, double* __restrict__ G1, int tadv, long syu, long szu, long syv, long szv,
                                                long syc, long szc) {
   OCN_NO_CONTRACT
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
-  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
   const int r = OCN_UNIFORM(j + g.Hy);       // blockDim.x == 64: one row per wave
-  const long cu = (i + g.Hx) + (long)r * syu + (long)(k + g.Hz) * szu, cv = (i + g.Hx) + (long)r * syv + (long)(k + g.Hz) * szv;
-  const long cc = (i + g.Hx) + (long)r * syc + (long)(k + g.Hz) * szc;
+  long cu = (i + g.Hx) + (long)r * syu + (long)g.Hz * szu, cv = (i + g.Hx) + (long)r * syv + (long)g.Hz * szv;
+  long cc = (i + g.Hx) + (long)r * syc + (long)g.Hz * szc;
   if (!tadv) {
-    G0[cc] = 0.0;
-    if (NT > 1) G1[cc] = 0.0;
+    for (int k = 0; k < g.Nz; ++k, cc += szc) {
+      G0[cc] = 0.0;
+      if (NT > 1) G1[cc] = 0.0;
+    }
     return;
   }
-  const double dz = g.dzc[k];
-  const double ax0 = (g.dyfc[r] * dz) * u[cu], ax1 = (g.dyfc[r] * dz) * u[cu + 1];                  // Ax_q^fcc u at faces i, i + 1
-  const double ay0 = (g.dxcf[r] * dz) * v[cv], ay1 = (g.dxcf[r + 1] * dz) * v[cv + syv];            // Ay_q^cfc v at faces j, j + 1
-  const double az0 = g.azcc[r] * w[cc], az1 = g.azcc[r] * w[cc + szc];                              // Az_q^ccf w at faces k, k + 1
-  const double rv = 1 / (g.azcc[r] * dz);
+  const double dyfc = g.dyfc[r], dxcf0 = g.dxcf[r], dxcf1 = g.dxcf[r + 1], azcc = g.azcc[r];
+  double cm[NT], cc_[NT], fz0[NT];
+  double az0 = azcc * w[cc];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const double* c = t ? c1 : c0;
-    const double cm = c[cc];
-    const double fx0 = ax0 * (0.5 * (c[cc - 1] + cm)), fx1 = ax1 * (0.5 * (cm + c[cc + 1]));
-    const double fy0 = ay0 * (0.5 * (c[cc - syc] + cm)), fy1 = ay1 * (0.5 * (cm + c[cc + syc]));
-    const double fz0 = az0 * (0.5 * (c[cc - szc] + cm)), fz1 = az1 * (0.5 * (cm + c[cc + szc]));
-    const double div = rv * (((fx1 - fx0) + (fy1 - fy0)) + (fz1 - fz0));
-    (t ? G1 : G0)[cc] = -div;
+    cm[t] = c[cc - szc];
+    cc_[t] = c[cc];
+    fz0[t] = az0 * (0.5 * (cm[t] + cc_[t]));
+  }
+  for (int k = 0; k < g.Nz; ++k, cu += szu, cv += szv, cc += szc) {
+    const double dz = g.dzc[k];
+    const double ax0 = (dyfc * dz) * u[cu], ax1 = (dyfc * dz) * u[cu + 1];                    // Ax_q^fcc u at faces i, i + 1
+    const double ay0 = (dxcf0 * dz) * v[cv], ay1 = (dxcf1 * dz) * v[cv + syv];                // Ay_q^cfc v at faces j, j + 1
+    const double az1 = azcc * w[cc + szc];                                                    // Az_q^ccf w at face k + 1
+    const double rv = 1 / (azcc * dz);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const double* c = t ? c1 : c0;
+      const double cen = cc_[t], cup = c[cc + szc];
+      const double fx0 = ax0 * (0.5 * (c[cc - 1] + cen)), fx1 = ax1 * (0.5 * (cen + c[cc + 1]));
+      const double fy0 = ay0 * (0.5 * (c[cc - syc] + cen)), fy1 = ay1 * (0.5 * (cen + c[cc + syc]));
+      const double fz1 = az1 * (0.5 * (cen + cup));
+      const double div = rv * (((fx1 - fx0) + (fy1 - fy0)) + (fz1 - fz0[t]));
+      (t ? G1 : G0)[cc] = -div;
+      fz0[t] = fz1;
+      cc_[t] = cup;
+    }
   }
 }
-
 
 // higher-order flux-form tracer advection on these grids (CenteredFourthOrder, UpwindBiasedFifthOrder, WENO5 with Z weights): the
 // reconstructions of stencils.h (the Nonhydrostatic kernels' own, fast reciprocal and contraction included: parity with the oracle to
@@ -1223,7 +1256,7 @@ static void hydro_tendencies(ocn_hydro* h) {
   ph.yb = g->topo[1] != OCN_PERIODIC;
   ph.jrow0 = g->j0;
   ph.gNy = g->gNy;
-  ocn_launch(k_hy_Guv, gr, b, g->ctx->stream, hy_metric(g), ph, (const double*)u->d, (const double*)v->d, (const double*)h->w->d, (const double*)p->d,
+  ocn_launch(k_hy_Guv, dim3((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, 1), b, g->ctx->stream, hy_metric(g), ph, (const double*)u->d, (const double*)v->d, (const double*)h->w->d, (const double*)p->d,
              h->gn[0]->d, h->gn[1]->d, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)p->T[0],
              (long)p->T[0] * p->T[1]);
   for (size_t q = 0; q < h->c.size(); q += 2) {
@@ -1247,11 +1280,12 @@ static void hydro_tendencies(ocn_hydro* h) {
 #undef HY_GC_HI
       continue;
     }
+    const dim3 grc((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, 1);          // one thread per column
     if (two)
-      ocn_launch(k_hy_Gc<2>, gr, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d, c0, c1, G0, G1,
+      ocn_launch(k_hy_Gc<2>, grc, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d, c0, c1, G0, G1,
                  h->phys.tadv, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)p->T[0], (long)p->T[0] * p->T[1]);
     else
-      ocn_launch(k_hy_Gc<1>, gr, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d, c0, c1, G0, G1,
+      ocn_launch(k_hy_Gc<1>, grc, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d, c0, c1, G0, G1,
                  h->phys.tadv, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1], (long)p->T[0], (long)p->T[0] * p->T[1]);
   }
 }
