@@ -438,71 +438,94 @@ __global__ void k_se_substep1(SeArgs1 b) {
 }
 
 
-// Up to SE_MS substeps in ONE launch, interior cells only (Periodic x; y Periodic or Bounded; Nx >= 64, Ny >= 16).  A workgroup owns a
-// tile of (64 - 2 SE_MS) x (16 - 2 SE_MS) cells and carries a ring of SE_MS ghost cells around it: every thread keeps eta, U, V (and the
-// constants of its cell) in registers, the neighbours' values pass through LDS, and each substep spoils one more ring of ghosts from
-// the outside in -- after n <= SE_MS substeps the tile itself still holds exactly what n launches of k_se_substep1 would have left
-// (the same expressions on the same operands).  Per cell and substep that is 50 B of HBM traffic instead of 128, and a quarter of the
-// launches.  Halos are not touched: a train ends with one k_se_substep1, which writes every halo image the reference's fills leave.
-#define SE_MS 4
+// Up to G substeps in ONE launch, interior cells only (Periodic x; y Periodic or Bounded).  A workgroup of 64 x 16 threads, RPT rows per
+// thread, owns a tile of (64 - 2 G) x (16 RPT - 2 G) cells and carries a ring of G ghost cells around it: every thread keeps eta, U, V
+// (and the constants of its cells) in registers, the neighbours' values pass through LDS, and each substep spoils one more ring of ghosts
+// from the outside in -- after n <= G substeps the tile itself still holds exactly what n launches of k_se_substep1 would have left (the
+// same expressions on the same operands).  <4, 1>: 56 x 8 cells, 50 B of HBM traffic per cell and substep instead of 128, a quarter of
+// the launches (grids of 64 x 16 cells and more); <8, 2>: 48 x 16 cells, 28 B, an eighth (64 x 32 and more).  Halos are not touched: a
+// train ends with one k_se_substep1, which writes every halo image the reference's fills leave.
+#define SE_MS 8                      // the most substeps a launch takes
 struct SeArgsM {
   SeArgs1 b;
   int nsub;
   double wv[SE_MS], wf[SE_MS];
 };
+template <int G, int RPT>
 __global__ void __launch_bounds__(1024) k_se_multi(SeArgsM m) {
   OCN_NO_CONTRACT
-  constexpr int BX = 64, BY = 16, G = SE_MS, TX = BX - 2 * G, TY = BY - 2 * G;
-  OCN_SHARED double sE[BY * (BX + 1)], sU[BY * (BX + 1)], sV[BY * (BX + 1)];
+  constexpr int BX = 64, BY = 16 * RPT, TX = BX - 2 * G, TY = BY - 2 * G, LS = BX + 1;
+  OCN_SHARED double sE[BY * LS], sU[BY * LS], sV[BY * LS];
   const SeArgs& a = m.b.a;
-  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tx = threadIdx.x;
   const int Nx = a.Nx, Ny = a.Ny, Hx = a.Hx, Hy = a.Hy;
-  const int i = (int)blockIdx.x * TX + tx - G, j = (int)blockIdx.y * TY + ty - G;
-  int gi = i < 0 ? i + Nx : (i >= Nx ? i - Nx : i);                 // Periodic x (Nx >= BX: one wrap is enough)
-  int gj = j;
-  bool rowok = true;
-  if (a.yper) gj = j < 0 ? j + Ny : (j >= Ny ? j - Ny : j);
-  else rowok = j >= 0 && j < Ny;
-  if (!rowok) gj = j < 0 ? 0 : Ny - 1;                              // any valid row: the loads below stay in bounds, the values are dropped
-  const bool own = tx >= G && tx < G + TX && ty >= G && ty < G + TY && i < Nx && j < Ny;
-  const int r = OCN_UNIFORM(gj + Hy);
-  const long cu = (gi + Hx) + (long)r * a.su, cv = (gi + Hx) + (long)r * a.sv, ce = (gi + Hx) + (long)r * a.se;
-  double e = m.b.etaI[ce], u = m.b.UI[cu], v = m.b.VI[cv];
-  const double hfc = a.Hfc[cu], hcf = a.Hcf[cv], gu = a.GU[cu], gv = a.GV[cv];
-  const double dxfc = a.dxfc[r], dycf = a.dycf[r], dyfc = a.dyfc[r], dxcf0 = a.dxcf[r], dxcf1 = a.dxcf[r + 1], azcc = a.azcc[r];
-  const double rdxfc = a.r_dxfc[r], rdycf = a.r_dycf[r];
-  double ub = 0, vb = 0, eb = 0;
-  if (own) { ub = a.Ubar[cu]; vb = a.Vbar[cv]; eb = a.etabar[ce]; }
-  if (!rowok) { e = 0.0; u = 0.0; v = 0.0; }
-  const bool south_face = !a.yper && j == 0;                        // the impenetrable face of the southern wall
-  const int me = ty * (BX + 1) + tx;
-  const int west = tx > 0 ? me - 1 : me, south = ty > 0 ? me - (BX + 1) : me;
-  const int east = tx + 1 < BX ? me + 1 : me, north = ty + 1 < BY ? me + (BX + 1) : me;
-  for (int q = 0; q < m.nsub; ++q) {
-    sE[me] = e;
-    __syncthreads();
-    const double ew = sE[west], es = sE[south];
-    u = u + a.dtau * (-a.g * hfc * hy_div(e - ew, dxfc, rdxfc) + gu);
-    v = v + a.dtau * (-a.g * hcf * hy_div(e - es, dycf, rdycf) + gv);
-    if (south_face || !rowok) v = 0.0;                              // rows beyond a wall hold V = 0: the wall's north / south face
-    sU[me] = u;
-    sV[me] = v;
-    __syncthreads();
-    const double ue = sU[east], vn = sV[north];
-    const double div = 1.0 / azcc * ((dyfc * ue - dyfc * u) + (dxcf1 * vn - dxcf0 * v));
-    e = e - a.dtau * div;
-    ub += m.wv[q] * u;
-    vb += m.wv[q] * v;
-    eb += m.wf[q] * e;
+  const int i = (int)blockIdx.x * TX + tx - G;
+  const int gi = i < 0 ? i + Nx : (i >= Nx ? i - Nx : i);           // Periodic x (Nx >= BX: one wrap is enough)
+  double e[RPT], u[RPT], v[RPT], hfc[RPT], hcf[RPT], gu[RPT], gv[RPT], ub[RPT], vb[RPT], eb[RPT];
+  double dxfc[RPT], dycf[RPT], dyfc[RPT], dxcf0[RPT], dxcf1[RPT], azcc[RPT], rdxfc[RPT], rdycf[RPT];
+  long cu[RPT], cv[RPT], ce[RPT];
+  bool own[RPT], rowok[RPT], south_face[RPT];
+  int me[RPT], west[RPT], south[RPT], east[RPT], north[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int ty = threadIdx.y + 16 * q;
+    const int j = (int)blockIdx.y * TY + ty - G;
+    int gj = j;
+    rowok[q] = true;
+    if (a.yper) gj = j < 0 ? j + Ny : (j >= Ny ? j - Ny : j);
+    else rowok[q] = j >= 0 && j < Ny;
+    if (!rowok[q]) gj = j < 0 ? 0 : Ny - 1;                         // any valid row: the loads below stay in bounds, the values are dropped
+    own[q] = tx >= G && tx < G + TX && ty >= G && ty < G + TY && i < Nx && j < Ny;
+    const int r = OCN_UNIFORM(gj + Hy);
+    cu[q] = (gi + Hx) + (long)r * a.su; cv[q] = (gi + Hx) + (long)r * a.sv; ce[q] = (gi + Hx) + (long)r * a.se;
+    e[q] = m.b.etaI[ce[q]]; u[q] = m.b.UI[cu[q]]; v[q] = m.b.VI[cv[q]];
+    hfc[q] = a.Hfc[cu[q]]; hcf[q] = a.Hcf[cv[q]]; gu[q] = a.GU[cu[q]]; gv[q] = a.GV[cv[q]];
+    dxfc[q] = a.dxfc[r]; dycf[q] = a.dycf[r]; dyfc[q] = a.dyfc[r]; dxcf0[q] = a.dxcf[r]; dxcf1[q] = a.dxcf[r + 1]; azcc[q] = a.azcc[r];
+    rdxfc[q] = a.r_dxfc[r]; rdycf[q] = a.r_dycf[r];
+    ub[q] = vb[q] = eb[q] = 0.0;
+    if (own[q]) { ub[q] = a.Ubar[cu[q]]; vb[q] = a.Vbar[cv[q]]; eb[q] = a.etabar[ce[q]]; }
+    if (!rowok[q]) { e[q] = 0.0; u[q] = 0.0; v[q] = 0.0; }
+    south_face[q] = !a.yper && j == 0;                              // the impenetrable face of the southern wall
+    me[q] = ty * LS + tx;
+    west[q] = tx > 0 ? me[q] - 1 : me[q];
+    south[q] = ty > 0 ? me[q] - LS : me[q];
+    east[q] = tx + 1 < BX ? me[q] + 1 : me[q];
+    north[q] = ty + 1 < BY ? me[q] + LS : me[q];
   }
-  if (own) {
-    m.b.etaO[ce] = e;
-    m.b.UO[cu] = u;
-    m.b.VO[cv] = v;
-    a.Ubar[cu] = ub;
-    a.Vbar[cv] = vb;
-    a.etabar[ce] = eb;
+  for (int n = 0; n < m.nsub; ++n) {
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) sE[me[q]] = e[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const double ew = sE[west[q]], es = sE[south[q]];
+      u[q] = u[q] + a.dtau * (-a.g * hfc[q] * hy_div(e[q] - ew, dxfc[q], rdxfc[q]) + gu[q]);
+      v[q] = v[q] + a.dtau * (-a.g * hcf[q] * hy_div(e[q] - es, dycf[q], rdycf[q]) + gv[q]);
+      if (south_face[q] || !rowok[q]) v[q] = 0.0;                   // rows beyond a wall hold V = 0: the wall's north / south face
+      sU[me[q]] = u[q];
+      sV[me[q]] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const double ue = sU[east[q]], vn = sV[north[q]];
+      const double div = 1.0 / azcc[q] * ((dyfc[q] * ue - dyfc[q] * u[q]) + (dxcf1[q] * vn - dxcf0[q] * v[q]));
+      e[q] = e[q] - a.dtau * div;
+      ub[q] += m.wv[n] * u[q];
+      vb[q] += m.wv[n] * v[q];
+      eb[q] += m.wf[n] * e[q];
+    }
   }
+#pragma unroll
+  for (int q = 0; q < RPT; ++q)
+    if (own[q]) {
+      m.b.etaO[ce[q]] = e[q];
+      m.b.UO[cu[q]] = u[q];
+      m.b.VO[cv[q]] = v[q];
+      a.Ubar[cu[q]] = ub[q];
+      a.Vbar[cv[q]] = vb[q];
+      a.etabar[ce[q]] = eb[q];
+    }
 }
 
 // ---- vertical integrals and the corrector ----------------------------------------------------------------------------------
@@ -1018,7 +1041,13 @@ static void sefs_substep_one(ocn_sefs* s, double dtau, int index, int flip) {
   q.etaO = flip ? s->eta->d : s->eta2; q.UO = flip ? s->U->d : s->U2; q.VO = flip ? s->V->d : s->V2;
   ocn_launch(k_se_substep1, gr, b, s->g->ctx->stream, q);
 }
-// substeps index .. index + n - 1 (n <= SE_MS) in one launch, interior cells only
+// the most substeps one launch takes on this grid: 8 (tiles of 48 x 16, two rows per thread) from 64 x 32 cells up, else 4 (56 x 8)
+static int sefs_multi_width(const ocn_sefs* s) {
+  static const int forced = getenv("OCNHIP_SE_MULTI") ? atoi(getenv("OCNHIP_SE_MULTI")) : 0;     // 4 or 8: measurement knob
+  if (forced == 4 || s->g->N[1] < 32) return 4;
+  return 8;
+}
+// substeps index .. index + n - 1 (n <= sefs_multi_width) in one launch, interior cells only
 static void sefs_substep_multi(ocn_sefs* s, double dtau, int index, int n, int flip) {
   const ocn_hgrid* g = s->g;
   SeArgsM m;
@@ -1030,8 +1059,13 @@ static void sefs_substep_multi(ocn_sefs* s, double dtau, int index, int n, int f
     m.wv[q] = q < n ? s->wv[index - 1 + q] : 0.0;
     m.wf[q] = q < n ? s->wf[index - 1 + q] : 0.0;
   }
-  constexpr int TX = 64 - 2 * SE_MS, TY = 16 - 2 * SE_MS;
-  ocn_launch_sync(k_se_multi, dim3((g->N[0] + TX - 1) / TX, (g->N[1] + TY - 1) / TY, 1), dim3(64, 16, 1), g->ctx->stream, m);
+  if (sefs_multi_width(s) == 8) {
+    constexpr int TX = 64 - 16, TY = 32 - 16;
+    ocn_launch_sync(k_se_multi<8, 2>, dim3((g->N[0] + TX - 1) / TX, (g->N[1] + TY - 1) / TY, 1), dim3(64, 16, 1), g->ctx->stream, m);
+  } else {
+    constexpr int TX = 64 - 8, TY = 16 - 8;
+    ocn_launch_sync(k_se_multi<4, 1>, dim3((g->N[0] + TX - 1) / TX, (g->N[1] + TY - 1) / TY, 1), dim3(64, 16, 1), g->ctx->stream, m);
+  }
 }
 static bool sefs_multi_ok(const ocn_sefs* s) { return sefs_fusable(s) && s->g->N[0] >= 64 && s->g->N[1] >= 16; }
 static void se_copy(ocn_ctx* ctx, double* dst, const double* src, size_t n) {
@@ -1696,8 +1730,9 @@ int ocn_sefs_substeps(ocn_sefs* s, double dtau, int first_index, int count, int 
       if (multi) {
         // all but the last substep SE_MS at a time (interior cells), the last one by the one-substep kernel, which also writes the halos
         int q = 0;
+        const int width = sefs_multi_width(s);
         while (q < count - 1) {
-          const int n = count - 1 - q < SE_MS ? count - 1 - q : SE_MS;
+          const int n = count - 1 - q < width ? count - 1 - q : width;
           sefs_substep_multi(s, dtau, first_index + q, n, launches & 1);
           q += n;
           ++launches;

@@ -319,12 +319,13 @@ def test_step_on_the_sphere_matches_oracle(kind, ocn, backend):
         assert np.abs(x - y).max() <= 1e-12 * np.abs(x).max()
 
 
-@pytest.mark.parametrize("size", [(40, 24), (72, 20), pytest.param((200, 90), marks=pytest.mark.gpu)], ids=["40x24", "72x20", "200x90"])
+@pytest.mark.parametrize("size", [(40, 24), (72, 20), (66, 34), pytest.param((200, 90), marks=pytest.mark.gpu)],
+                         ids=["40x24", "72x20", "66x34", "200x90"])
 @pytest.mark.parametrize("topo_y", [P, B])
 @pytest.mark.parametrize("kind", ["hostemu", pytest.param("gpu", marks=pytest.mark.gpu)])
 def test_fused_train_is_bitwise_the_plain_substeps(kind, topo_y, size, ocn, backend):
-    """ocn_sefs_substeps(fused = 1, 2, 3) -- two launches per substep, one launch per substep, four substeps per launch (tiles with
-    ghost rings; from 64 x 16 cells up: 72 x 20 and 200 x 90 have ragged last tiles), replayed from hipGraphs on the GPU -- leave exactly the bits
+    """ocn_sefs_substeps(fused = 1, 2, 3) -- two launches per substep, one launch per substep, four or eight substeps per launch (tiles with
+    ghost rings; four from 64 x 16 cells up, eight from 64 x 32 up: 72 x 20, 66 x 34 and 200 x 90 have ragged last tiles), replayed from hipGraphs on the GPU -- leave exactly the bits
     of the reference's five-launch substeps in every parent array, halos included (periodic and wall-bounded y)"""
     be = _backend(kind, ocn, backend)
     out = []
