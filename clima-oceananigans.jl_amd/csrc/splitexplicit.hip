@@ -909,35 +909,45 @@ __global__ void __launch_bounds__(256) k_hy_Gc(HyMetric g, const double* __restr
 // reconstructions of stencils.h (the Nonhydrostatic kernels' own, fast reciprocal and contraction included: parity with the oracle to
 // round-off, not to the bit) times the area-weighted face velocities; upwind_biased_product(Ax u, c^L, c^R) = (Ax u) c^upwind;
 // inside the boundary buffer of a Bounded direction the second-order fallback (topologically_conditional_interpolation.jl:19-83).
-// On a latitude band the buffer test uses the GLOBAL row (jrow0 + j) and row count.  One thread per cell: every face flux is
-// formed twice (by the two cells it separates) -- the general kernel, not a tiled one.
+// On a latitude band the buffer test uses the GLOBAL row (jrow0 + j) and row count.  One thread per column, the vertical flux reused
+// from level to level; the x and y face fluxes are still formed twice (by the two cells they separate) -- not a tiled kernel.
 template <int ADV, int NT>
 __global__ void __launch_bounds__(256) k_hy_Gc_hi(HyMetric g, const double* __restrict__ u, const double* __restrict__ v,
                                                   const double* __restrict__ w, const double* __restrict__ c0, const double* __restrict__ c1,
                                                   double* __restrict__ G0, double* __restrict__ G1, int xb, int yb, int jrow0, int gNy, long syu,
                                                   long szu, long syv, long szv, long syc, long szc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
-  if (i >= g.Nx || j >= g.Ny || k >= g.Nz) return;
+  // one thread per column marching upwards: the flux through a level's upper face is kept for the next level
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= g.Nx || j >= g.Ny) return;
   constexpr int NB = ADV == ADV_C4 ? 1 : 2;                       // boundary_buffer of the scheme
   const int r = OCN_UNIFORM(j + g.Hy);       // blockDim.x == 64: one row per wave
-  const long cu = (i + g.Hx) + (long)r * syu + (long)(k + g.Hz) * szu, cv = (i + g.Hx) + (long)r * syv + (long)(k + g.Hz) * szv;
-  const long cc = (i + g.Hx) + (long)r * syc + (long)(k + g.Hz) * szc;
-  const double dz = g.dzc[k];
-  const double ax0 = (g.dyfc[r] * dz) * u[cu], ax1 = (g.dyfc[r] * dz) * u[cu + 1];
-  const double ay0 = (g.dxcf[r] * dz) * v[cv], ay1 = (g.dxcf[r + 1] * dz) * v[cv + syv];
-  const double az0 = g.azcc[r] * w[cc], az1 = g.azcc[r] * w[cc + szc];
-  const double rv = 1 / (g.azcc[r] * dz);
+  long cu = (i + g.Hx) + (long)r * syu + (long)g.Hz * szu, cv = (i + g.Hx) + (long)r * syv + (long)g.Hz * szv;
+  long cc = (i + g.Hx) + (long)r * syc + (long)g.Hz * szc;
+  const double dyfc = g.dyfc[r], dxcf0 = g.dxcf[r], dxcf1 = g.dxcf[r + 1], azcc = g.azcc[r];
   const int jg = jrow0 + j;
+  double fz0[NT];
+  {
+    const double az0 = azcc * w[cc];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const double* c = (t ? c1 : c0) + cc;
-    const double fx0 = adv_flux_b<ADV>(c, 1, ax0, xb != 0, i + 1, g.Nx, NB), fx1 = adv_flux_b<ADV>(c + 1, 1, ax1, xb != 0, i + 2, g.Nx, NB);
-    const double fy0 = adv_flux_b<ADV>(c, syc, ay0, yb != 0, jg + 1, gNy, NB), fy1 = adv_flux_b<ADV>(c + syc, syc, ay1, yb != 0, jg + 2, gNy, NB);
-    const double fz0 = adv_flux_b<ADV>(c, szc, az0, true, k + 1, g.Nz, NB), fz1 = adv_flux_b<ADV>(c + szc, szc, az1, true, k + 2, g.Nz, NB);
-    (t ? G1 : G0)[cc] = -(rv * (((fx1 - fx0) + (fy1 - fy0)) + (fz1 - fz0)));
+    for (int t = 0; t < NT; ++t) fz0[t] = adv_flux_b<ADV>((t ? c1 : c0) + cc, szc, az0, true, 1, g.Nz, NB);
+  }
+  for (int k = 0; k < g.Nz; ++k, cu += szu, cv += szv, cc += szc) {
+    const double dz = g.dzc[k];
+    const double ax0 = (dyfc * dz) * u[cu], ax1 = (dyfc * dz) * u[cu + 1];
+    const double ay0 = (dxcf0 * dz) * v[cv], ay1 = (dxcf1 * dz) * v[cv + syv];
+    const double az1 = azcc * w[cc + szc];
+    const double rv = 1 / (azcc * dz);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const double* c = (t ? c1 : c0) + cc;
+      const double fx0 = adv_flux_b<ADV>(c, 1, ax0, xb != 0, i + 1, g.Nx, NB), fx1 = adv_flux_b<ADV>(c + 1, 1, ax1, xb != 0, i + 2, g.Nx, NB);
+      const double fy0 = adv_flux_b<ADV>(c, syc, ay0, yb != 0, jg + 1, gNy, NB), fy1 = adv_flux_b<ADV>(c + syc, syc, ay1, yb != 0, jg + 2, gNy, NB);
+      const double fz1 = adv_flux_b<ADV>(c + szc, szc, az1, true, k + 2, g.Nz, NB);
+      (t ? G1 : G0)[cc] = -(rv * (((fx1 - fx0) + (fy1 - fy0)) + (fz1 - fz0[t])));
+      fz0[t] = fz1;
+    }
   }
 }
-
 
 // implicit_step! for VerticalScalarDiffusivity(VerticallyImplicitTimeDiscretization(); nu, kappa) with constant coefficients
 // (vertically_implicit_diffusion_solver.jl:46-100, Solvers/batched_tridiagonal_solver.jl:89-121): the tridiagonal coefficients depend on
@@ -1301,13 +1311,14 @@ static void hydro_tendencies(ocn_hydro* h) {
     if (tadv >= 2) {
       // CenteredFourthOrder / UpwindBiasedFifthOrder / WENO5
       const int xb = g->topo[0] != OCN_PERIODIC, yb = g->topo[1] != OCN_PERIODIC;
+      const dim3 grh((g->N[0] + 63) / 64, (g->N[1] + 3) / 4, 1);          // one thread per column
 #define HY_GC_HI(ADVV)                                                                                                                     \
   if (two)                                                                                                                                 \
-    ocn_launch(k_hy_Gc_hi<ADVV, 2>, gr, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d,  \
+    ocn_launch(k_hy_Gc_hi<ADVV, 2>, grh, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d,  \
                c0, c1, G0, G1, xb, yb, g->j0, g->gNy, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1],        \
                (long)p->T[0], (long)p->T[0] * p->T[1]);                                                                                    \
   else                                                                                                                                     \
-    ocn_launch(k_hy_Gc_hi<ADVV, 1>, gr, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d,  \
+    ocn_launch(k_hy_Gc_hi<ADVV, 1>, grh, b, g->ctx->stream, hy_metric(g), (const double*)u->d, (const double*)v->d, (const double*)h->w->d,  \
                c0, c1, G0, G1, xb, yb, g->j0, g->gNy, (long)u->T[0], (long)u->T[0] * u->T[1], (long)v->T[0], (long)v->T[0] * v->T[1],        \
                (long)p->T[0], (long)p->T[0] * p->T[1]);
       if (tadv == 2) { HY_GC_HI(ADV_C4) } else if (tadv == 3) { HY_GC_HI(ADV_U5) } else { HY_GC_HI(ADV_WENO_Z) }
