@@ -646,17 +646,28 @@ __global__ void k_hy_pressure(HyGrid g, HyBuoy q, const double* T, const double*
   }
 }
 
+// per-level tables of the vertically implicit diffusion solve (k_hy_implicit below explains them)
+struct HyImp {
+  const double *a, *beta, *rbeta, *t;      // a[k]: lower diagonal below level k + 1 (0-based k = 0..Nz-2); beta[k], t[k]: level k
+};
+
 // fused pass over one velocity component: the barotropic mode of the velocity before the step (-> U), the vertical integral of
 // the AB2 tendency (-> G^U), the AB2 step, the barotropic mode of the stepped velocity (-> Un, for the corrector) and G^- <- G^n;
 // sums over the field's interior (incl. the boundary face of a Bounded direction), the step over the grid's cells
 __global__ void k_hy_momentum(double* u, const double* gn, double* gm, double* U, double* GU, double* Un, double dt, double cn, double cm,
-                              const double* dzc, int Sx, int Sy, int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, long sy3, long sz3, long sy2) {
+                              const double* dzc, int Sx, int Sy, int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, long sy3, long sz3, long sy2,
+                              HyImp imp, int implicit) {
   OCN_NO_CONTRACT
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= Sx || j >= Sy) return;
   const bool step = i < Nx && j < Ny;
-  long c = (i + Hx) + (long)(j + Hy) * sy3 + (long)Hz * sz3;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  const long c0 = (i + Hx) + (long)(j + Hy) * sy3 + (long)Hz * sz3;
+  long c = c0;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, phi = 0.0;
+  // implicit (a vertically implicit viscosity): the stepped value is the right-hand side of the column's tridiagonal system, so the
+  // forward elimination rides in this pass (phi_k = (u*_k - a_{k-1} phi_{k-1}) / beta_k), the back substitution and the barotropic
+  // mode of the solved column follow below -- two sweeps fewer than stepping, solving and summing in three kernels
+  const bool imp_on = implicit && step;
   for (int k = 0; k < Nz; ++k, c += sz3) {
     const double uo = u[c], n = gn[c], m = gm[c], dz = dzc[k];
     const double G = cn * n - cm * m;
@@ -665,14 +676,56 @@ __global__ void k_hy_momentum(double* u, const double* gn, double* gm, double* U
     a1 = k == 0 ? G * dz : a1 + G * dz;
     a2 = k == 0 ? un * dz : a2 + un * dz;
     if (step) {
-      u[c] = un;
+      if (imp_on) {
+        phi = k == 0 ? hy_div(un, imp.beta[0], imp.rbeta[0]) : hy_div(un - imp.a[k - 1] * phi, imp.beta[k], imp.rbeta[k]);
+        u[c] = phi;
+      } else {
+        u[c] = un;
+      }
       gm[c] = n;
+    }
+  }
+  if (imp_on) {
+    c = c0 + (long)(Nz - 1) * sz3;
+    for (int k = Nz - 2; k >= 0; --k) {
+      c -= sz3;
+      phi = u[c] - imp.t[k + 1] * phi;
+      u[c] = phi;
+    }
+    c = c0;
+    for (int k = 0; k < Nz; ++k, c += sz3) {
+      const double q = u[c] * dzc[k];
+      a2 = k == 0 ? q : a2 + q;
     }
   }
   const long c2 = (i + Hx) + (long)(j + Hy) * sy2;
   U[c2] = a0;
   GU[c2] = a1;
   Un[c2] = a2;
+}
+
+// AB2 step, G^- <- G^n and the vertically implicit diffusion solve of one field in one kernel: up the column the stepped value feeds the
+// forward elimination directly, down the column the back substitution (seven sweeps instead of nine for k_hy_ab2_store + k_hy_implicit)
+__global__ void k_hy_ab2_implicit(double* f, const double* gn, double* gm, double dt, double cn, double cm, HyImp imp, int Nx, int Ny, int Nz,
+                                  int Hx, int Hy, int Hz, long sy, long sz) {
+  OCN_NO_CONTRACT
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= Nx || j >= Ny) return;
+  long c = (i + Hx) + (long)(j + Hy) * sy + (long)Hz * sz;
+  double phi = 0.0;
+  for (int k = 0; k < Nz; ++k, c += sz) {
+    const double n = gn[c];
+    const double cs = hy_ab2(f[c], n, gm[c], dt, cn, cm);
+    gm[c] = n;
+    phi = k == 0 ? hy_div(cs, imp.beta[0], imp.rbeta[0]) : hy_div(cs - imp.a[k - 1] * phi, imp.beta[k], imp.rbeta[k]);
+    f[c] = phi;
+  }
+  c -= sz;
+  for (int k = Nz - 2; k >= 0; --k) {
+    c -= sz;
+    phi = f[c] - imp.t[k + 1] * phi;
+    f[c] = phi;
+  }
 }
 
 // fused pass over the tracers that make the buoyancy (one or two), marching downwards: AB2 step, G^- <- G^n, and the hydrostatic
@@ -954,9 +1007,6 @@ __global__ void __launch_bounds__(256) k_hy_Gc_hi(HyMetric g, const double* __re
 // the level only, so the pivots beta_k and the multipliers t_k of the modified Thomas algorithm are tabulated once per (kappa, dt) on
 // the host -- the very numbers every column of the reference's solver computes -- and a thread only substitutes: up the column
 // phi_k = (f_k - a_{k-1} phi_{k-1}) / beta_k (the division through beta's correctly rounded reciprocal), down phi_k -= t_{k+1} phi_{k+1}.
-struct HyImp {
-  const double *a, *beta, *rbeta, *t;      // a[k]: lower diagonal below level k + 1 (0-based k = 0..Nz-2); beta[k], t[k]: level k
-};
 __global__ void k_hy_implicit(double* f, HyImp c, int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, long sy, long sz) {
   OCN_NO_CONTRACT
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
@@ -2038,25 +2088,16 @@ int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fus
   }
   const double cn = 1.5 + chi, cm = 0.5 + chi;
   dim3 blk(64, 4, 1);
+  const bool implicit = hydro_has_implicit(h);
+  HyImp impv{nullptr, nullptr, nullptr, nullptr};
+  const int visc = implicit && h->kap[0] != 0.0;
+  if (visc && (rc = hydro_imp_table(h, h->kap[0], dt, &impv))) return api_done(ctx, rc);
   for (int q = 0; q < 2; ++q) {
     ocn_hfield *f = q ? h->v : h->u, *U = q ? s->V : s->U, *GU = q ? s->GV : s->GU;
     const long off = q ? h->offV : h->offU;
     ocn_launch(k_hy_momentum, dim3((f->S[0] + 63) / 64, (f->S[1] + 3) / 4, 1), blk, ctx->stream, f->d, (const double*)h->gn[q]->d, h->gm[q]->d, U->d + off,
                GU->d + off, (q ? h->Vn : h->Un) + off, dt, cn, cm, (const double*)g->dzc, f->S[0], f->S[1], g->N[0], g->N[1], g->N[2], g->H[0], g->H[1],
-               g->H[2], (long)f->T[0], (long)f->T[0] * f->T[1], (long)U->T[0]);
-  }
-  const bool implicit = hydro_has_implicit(h);
-  if (implicit && h->kap[0] != 0.0) {
-    // the implicit vertical-viscosity solves follow the explicit steps; the barotropic mode of the stepped velocities (for the corrector)
-    // is then summed again from the solved columns
-    if ((rc = hydro_implicit(h, h->u, 0, dt)) || (rc = hydro_implicit(h, h->v, 0, dt))) return api_done(ctx, rc);
-    for (int q = 0; q < 2; ++q) {
-      ocn_hfield* f = q ? h->v : h->u;
-      ocn_hfield* U = q ? s->V : s->U;
-      dim3 vb(64, 4, 1), vg((f->S[0] + 63) / 64, (f->S[1] + 3) / 4, 1);
-      ocn_launch(k_se_vsum, vg, vb, ctx->stream, (q ? h->Vn : h->Un) + (q ? h->offV : h->offU), (const double*)f->d, (const double*)nullptr, 0.0, 0.0,
-                 (const double*)g->dzc, f->S[0], f->S[1], g->N[2], g->H[0], g->H[1], g->H[2], (long)f->T[0], (long)f->T[0] * f->T[1], (long)U->T[0]);
-    }
+               g->H[2], (long)f->T[0], (long)f->T[0] * f->T[1], (long)U->T[0], impv, visc);
   }
   if ((rc = hydro_allgather_rows(h))) return api_done(ctx, rc);
   hfield_fill(s->U);
@@ -2073,12 +2114,20 @@ int ocn_hydro_step_after_tendencies(ocn_hydro* h, double dt, double chi, int fus
                  (long)T->T[0], (long)T->T[0] * T->T[1]);
       pressure_done = true;
     } else {
-      hy_ab2_launch(h->c[q], h->gn[2 + q], h->gm[2 + q], dt, chi, true);
+      if (implicit && h->kap[1 + q] != 0.0) {
+        // explicit step, G^- <- G^n and the implicit solve in one kernel; the hydrostatic pressure then comes from update_state!'s kernel
+        HyImp it;
+        if ((rc = hydro_imp_table(h, h->kap[1 + q], dt, &it))) return api_done(ctx, rc);
+        dim3 b2, g2;
+        hy_cols(g, b2, g2);
+        ocn_hfield* f = h->c[q];
+        ocn_launch(k_hy_ab2_implicit, g2, b2, ctx->stream, f->d, (const double*)h->gn[2 + q]->d, h->gm[2 + q]->d, dt, cn, cm, it, g->N[0], g->N[1], g->N[2],
+                   g->H[0], g->H[1], g->H[2], (long)f->T[0], (long)f->T[0] * f->T[1]);
+      } else {
+        hy_ab2_launch(h->c[q], h->gn[2 + q], h->gm[2 + q], dt, chi, true);
+      }
     }
   }
-  if (implicit)          // the tracers' implicit solves; the hydrostatic pressure then comes from update_state!'s own kernel
-    for (size_t q = 0; q < h->c.size(); ++q)
-      if ((rc = hydro_implicit(h, h->c[q], 1 + (int)q, dt))) return api_done(ctx, rc);
   // the free surface: G^U, G^V are in place
   for (ocn_hfield* f : {s->etabar, s->Ubar, s->Vbar}) OCN_ASYNC(hipMemsetAsync(f->d, 0, f->n * sizeof(double), ctx->stream));
   if ((rc = sefs_step_tail(s, dt))) return api_done(ctx, rc);
